@@ -1,0 +1,717 @@
+// Attention kernels.
+//   attn_global_*  : SelfAttention core (model.py:241-257, 353-367): RoPE on q,k (rope.py:25-53),
+//                    q / sqrt(64), softmax in fp32, optional weight dropout, P.V — flash-style,
+//                    QK^T and PV on the matrix cores (16x16 MFMA tiles), online softmax in registers.
+//   attn_local_*   : LocalSelfAttention (model.py:409-471): 16-token windows, stride 8,
+//                    window-relative RoPE, outputs averaged over the covering windows with the
+//                    reference's padded-coordinate scatter (out[j] <- padded position j).
+//
+// Inputs are the raw projections: q = QC[:, h*64 ..], k = KV[:, h*64 ..], v = KV[:, 256 + h*64 ..].
+// RoPE is applied while staging (and its transpose while writing dq/dk), so no separate RoPE pass
+// ever touches HBM.
+//
+// MFMA orientation ("transposed" form): every product is computed as D^T so that a lane owns ONE
+// query (or one key in the dK/dV kernel) = lane & 15, and its 4 accumulator registers are 4
+// consecutive head-dim features: row statistics are two xor-shuffles, outputs are 8-byte vectors.
+#include "common.h"
+#include "kernels.h"
+
+namespace amt {
+
+constexpr int ALD = 72;   // LDS row stride (elements) of the [64][64] tiles
+
+template <typename T> AMT_DEV Frag<T> make_frag(const float (&y)[8]);
+template <> AMT_DEV Frag<bf16> make_frag<bf16>(const float (&y)[8]) {
+  Frag<bf16> f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f.v[i] = (bf16)y[i];
+  return f;
+}
+template <> AMT_DEV Frag<float> make_frag<float>(const float (&y)[8]) {
+  Frag<float> f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f.v[i] = y[i];
+  return f;
+}
+
+// rotate 4 interleaved pairs starting at pair index pi for position pos, then scale
+AMT_DEV void rope8(float (&x)[8], const float* __restrict__ cs, const float* __restrict__ sn, int pos, int pi,
+                   float scale) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float c = cs[pos * 32 + pi + j], s = sn[pos * 32 + pi + j];
+    float x1 = x[2 * j], x2 = x[2 * j + 1];
+    x[2 * j] = (x1 * c - x2 * s) * scale;
+    x[2 * j + 1] = (x1 * s + x2 * c) * scale;
+  }
+}
+// transpose of the rotation (gradient w.r.t. the un-rotated input) for 2 pairs (4 features)
+AMT_DEV void rope4_bwd(float (&d)[4], const float* __restrict__ cs, const float* __restrict__ sn, int pos, int pi,
+                       float scale) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float c = cs[pos * 32 + pi + j], s = sn[pos * 32 + pi + j];
+    float d1 = d[2 * j], d2 = d[2 * j + 1];
+    d[2 * j] = (d1 * c + d2 * s) * scale;
+    d[2 * j + 1] = (-d1 * s + d2 * c) * scale;
+  }
+}
+
+template <typename T>
+AMT_DEV void stage_row_chunk(T* dst, const T* src, bool valid, const float* cs, const float* sn, int pos, int pi,
+                             bool do_rope, float scale) {
+  float x[8];
+  if (valid) {
+    load8f(src, x);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = 0.f;
+  }
+  if (do_rope && valid) rope8(x, cs, sn, pos, pi, scale);
+  store8f(dst, x);
+}
+
+AMT_DEV uint32_t gdrop_idx(int b, int H, int h, int S, int q, int key) {
+  return (uint32_t)(((b * H + h) * S + q)) * (uint32_t)S + (uint32_t)key;
+}
+
+// ------------------------------------------------------------------ global forward
+template <typename T>
+__global__ __launch_bounds__(256) void attn_global_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* Ks = reinterpret_cast<T*>(smem_raw);
+  T* Vs = Ks + 64 * ALD;
+  T* Ps = Vs + 64 * ALD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z, S = a.S;
+  const int qrow = blockIdx.x * 64 + wave * 16 + r;
+  const T* QC = reinterpret_cast<const T*>(a.QC);
+  const T* KV = reinterpret_cast<const T*>(a.KV);
+  T* Pw = Ps + wave * 16 * ALD;
+
+  Frag<T> qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = 0.f;
+    if (qrow < S) {
+      load8f(QC + (size_t)(b * S + qrow) * a.ldqc + h * 64 + 32 * ks + 8 * g, x);
+      rope8(x, a.cos, a.sin, qrow, 16 * ks + 4 * g, 1.f);
+      // reference: rope output is cast to the activation dtype, then divided by sqrt(64) (exact)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = to_f(from_f<T>(x[i])) * 0.125f;
+    }
+    qf[ks] = make_frag<T>(x);
+  }
+
+  float m_run = -1e30f, l_run = 0.f;
+  f32x4 oacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (S + 63) / 64;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      int id = tid + 256 * it, row = id >> 3, c = id & 7;
+      int key = kt * 64 + row;
+      const T* kp = KV + (size_t)(b * S + key) * a.ldkv + h * 64 + 8 * c;
+      stage_row_chunk(Ks + row * ALD + 8 * c, kp, key < S, a.cos, a.sin, key, 4 * c, true, 1.f);
+      stage_row_chunk(Vs + row * ALD + 8 * c, kp + 256, key < S, a.cos, a.sin, key, 4 * c, false, 1.f);
+    }
+    __syncthreads();
+
+    f32x4 sacc[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      sacc[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) mma(sacc[st], frag_row(Ks + (16 * st + r) * ALD + 32 * ks + 8 * g), qf[ks]);
+    }
+    // sacc[st][e] = score[key = kt*64 + 16 st + 4 g + e][query = this lane's]
+    float mx = -1e30f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int key = kt * 64 + 16 * st + 4 * g + e;
+        if (key >= S) sacc[st][e] = -1e30f;
+        mx = fmaxf(mx, sacc[st][e]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float m_new = fmaxf(m_run, mx);
+    float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      float pv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float p = __expf(sacc[st][e] - m_new);
+        psum += p;
+        if (a.drop_thresh24) {
+          int key = kt * 64 + 16 * st + 4 * g + e;
+          bool keep = rng_keep(a.seed, a.stream, gdrop_idx(b, a.H, h, S, qrow, key), a.drop_thresh24);
+          p = keep ? p * a.inv_keep : 0.f;
+        }
+        pv[e] = p;
+      }
+      store4f(Pw + r * ALD + 16 * st + 4 * g, pv);
+    }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
+    __syncthreads();
+    // O^T[d][q] += V^T[d][key] P^T[key][q]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Frag<T> pf = frag_row(Pw + r * ALD + 32 * ks + 8 * g);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) mma(oacc[dt], frag_col(Vs + (32 * ks + 8 * g) * ALD + 16 * dt + r, ALD), pf);
+    }
+  }
+  if (qrow < S) {
+    float inv = 1.f / l_run;
+    T* op = reinterpret_cast<T*>(a.O) + (size_t)(b * S + qrow) * a.ldo + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = oacc[dt][e] * inv;
+      store4f(op + 16 * dt + 4 * g, o);
+    }
+    if (g == 0 && a.LSE != nullptr) a.LSE[(size_t)(b * a.H + h) * S + qrow] = m_run + logf(l_run);
+  }
+}
+
+// ------------------------------------------------------------------ global backward: dQ (and delta)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_global_bwd_dq_kernel(AttnBwdArgs ba) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const AttnArgs& a = ba.f;
+  T* Ks = reinterpret_cast<T*>(smem_raw);
+  T* Vs = Ks + 64 * ALD;
+  T* Ps = Vs + 64 * ALD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z, S = a.S;
+  const int qrow = blockIdx.x * 64 + wave * 16 + r;
+  const T* QC = reinterpret_cast<const T*>(a.QC);
+  const T* KV = reinterpret_cast<const T*>(a.KV);
+  const T* O = reinterpret_cast<const T*>(a.O);
+  const T* dO = reinterpret_cast<const T*>(ba.dO);
+  T* Pw = Ps + wave * 16 * ALD;
+
+  Frag<T> qf[2], dof[2];
+  float dl = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    float x[8], d[8], o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { x[i] = 0.f; d[i] = 0.f; o[i] = 0.f; }
+    if (qrow < S) {
+      int off = h * 64 + 32 * ks + 8 * g;
+      load8f(QC + (size_t)(b * S + qrow) * a.ldqc + off, x);
+      rope8(x, a.cos, a.sin, qrow, 16 * ks + 4 * g, 1.f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = to_f(from_f<T>(x[i])) * 0.125f;
+      load8f(dO + (size_t)(b * S + qrow) * ba.lddo + off, d);
+      load8f(O + (size_t)(b * S + qrow) * a.ldo + off, o);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dl += d[i] * o[i];
+    qf[ks] = make_frag<T>(x);
+    dof[ks] = make_frag<T>(d);
+  }
+  dl += __shfl_xor(dl, 16, 64);
+  dl += __shfl_xor(dl, 32, 64);
+  float lse = 0.f;
+  if (qrow < S) {
+    lse = a.LSE[(size_t)(b * a.H + h) * S + qrow];
+    if (g == 0) ba.delta[(size_t)(b * a.H + h) * S + qrow] = dl;
+  }
+
+  f32x4 dqacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dqacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (S + 63) / 64;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      int id = tid + 256 * it, row = id >> 3, c = id & 7;
+      int key = kt * 64 + row;
+      const T* kp = KV + (size_t)(b * S + key) * a.ldkv + h * 64 + 8 * c;
+      stage_row_chunk(Ks + row * ALD + 8 * c, kp, key < S, a.cos, a.sin, key, 4 * c, true, 1.f);
+      stage_row_chunk(Vs + row * ALD + 8 * c, kp + 256, key < S, a.cos, a.sin, key, 4 * c, false, 1.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f}, dpacc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        mma(sacc, frag_row(Ks + (16 * st + r) * ALD + 32 * ks + 8 * g), qf[ks]);
+        mma(dpacc, frag_row(Vs + (16 * st + r) * ALD + 32 * ks + 8 * g), dof[ks]);
+      }
+      float ds[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int key = kt * 64 + 16 * st + 4 * g + e;
+        float p = (key < S) ? __expf(sacc[e] - lse) : 0.f;
+        float dp = dpacc[e];
+        if (a.drop_thresh24) {
+          bool keep = rng_keep(a.seed, a.stream, gdrop_idx(b, a.H, h, S, qrow, key), a.drop_thresh24);
+          dp = keep ? dp * a.inv_keep : 0.f;
+        }
+        ds[e] = p * (dp - dl);
+      }
+      store4f(Pw + r * ALD + 16 * st + 4 * g, ds);
+    }
+    __syncthreads();
+    // dQs^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Frag<T> dsf = frag_row(Pw + r * ALD + 32 * ks + 8 * g);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) mma(dqacc[dt], frag_col(Ks + (32 * ks + 8 * g) * ALD + 16 * dt + r, ALD), dsf);
+    }
+  }
+  if (qrow < S) {
+    T* dq = reinterpret_cast<T*>(ba.dQC) + (size_t)(b * S + qrow) * ba.lddqc + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      float d[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = dqacc[dt][e];
+      rope4_bwd(d, a.cos, a.sin, qrow, 8 * dt + 2 * g, 0.125f);
+      store4f(dq + 16 * dt + 4 * g, d);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ global backward: dK, dV
+template <typename T>
+__global__ __launch_bounds__(256) void attn_global_bwd_dkv_kernel(AttnBwdArgs ba) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const AttnArgs& a = ba.f;
+  T* Qs = reinterpret_cast<T*>(smem_raw);
+  T* dOs = Qs + 64 * ALD;
+  T* PT = dOs + 64 * ALD;          // [4 waves][16][ALD]
+  T* dST = PT + 4 * 16 * ALD;      // [4 waves][16][ALD]
+  float* lse_s = reinterpret_cast<float*>(dST + 4 * 16 * ALD);
+  float* delta_s = lse_s + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z, S = a.S;
+  const int key = blockIdx.x * 64 + wave * 16 + r;
+  const T* QC = reinterpret_cast<const T*>(a.QC);
+  const T* KV = reinterpret_cast<const T*>(a.KV);
+  const T* dO = reinterpret_cast<const T*>(ba.dO);
+  T* PTw = PT + wave * 16 * ALD;
+  T* dSTw = dST + wave * 16 * ALD;
+
+  Frag<T> kf[2], vf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    float x[8], v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { x[i] = 0.f; v[i] = 0.f; }
+    if (key < S) {
+      const T* kp = KV + (size_t)(b * S + key) * a.ldkv + h * 64 + 32 * ks + 8 * g;
+      load8f(kp, x);
+      rope8(x, a.cos, a.sin, key, 16 * ks + 4 * g, 1.f);
+      load8f(kp + 256, v);
+    }
+    kf[ks] = make_frag<T>(x);
+    vf[ks] = make_frag<T>(v);
+  }
+  f32x4 dkacc[4], dvacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dkacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int nqt = (S + 63) / 64;
+  for (int qt = 0; qt < nqt; ++qt) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      int id = tid + 256 * it, row = id >> 3, c = id & 7;
+      int q = qt * 64 + row;
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = 0.f;
+      if (q < S) {
+        load8f(QC + (size_t)(b * S + q) * a.ldqc + h * 64 + 8 * c, x);
+        rope8(x, a.cos, a.sin, q, 4 * c, 1.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = to_f(from_f<T>(x[i])) * 0.125f;
+      }
+      store8f(Qs + row * ALD + 8 * c, x);
+      stage_row_chunk(dOs + row * ALD + 8 * c, dO + (size_t)(b * S + q) * ba.lddo + h * 64 + 8 * c, q < S, a.cos,
+                      a.sin, 0, 0, false, 1.f);
+    }
+    if (tid < 64) {
+      int q = qt * 64 + tid;
+      lse_s[tid] = (q < S) ? a.LSE[(size_t)(b * a.H + h) * S + q] : 0.f;
+      delta_s[tid] = (q < S) ? ba.delta[(size_t)(b * a.H + h) * S + q] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f}, dpacc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        mma(sacc, frag_row(Qs + (16 * st + r) * ALD + 32 * ks + 8 * g), kf[ks]);     // S[q][key]
+        mma(dpacc, frag_row(dOs + (16 * st + r) * ALD + 32 * ks + 8 * g), vf[ks]);   // dP[q][key]
+      }
+      float pd[4], ds[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int ql = 16 * st + 4 * g + e, q = qt * 64 + ql;
+        bool valid = (q < S) && (key < S);
+        float p = valid ? __expf(sacc[e] - lse_s[ql]) : 0.f;
+        float dp = dpacc[e], pdrop = p;
+        if (a.drop_thresh24) {
+          bool keep = rng_keep(a.seed, a.stream, gdrop_idx(b, a.H, h, S, q, key), a.drop_thresh24);
+          dp = keep ? dp * a.inv_keep : 0.f;
+          pdrop = keep ? p * a.inv_keep : 0.f;
+        }
+        pd[e] = pdrop;
+        ds[e] = p * (dp - delta_s[ql]);
+      }
+      store4f(PTw + r * ALD + 16 * st + 4 * g, pd);
+      store4f(dSTw + r * ALD + 16 * st + 4 * g, ds);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Frag<T> pf = frag_row(PTw + r * ALD + 32 * ks + 8 * g);
+      Frag<T> dsf = frag_row(dSTw + r * ALD + 32 * ks + 8 * g);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        mma(dvacc[dt], frag_col(dOs + (32 * ks + 8 * g) * ALD + 16 * dt + r, ALD), pf);   // dV^T[d][key]
+        mma(dkacc[dt], frag_col(Qs + (32 * ks + 8 * g) * ALD + 16 * dt + r, ALD), dsf);   // dK^T[d][key]
+      }
+    }
+  }
+  if (key < S) {
+    T* dk = reinterpret_cast<T*>(ba.dKV) + (size_t)(b * S + key) * ba.lddkv + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      float d[4], v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { d[e] = dkacc[dt][e]; v[e] = dvacc[dt][e]; }
+      rope4_bwd(d, a.cos, a.sin, key, 8 * dt + 2 * g, 1.f);
+      store4f(dk + 16 * dt + 4 * g, d);
+      store4f(dk + 256 + 16 * dt + 4 * g, v);
+    }
+  }
+}
+
+template <typename K> static void set_max_lds(K kernel, size_t bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes);
+}
+
+void attn_global_fwd(hipStream_t s, DType dt, const AttnArgs& a) {
+  dim3 grid((a.S + 63) / 64, a.H, a.B);
+  if (dt == DT_F32) {
+    size_t lds = (size_t)(64 * 2 + 64) * ALD * sizeof(float);
+    static bool once = (set_max_lds(attn_global_fwd_kernel<float>, 96 * 1024), true);
+    (void)once;
+    hipLaunchKernelGGL((attn_global_fwd_kernel<float>), grid, dim3(256), lds, s, a);
+  } else {
+    size_t lds = (size_t)(64 * 2 + 64) * ALD * sizeof(bf16);
+    hipLaunchKernelGGL((attn_global_fwd_kernel<bf16>), grid, dim3(256), lds, s, a);
+  }
+}
+
+void attn_global_bwd(hipStream_t s, DType dt, const AttnBwdArgs& a) {
+  dim3 grid((a.f.S + 63) / 64, a.f.H, a.f.B);
+  if (dt == DT_F32) {
+    size_t lds1 = (size_t)(64 * 2 + 64) * ALD * sizeof(float);
+    size_t lds2 = (size_t)(64 * 2 + 128) * ALD * sizeof(float) + 128 * sizeof(float);
+    static bool once = (set_max_lds(attn_global_bwd_dq_kernel<float>, 96 * 1024),
+                        set_max_lds(attn_global_bwd_dkv_kernel<float>, 96 * 1024), true);
+    (void)once;
+    hipLaunchKernelGGL((attn_global_bwd_dq_kernel<float>), grid, dim3(256), lds1, s, a);
+    hipLaunchKernelGGL((attn_global_bwd_dkv_kernel<float>), grid, dim3(256), lds2, s, a);
+  } else {
+    size_t lds1 = (size_t)(64 * 2 + 64) * ALD * sizeof(bf16);
+    size_t lds2 = (size_t)(64 * 2 + 128) * ALD * sizeof(bf16) + 128 * sizeof(float);
+    hipLaunchKernelGGL((attn_global_bwd_dq_kernel<bf16>), grid, dim3(256), lds1, s, a);
+    hipLaunchKernelGGL((attn_global_bwd_dkv_kernel<bf16>), grid, dim3(256), lds2, s, a);
+  }
+}
+
+// ------------------------------------------------------------------ local (windowed) attention
+// One wave per (stripe of 8 output positions, head, clip).  Output position j = 8 s + i is covered
+// by window A = s - 1 (its rows 8..15) and window B = s (its rows 0..7); both windows are
+// evaluated in LDS and averaged, which reproduces model.py:451-469 without atomics.  Everything is
+// fp32 VALU work on LDS-resident data (8 MFLOP per clip-layer: latency-, not throughput-bound).
+constexpr int LLD = 65;
+
+struct LocalGeom { int padL, nW, Lp; };
+static LocalGeom local_geom(int S, int W) {
+  int stride = W / 2;
+  int req = stride - (S - W) % stride;
+  int pl = 0, pr = 0;
+  if (req != stride) { pl = req / 2; pr = req / 2 + (req % 2); }
+  LocalGeom gm;
+  gm.padL = pl;
+  gm.Lp = S + pl + pr;
+  gm.nW = (gm.Lp - W) / stride + 1;
+  return gm;
+}
+
+AMT_DEV uint32_t ldrop_idx(int b, int H, int h, int nW, int win, int iw, int j) {
+  return (uint32_t)((((b * H + h) * nW + win) * 16 + iw) * 16 + j);
+}
+
+// load one 8-feature chunk of token (padded position p) or zeros
+template <typename T>
+AMT_DEV void load_tok_chunk(const T* base, int ld, int b, int S, int p, int padL, int off, float (&x)[8]) {
+  int t = p - padL;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = 0.f;
+  if (t >= 0 && t < S) load8f(base + (size_t)(b * S + t) * ld + off, x);
+}
+
+template <typename T>
+AMT_DEV void store_roped(float (*dst)[LLD], int row, int c, const float (&x)[8], const float* cs, const float* sn,
+                         int pos, float scale) {
+  float y[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) y[i] = x[i];
+  rope8(y, cs, sn, pos, 4 * c, 1.f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dst[row][8 * c + i] = to_f(from_f<T>(y[i])) * scale;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn_local_fwd_kernel(AttnArgs a, int padL, int nW) {
+  __shared__ float qA[8][LLD], qB[8][LLD], kA[16][LLD], kB[16][LLD], vs[24][LLD];
+  __shared__ float P[2][8][17];
+  const int lane = threadIdx.x, s = blockIdx.x, h = blockIdx.y, b = blockIdx.z, S = a.S;
+  const bool validA = (s >= 1) && (s - 1 < nW), validB = (s < nW);
+  const T* QC = reinterpret_cast<const T*>(a.QC);
+  const T* KV = reinterpret_cast<const T*>(a.KV);
+  {
+    int i = lane >> 3, c = lane & 7;
+    float x[8];
+    load_tok_chunk(QC, a.ldqc, b, S, 8 * s + i, padL, h * 64 + 8 * c, x);
+    store_roped<T>(qA, i, c, x, a.cos, a.sin, 8 + i, 0.125f);
+    store_roped<T>(qB, i, c, x, a.cos, a.sin, i, 0.125f);
+  }
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    int id = lane + 64 * it, jp = id >> 3, c = id & 7;
+    int p = 8 * s - 8 + jp;
+    float x[8];
+    load_tok_chunk(KV, a.ldkv, b, S, p, padL, h * 64 + 8 * c, x);
+    if (jp < 16) store_roped<T>(kA, jp, c, x, a.cos, a.sin, jp, 1.f);
+    if (jp >= 8) store_roped<T>(kB, jp - 8, c, x, a.cos, a.sin, jp - 8, 1.f);
+    load_tok_chunk(KV, a.ldkv, b, S, p, padL, 256 + h * 64 + 8 * c, x);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vs[jp][8 * c + i] = x[i];
+  }
+  __syncthreads();
+  {
+    const int w = lane >> 5, i = (lane >> 2) & 7, kg = lane & 3;
+    float (*qw)[LLD] = w ? qB : qA;
+    float (*kw)[LLD] = w ? kB : kA;
+    float sc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < 64; ++d) {
+      float qv = qw[i][d];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) sc[kk] += qv * kw[4 * kg + kk][d];
+    }
+    float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { sc[kk] = __expf(sc[kk] - mx); sum += sc[kk]; }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    float inv = 1.f / sum;
+    const int win = s - 1 + w, iw = w ? i : 8 + i;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float p = sc[kk] * inv;
+      if (a.drop_thresh24) {
+        bool keep = rng_keep(a.seed, a.stream, ldrop_idx(b, a.H, h, nW, win, iw, 4 * kg + kk), a.drop_thresh24);
+        p = keep ? p * a.inv_keep : 0.f;
+      }
+      P[w][i][4 * kg + kk] = p;
+    }
+  }
+  __syncthreads();
+  {
+    const int d = lane;
+    const float fa = validA ? 1.f : 0.f, fb = validB ? 1.f : 0.f;
+    const float icnt = 1.f / (fa + fb);
+    T* O = reinterpret_cast<T*>(a.O);
+    for (int i = 0; i < 8; ++i) {
+      float oA = 0.f, oB = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        oA += P[0][i][j] * vs[j][d];
+        oB += P[1][i][j] * vs[8 + j][d];
+      }
+      int jo = 8 * s + i;
+      if (jo < S) O[(size_t)(b * S + jo) * a.ldo + h * 64 + d] = from_f<T>((fa * oA + fb * oB) * icnt);
+    }
+  }
+}
+
+// number of valid windows covering padded/output position p
+AMT_DEV float local_cnt(int p, int nW) {
+  int st = p >> 3;
+  float c = 0.f;
+  if (st - 1 >= 0 && st - 1 < nW) c += 1.f;
+  if (st < nW) c += 1.f;
+  return c;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn_local_bwd_kernel(AttnBwdArgs ba, int padL, int nW) {
+  const AttnArgs& a = ba.f;
+  __shared__ float qA[16][LLD], qB[16][LLD], kA[16][LLD], kB[16][LLD], vs[24][LLD], dOs[24][LLD];
+  __shared__ float Pd[2][16][17], dS[2][16][17];
+  const int lane = threadIdx.x, s = blockIdx.x, h = blockIdx.y, b = blockIdx.z, S = a.S;
+  const bool validA = (s >= 1) && (s - 1 < nW), validB = (s < nW);
+  const T* QC = reinterpret_cast<const T*>(a.QC);
+  const T* KV = reinterpret_cast<const T*>(a.KV);
+  const T* dO = reinterpret_cast<const T*>(ba.dO);
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    int id = lane + 64 * it, jp = id >> 3, c = id & 7;
+    int p = 8 * s - 8 + jp;
+    float x[8];
+    load_tok_chunk(QC, a.ldqc, b, S, p, padL, h * 64 + 8 * c, x);
+    if (jp < 16) store_roped<T>(qA, jp, c, x, a.cos, a.sin, jp, 0.125f);
+    if (jp >= 8) store_roped<T>(qB, jp - 8, c, x, a.cos, a.sin, jp - 8, 0.125f);
+    load_tok_chunk(KV, a.ldkv, b, S, p, padL, h * 64 + 8 * c, x);
+    if (jp < 16) store_roped<T>(kA, jp, c, x, a.cos, a.sin, jp, 1.f);
+    if (jp >= 8) store_roped<T>(kB, jp - 8, c, x, a.cos, a.sin, jp - 8, 1.f);
+    load_tok_chunk(KV, a.ldkv, b, S, p, padL, 256 + h * 64 + 8 * c, x);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vs[jp][8 * c + i] = x[i];
+    // window-output gradient at OUTPUT coordinate p (no pad shift), divided by the cover count
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = 0.f;
+    if (p >= 0 && p < S) {
+      load8f(dO + (size_t)(b * S + p) * ba.lddo + h * 64 + 8 * c, x);
+      float ic = 1.f / local_cnt(p, nW);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] *= ic;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dOs[jp][8 * c + i] = x[i];
+  }
+  __syncthreads();
+  {
+    const int w = lane >> 5, i = (lane >> 1) & 15, hf = lane & 1;
+    float (*qw)[LLD] = w ? qB : qA;
+    float (*kw)[LLD] = w ? kB : kA;
+    float sc[8], dp[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) { sc[kk] = 0.f; dp[kk] = 0.f; }
+    for (int d = 0; d < 64; ++d) {
+      float qv = qw[i][d], dv = dOs[8 * w + i][d];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        sc[kk] += qv * kw[8 * hf + kk][d];
+        dp[kk] += dv * vs[8 * w + 8 * hf + kk][d];
+      }
+    }
+    float mx = sc[0];
+#pragma unroll
+    for (int kk = 1; kk < 8; ++kk) mx = fmaxf(mx, sc[kk]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) { sc[kk] = __expf(sc[kk] - mx); sum += sc[kk]; }
+    sum += __shfl_xor(sum, 1, 64);
+    float inv = 1.f / sum;
+    const int win = s - 1 + w;
+    float dl = 0.f, pdv[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      float p = sc[kk] * inv;
+      float pd = p, dpm = dp[kk];
+      if (a.drop_thresh24) {
+        bool keep = rng_keep(a.seed, a.stream, ldrop_idx(b, a.H, h, nW, win, i, 8 * hf + kk), a.drop_thresh24);
+        pd = keep ? p * a.inv_keep : 0.f;
+        dpm = keep ? dpm * a.inv_keep : 0.f;
+      }
+      sc[kk] = p;
+      dp[kk] = dpm;
+      pdv[kk] = pd;
+      dl += p * dpm;
+    }
+    dl += __shfl_xor(dl, 1, 64);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      Pd[w][i][8 * hf + kk] = pdv[kk];
+      dS[w][i][8 * hf + kk] = sc[kk] * (dp[kk] - dl);
+    }
+  }
+  __syncthreads();
+  {
+    const int d = lane;
+    const float fa = validA ? 1.f : 0.f, fb = validB ? 1.f : 0.f;
+    T* dQC = reinterpret_cast<T*>(ba.dQC);
+    T* dKV = reinterpret_cast<T*>(ba.dKV);
+    for (int ip = 0; ip < 8; ++ip) {
+      float dvA = 0.f, dvB = 0.f, dqA = 0.f, dqB = 0.f, dkA = 0.f, dkB = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        dvA += Pd[0][i][8 + ip] * dOs[i][d];
+        dvB += Pd[1][i][ip] * dOs[8 + i][d];
+        dqA += dS[0][8 + ip][i] * kA[i][d];
+        dqB += dS[1][ip][i] * kB[i][d];
+        dkA += dS[0][i][8 + ip] * qA[i][d];
+        dkB += dS[1][i][ip] * qB[i][d];
+      }
+      // transpose of the rotation: partner feature sits in the neighbouring lane
+      auto unrope = [&](float v, int pos) {
+        float o = __shfl_xor(v, 1, 64);
+        float c = a.cos[pos * 32 + (d >> 1)], sn = a.sin[pos * 32 + (d >> 1)];
+        return (d & 1) ? (-o * sn + v * c) : (v * c + o * sn);
+      };
+      float dq = (fa * unrope(dqA, 8 + ip) + fb * unrope(dqB, ip)) * 0.125f;
+      float dk = fa * unrope(dkA, 8 + ip) + fb * unrope(dkB, ip);
+      float dv = fa * dvA + fb * dvB;
+      int t = 8 * s + ip - padL;
+      if (t >= 0 && t < S) {
+        size_t row = (size_t)(b * S + t);
+        dQC[row * ba.lddqc + h * 64 + d] = from_f<T>(dq);
+        dKV[row * ba.lddkv + h * 64 + d] = from_f<T>(dk);
+        dKV[row * ba.lddkv + 256 + h * 64 + d] = from_f<T>(dv);
+      }
+    }
+  }
+}
+
+void attn_local_fwd(hipStream_t s, DType dt, const AttnArgs& a) {
+  LocalGeom gm = local_geom(a.S, 16);
+  dim3 grid((a.S + 7) / 8, a.H, a.B);
+  if (dt == DT_F32) hipLaunchKernelGGL((attn_local_fwd_kernel<float>), grid, dim3(64), 0, s, a, gm.padL, gm.nW);
+  else hipLaunchKernelGGL((attn_local_fwd_kernel<bf16>), grid, dim3(64), 0, s, a, gm.padL, gm.nW);
+}
+
+void attn_local_bwd(hipStream_t s, DType dt, const AttnBwdArgs& a) {
+  LocalGeom gm = local_geom(a.f.S, 16);
+  dim3 grid(gm.Lp / 8, a.f.H, a.f.B);
+  if (dt == DT_F32) hipLaunchKernelGGL((attn_local_bwd_kernel<float>), grid, dim3(64), 0, s, a, gm.padL, gm.nW);
+  else hipLaunchKernelGGL((attn_local_bwd_kernel<bf16>), grid, dim3(64), 0, s, a, gm.padL, gm.nW);
+}
+
+}  // namespace amt

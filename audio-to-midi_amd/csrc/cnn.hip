@@ -1,0 +1,402 @@
+// CNN frontend kernels (channels-last [B][L][C]):
+//   stem_fwd / stem_bwd      Stem: Conv1d(2->4, k5, s5) + per-position LayerNorm   model.py:84-100
+//   dwln_fwd / dwln_bwd      Block: depthwise Conv1d(k7, SAME) + LayerNorm          model.py:161-162
+//   dwconv_bwd               data + weight gradient of the depthwise conv
+//   scale_bwd                layer-scale gamma                                      model.py:166
+// The pointwise convs of Block and the k2/s2 conv of Downsample are GEMMs (gemm.hip): in
+// channels-last a stride-2 kernel-2 conv is a Linear over two concatenated positions.
+#include "rowops.h"
+#include "kernels.h"
+
+namespace amt {
+
+// ------------------------------------------------------------------ stem
+// One thread per output position; a block stages 256 positions x 5 taps x 2 channels of audio in
+// LDS with 16-byte coalesced loads (the audio is read from HBM exactly once).
+constexpr int STEM_POS = 256;
+constexpr int STEM_SAMP = STEM_POS * 5;   // 1280 samples per channel per block
+
+template <typename T>
+AMT_DEV void stem_stage_audio(const T* audio, float (*xs)[STEM_SAMP], int b, long t0, int T_) {
+  // 2 channels x 1280 samples = 320 chunks of 8
+  for (int id = threadIdx.x; id < 2 * (STEM_SAMP / 8); id += blockDim.x) {
+    int ch = id / (STEM_SAMP / 8), c = id % (STEM_SAMP / 8);
+    long t = t0 + 8 * c;
+    float v[8];
+    if (t + 8 <= T_) {
+      load8f(audio + ((long)b * 2 + ch) * T_ + t, v);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xs[ch][8 * c + i] = v[i];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const T* __restrict__ audio, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, const float* __restrict__ lnw,
+                                                       const float* __restrict__ lnb, T* __restrict__ Y, int B, int T_,
+                                                       int L, int tiles_per_clip) {
+  __shared__ float xs[2][STEM_SAMP];
+  const int b = blockIdx.x / tiles_per_clip, tile = blockIdx.x % tiles_per_clip;
+  const int l0 = tile * STEM_POS;
+  stem_stage_audio(audio, xs, b, (long)l0 * 5, T_);
+  __syncthreads();
+  const int l = l0 + threadIdx.x;
+  if (l >= L) return;
+  float c[4];
+#pragma unroll
+  for (int co = 0; co < 4; ++co) {
+    float a = bias[co];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) a += w[(co * 2 + ci) * 5 + k] * xs[ci][threadIdx.x * 5 + k];
+    c[co] = a;
+  }
+  float mu = 0.25f * (c[0] + c[1] + c[2] + c[3]);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { c[i] -= mu; q += c[i] * c[i]; }
+  float rs = 1.f / sqrtf(0.25f * q + kLnEps);
+  float y[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) y[i] = c[i] * rs * lnw[i] + lnb[i];
+  store4f(Y + ((long)b * L + l) * 4, y);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const T* __restrict__ audio, const T* __restrict__ dY,
+                                                       const float* __restrict__ w, const float* __restrict__ bias,
+                                                       const float* __restrict__ lnw, float* __restrict__ dw,
+                                                       float* __restrict__ db, float* __restrict__ dlnw,
+                                                       float* __restrict__ dlnb, int B, int T_, int L,
+                                                       int tiles_per_clip, int total_tiles) {
+  __shared__ float xs[2][STEM_SAMP];
+  __shared__ float red[52];
+  float acc[52];   // 40 dw, 4 db, 4 dlnw, 4 dlnb
+#pragma unroll
+  for (int i = 0; i < 52; ++i) acc[i] = 0.f;
+  for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    const int b = t / tiles_per_clip, tile = t % tiles_per_clip;
+    const int l0 = tile * STEM_POS;
+    __syncthreads();
+    stem_stage_audio(audio, xs, b, (long)l0 * 5, T_);
+    __syncthreads();
+    const int l = l0 + threadIdx.x;
+    if (l < L) {
+      float c[4], dy[4];
+#pragma unroll
+      for (int co = 0; co < 4; ++co) {
+        float a = bias[co];
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+          for (int k = 0; k < 5; ++k) a += w[(co * 2 + ci) * 5 + k] * xs[ci][threadIdx.x * 5 + k];
+        c[co] = a;
+      }
+      load4f(dY + ((long)b * L + l) * 4, dy);
+      float mu = 0.25f * (c[0] + c[1] + c[2] + c[3]);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { c[i] -= mu; q += c[i] * c[i]; }
+      float rs = 1.f / sqrtf(0.25f * q + kLnEps);
+      float s1 = 0.f, s2 = 0.f, gy[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        c[i] *= rs;   // xhat
+        gy[i] = dy[i] * lnw[i];
+        s1 += gy[i];
+        s2 += gy[i] * c[i];
+        acc[44 + i] += dy[i] * c[i];
+        acc[48 + i] += dy[i];
+      }
+      s1 *= 0.25f; s2 *= 0.25f;
+#pragma unroll
+      for (int co = 0; co < 4; ++co) {
+        float dc = rs * (gy[co] - s1 - c[co] * s2);
+        acc[40 + co] += dc;
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+          for (int k = 0; k < 5; ++k) acc[(co * 2 + ci) * 5 + k] += dc * xs[ci][threadIdx.x * 5 + k];
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 52) red[threadIdx.x] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 52; ++i) {
+    float v = group_sum<64>(acc[i]);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&red[i], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 40) atomicAdd(&dw[threadIdx.x], red[threadIdx.x]);
+  else if (threadIdx.x < 44) atomicAdd(&db[threadIdx.x - 40], red[threadIdx.x]);
+  else if (threadIdx.x < 48) atomicAdd(&dlnw[threadIdx.x - 44], red[threadIdx.x]);
+  else if (threadIdx.x < 52) atomicAdd(&dlnb[threadIdx.x - 48], red[threadIdx.x]);
+}
+
+void stem_fwd(hipStream_t s, DType dt, const void* audio, const float* w, const float* b, const float* lnw,
+              const float* lnb, void* Y, int B, int T_) {
+  int L = T_ / 5, tiles = (L + STEM_POS - 1) / STEM_POS;
+  if (dt == DT_F32)
+    hipLaunchKernelGGL((stem_fwd_kernel<float>), dim3(B * tiles), dim3(256), 0, s, (const float*)audio, w, b, lnw, lnb,
+                       (float*)Y, B, T_, L, tiles);
+  else
+    hipLaunchKernelGGL((stem_fwd_kernel<bf16>), dim3(B * tiles), dim3(256), 0, s, (const bf16*)audio, w, b, lnw, lnb,
+                       (bf16*)Y, B, T_, L, tiles);
+}
+
+void stem_bwd(hipStream_t s, DType dt, const void* audio, const void* dY, const float* w, const float* b,
+              const float* lnw, float* dw, float* db, float* dlnw, float* dlnb, int B, int T_) {
+  int L = T_ / 5, tiles = (L + STEM_POS - 1) / STEM_POS, total = B * tiles;
+  int grid = total < 512 ? total : 512;
+  if (dt == DT_F32)
+    hipLaunchKernelGGL((stem_bwd_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)audio, (const float*)dY, w,
+                       b, lnw, dw, db, dlnw, dlnb, B, T_, L, tiles, total);
+  else
+    hipLaunchKernelGGL((stem_bwd_kernel<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)audio, (const bf16*)dY, w, b,
+                       lnw, dw, db, dlnw, dlnb, B, T_, L, tiles, total);
+}
+
+// ------------------------------------------------------------------ depthwise conv k7 (+ LayerNorm)
+// conv output of row (b, l), feature chunk `sub`: sum_k w[k][c] X[b][l + k - 3][c] + bias[c]
+template <typename T, int VEC>
+AMT_DEV void dwconv_row(const T* __restrict__ X, long rowbase /* b*L */, int l, int L, int C, int sub,
+                        const float (&wk)[7][VEC], const float (&bv)[VEC], float (&out)[VEC]) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) out[i] = bv[i];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    int ll = l + k - 3;
+    if (ll >= 0 && ll < L) {
+      float x[VEC];
+      loadvf<VEC>(X + (rowbase + ll) * C + sub * VEC, x);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) out[i] += wk[k][i] * x[i];
+    }
+  }
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void dwln_fwd_kernel(const T* __restrict__ X, const float* __restrict__ wdw,
+                                                       const float* __restrict__ bdw, const float* __restrict__ lnw,
+                                                       const float* __restrict__ lnb, T* __restrict__ Y,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, int B,
+                                                       int L) {
+  using R = RowCfg<C>;
+  constexpr int VEC = R::VEC, LPR = R::LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, rw = lane / LPR;
+  float wk[7][VEC], bv[VEC], wv[VEC], lb[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    bv[i] = bdw[sub * VEC + i]; wv[i] = lnw[sub * VEC + i]; lb[i] = lnb[sub * VEC + i];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) wk[k][i] = wdw[k * C + sub * VEC + i];
+  }
+  const long N = (long)B * L;
+  for (long row = ((long)blockIdx.x * 4 + wave) * R::RPW + rw; row < N; row += (long)gridDim.x * R::RPB) {
+    int b = (int)(row / L), l = (int)(row % L);
+    float d[VEC];
+    dwconv_row<T, VEC>(X, (long)b * L, l, L, C, sub, wk, bv, d);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s += d[i];
+    float mu = group_sum<LPR>(s) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { d[i] -= mu; q += d[i] * d[i]; }
+    float rs = 1.f / sqrtf(group_sum<LPR>(q) * (1.f / C) + kLnEps);
+    float y[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) y[i] = d[i] * rs * wv[i] + lb[i];
+    storevf<VEC>(Y + row * C + sub * VEC, y);
+    if (sub == 0) { mean[row] = mu; rstd[row] = rs; }
+  }
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void dwln_bwd_kernel(const T* __restrict__ dY, const T* __restrict__ X,
+                                                       const float* __restrict__ wdw, const float* __restrict__ bdw,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ lnw, T* __restrict__ dD,
+                                                       float* __restrict__ dlnw, float* __restrict__ dlnb, int B,
+                                                       int L) {
+  using R = RowCfg<C>;
+  constexpr int VEC = R::VEC, LPR = R::LPR;
+  __shared__ float smem[C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, rw = lane / LPR;
+  float wk[7][VEC], bv[VEC], wv[VEC], aw[VEC], ab[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    bv[i] = bdw[sub * VEC + i]; wv[i] = lnw[sub * VEC + i]; aw[i] = 0.f; ab[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) wk[k][i] = wdw[k * C + sub * VEC + i];
+  }
+  const long N = (long)B * L;
+  for (long row = ((long)blockIdx.x * 4 + wave) * R::RPW + rw; row < N; row += (long)gridDim.x * R::RPB) {
+    int b = (int)(row / L), l = (int)(row % L);
+    float d[VEC], dy[VEC];
+    dwconv_row<T, VEC>(X, (long)b * L, l, L, C, sub, wk, bv, d);
+    loadvf<VEC>(dY + row * C + sub * VEC, dy);
+    float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f, gy[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      d[i] = (d[i] - mu) * rs;
+      gy[i] = dy[i] * wv[i];
+      s1 += gy[i];
+      s2 += gy[i] * d[i];
+      aw[i] += dy[i] * d[i];
+      ab[i] += dy[i];
+    }
+    s1 = group_sum<LPR>(s1) * (1.f / C);
+    s2 = group_sum<LPR>(s2) * (1.f / C);
+    float o[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = rs * (gy[i] - s1 - d[i] * s2);
+    storevf<VEC>(dD + row * C + sub * VEC, o);
+  }
+  reduce_cols_to_global<VEC, LPR>(aw, dlnw, smem);
+  reduce_cols_to_global<VEC, LPR>(ab, dlnb, smem);
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ dD, const T* __restrict__ X,
+                                                         const float* __restrict__ wdw, const T* dRes, T* dX,
+                                                         float* __restrict__ dwdw, float* __restrict__ dbdw, int B,
+                                                         int L) {
+  using R = RowCfg<C>;
+  constexpr int VEC = R::VEC, LPR = R::LPR;
+  __shared__ float smem[C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, rw = lane / LPR;
+  float wk[7][VEC], aw[7][VEC], ab[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    ab[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { wk[k][i] = wdw[k * C + sub * VEC + i]; aw[k][i] = 0.f; }
+  }
+  const long N = (long)B * L;
+  for (long row = ((long)blockIdx.x * 4 + wave) * R::RPW + rw; row < N; row += (long)gridDim.x * R::RPB) {
+    int b = (int)(row / L), l = (int)(row % L);
+    const long rb = (long)b * L;
+    float o[VEC], dd[VEC];
+    if (dRes != nullptr) {
+      loadvf<VEC>(dRes + row * C + sub * VEC, o);
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o[i] = 0.f;
+    }
+    loadvf<VEC>(dD + row * C + sub * VEC, dd);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) ab[i] += dd[i];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      // data grad: dX[l] += w[k] * dD[l - k + 3]
+      int ls = l - k + 3;
+      if (ls >= 0 && ls < L) {
+        float t[VEC];
+        loadvf<VEC>(dD + (rb + ls) * C + sub * VEC, t);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] += wk[k][i] * t[i];
+      }
+      // weight grad: dw[k] += dD[l] * X[l + k - 3]
+      int lx = l + k - 3;
+      if (lx >= 0 && lx < L) {
+        float x[VEC];
+        loadvf<VEC>(X + (rb + lx) * C + sub * VEC, x);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) aw[k][i] += dd[i] * x[i];
+      }
+    }
+    storevf<VEC>(dX + row * C + sub * VEC, o);
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) reduce_cols_to_global<VEC, LPR>(aw[k], dwdw + k * C, smem);
+  reduce_cols_to_global<VEC, LPR>(ab, dbdw, smem);
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void scale_bwd_kernel(const T* __restrict__ dY, const T* __restrict__ Z,
+                                                        const float* __restrict__ gamma, T* __restrict__ dZ,
+                                                        float* __restrict__ dgamma, long N) {
+  using R = RowCfg<C>;
+  constexpr int VEC = R::VEC, LPR = R::LPR;
+  __shared__ float smem[C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, rw = lane / LPR;
+  float gv[VEC], ag[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { gv[i] = gamma[sub * VEC + i]; ag[i] = 0.f; }
+  for (long row = ((long)blockIdx.x * 4 + wave) * R::RPW + rw; row < N; row += (long)gridDim.x * R::RPB) {
+    float dy[VEC], z[VEC], o[VEC];
+    loadvf<VEC>(dY + row * C + sub * VEC, dy);
+    loadvf<VEC>(Z + row * C + sub * VEC, z);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { ag[i] += dy[i] * z[i]; o[i] = gv[i] * dy[i]; }
+    storevf<VEC>(dZ + row * C + sub * VEC, o);
+  }
+  reduce_cols_to_global<VEC, LPR>(ag, dgamma, smem);
+}
+
+template <typename T>
+static void dwln_fwd_t(hipStream_t s, const void* X, const float* wdw, const float* bdw, const float* lnw,
+                       const float* lnb, void* Y, float* mean, float* rstd, int B, int L, int C) {
+  long N = (long)B * L;
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwln_fwd_kernel<T, CC>), dim3(row_grid(N, RowCfg<CC>::RPB)), dim3(256), 0, s,
+                                       (const T*)X, wdw, bdw, lnw, lnb, (T*)Y, mean, rstd, B, L));
+}
+template <typename T>
+static void dwln_bwd_t(hipStream_t s, const void* dY, const void* X, const float* wdw, const float* bdw,
+                       const float* mean, const float* rstd, const float* lnw, void* dD, float* dlnw, float* dlnb,
+                       int B, int L, int C) {
+  long N = (long)B * L;
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwln_bwd_kernel<T, CC>), dim3(row_grid(N, RowCfg<CC>::RPB, 512)), dim3(256), 0,
+                                       s, (const T*)dY, (const T*)X, wdw, bdw, mean, rstd, lnw, (T*)dD, dlnw, dlnb, B,
+                                       L));
+}
+template <typename T>
+static void dwconv_bwd_t(hipStream_t s, const void* dD, const void* X, const float* wdw, const void* dRes, void* dX,
+                         float* dwdw, float* dbdw, int B, int L, int C) {
+  long N = (long)B * L;
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwconv_bwd_kernel<T, CC>), dim3(row_grid(N, RowCfg<CC>::RPB, 512)), dim3(256),
+                                       0, s, (const T*)dD, (const T*)X, wdw, (const T*)dRes, (T*)dX, dwdw, dbdw, B, L));
+}
+template <typename T>
+static void scale_bwd_t(hipStream_t s, const void* dY, const void* Z, const float* gamma, void* dZ, float* dgamma,
+                        int N, int C) {
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((scale_bwd_kernel<T, CC>), dim3(row_grid(N, RowCfg<CC>::RPB, 512)), dim3(256), 0,
+                                       s, (const T*)dY, (const T*)Z, gamma, (T*)dZ, dgamma, (long)N));
+}
+
+void dwln_fwd(hipStream_t s, DType dt, const void* X, const float* wdw, const float* bdw, const float* lnw,
+              const float* lnb, void* Y, float* mean, float* rstd, int B, int L, int C) {
+  if (dt == DT_F32) dwln_fwd_t<float>(s, X, wdw, bdw, lnw, lnb, Y, mean, rstd, B, L, C);
+  else dwln_fwd_t<bf16>(s, X, wdw, bdw, lnw, lnb, Y, mean, rstd, B, L, C);
+}
+void dwln_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const float* wdw, const float* bdw,
+              const float* mean, const float* rstd, const float* lnw, void* dD, float* dlnw, float* dlnb, int B, int L,
+              int C) {
+  if (dt == DT_F32) dwln_bwd_t<float>(s, dY, X, wdw, bdw, mean, rstd, lnw, dD, dlnw, dlnb, B, L, C);
+  else dwln_bwd_t<bf16>(s, dY, X, wdw, bdw, mean, rstd, lnw, dD, dlnw, dlnb, B, L, C);
+}
+void dwconv_bwd(hipStream_t s, DType dt, const void* dD, const void* X, const float* wdw, const void* dRes, void* dX,
+                float* dwdw, float* dbdw, int B, int L, int C) {
+  if (dt == DT_F32) dwconv_bwd_t<float>(s, dD, X, wdw, dRes, dX, dwdw, dbdw, B, L, C);
+  else dwconv_bwd_t<bf16>(s, dD, X, wdw, dRes, dX, dwdw, dbdw, B, L, C);
+}
+void scale_bwd(hipStream_t s, DType dt, const void* dY, const void* Z, const float* gamma, void* dZ, float* dgamma,
+               int N, int C) {
+  if (dt == DT_F32) scale_bwd_t<float>(s, dY, Z, gamma, dZ, dgamma, N, C);
+  else scale_bwd_t<bf16>(s, dY, Z, gamma, dZ, dgamma, N, C);
+}
+
+}  // namespace amt

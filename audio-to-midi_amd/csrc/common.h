@@ -1,0 +1,206 @@
+// Common device helpers for the gfx950 (MI355X / CDNA4) kernels.
+// wave = 64 lanes; MFMA 16x16x32 (bf16) or 8 x 16x16x4 (f32) per 32-deep K step.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace amt {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define AMT_DEV __device__ __forceinline__
+constexpr int WAVE = 64;
+
+// ------------------------------------------------------------------ scalar conversions
+template <typename T> AMT_DEV float to_f(T x) { return (float)x; }
+template <typename T> AMT_DEV T from_f(float x) { return (T)x; }
+
+// ------------------------------------------------------------------ vector load/store (n = 4 or 8 elements)
+// 8 x bf16 = 16 B, 8 x f32 = 32 B (two 16-B accesses), 4 x bf16 = 8 B, 4 x f32 = 16 B.
+template <typename T> struct V8;
+template <> struct V8<bf16> { bf16x8 v; };
+template <> struct V8<float> { f32x4 a, b; };
+
+AMT_DEV void load8f(const bf16* p, float (&o)[8]) {
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+}
+AMT_DEV void load8f(const float* p, float (&o)[8]) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
+}
+AMT_DEV void store8f(bf16* p, const float (&o)[8]) {
+  bf16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (bf16)o[i];
+  *reinterpret_cast<bf16x8*>(p) = v;
+}
+AMT_DEV void store8f(float* p, const float (&o)[8]) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = o[i]; b[i] = o[4 + i]; }
+  *reinterpret_cast<f32x4*>(p) = a;
+  *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+AMT_DEV void load4f(const bf16* p, float (&o)[4]) {
+  bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (float)v[i];
+}
+AMT_DEV void load4f(const float* p, float (&o)[4]) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = a[i];
+}
+AMT_DEV void store4f(bf16* p, const float (&o)[4]) {
+  bf16x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = (bf16)o[i];
+  *reinterpret_cast<bf16x4*>(p) = v;
+}
+AMT_DEV void store4f(float* p, const float (&o)[4]) {
+  f32x4 a;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = o[i];
+  *reinterpret_cast<f32x4*>(p) = a;
+}
+// generic VEC (4 or 8) forms
+template <int VEC, typename T> AMT_DEV void loadvf(const T* p, float (&o)[VEC]) {
+  if constexpr (VEC == 8) load8f(p, o); else load4f(p, o);
+}
+template <int VEC, typename T> AMT_DEV void storevf(T* p, const float (&o)[VEC]) {
+  if constexpr (VEC == 8) store8f(p, o); else store4f(p, o);
+}
+
+// raw (no conversion) 8-element chunk copy global -> regs -> LDS
+template <typename T> struct Chunk8;
+template <> struct Chunk8<bf16> { bf16x8 v; };
+template <> struct Chunk8<float> { f32x4 a, b; };
+
+template <typename T> AMT_DEV Chunk8<T> chunk_zero();
+template <> AMT_DEV Chunk8<bf16> chunk_zero<bf16>() { Chunk8<bf16> c; for (int i = 0; i < 8; ++i) c.v[i] = (bf16)0.f; return c; }
+template <> AMT_DEV Chunk8<float> chunk_zero<float>() { Chunk8<float> c; c.a = f32x4{0, 0, 0, 0}; c.b = f32x4{0, 0, 0, 0}; return c; }
+
+AMT_DEV Chunk8<bf16> chunk_load(const bf16* p) { Chunk8<bf16> c; c.v = *reinterpret_cast<const bf16x8*>(p); return c; }
+AMT_DEV Chunk8<float> chunk_load(const float* p) {
+  Chunk8<float> c; c.a = *reinterpret_cast<const f32x4*>(p); c.b = *reinterpret_cast<const f32x4*>(p + 4); return c;
+}
+// 4 valid elements followed by 4 zeros (K == 4 / M == 4 operands)
+AMT_DEV Chunk8<bf16> chunk_load4(const bf16* p) {
+  Chunk8<bf16> c = chunk_zero<bf16>();
+  bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  for (int i = 0; i < 4; ++i) c.v[i] = v[i];
+  return c;
+}
+AMT_DEV Chunk8<float> chunk_load4(const float* p) {
+  Chunk8<float> c = chunk_zero<float>();
+  c.a = *reinterpret_cast<const f32x4*>(p);
+  return c;
+}
+AMT_DEV void chunk_store(bf16* p, const Chunk8<bf16>& c) { *reinterpret_cast<bf16x8*>(p) = c.v; }
+AMT_DEV void chunk_store(float* p, const Chunk8<float>& c) {
+  *reinterpret_cast<f32x4*>(p) = c.a; *reinterpret_cast<f32x4*>(p + 4) = c.b;
+}
+AMT_DEV float chunk_get(const Chunk8<bf16>& c, int i) { return (float)c.v[i]; }
+AMT_DEV float chunk_get(const Chunk8<float>& c, int i) { return i < 4 ? c.a[i] : c.b[i - 4]; }
+
+// ------------------------------------------------------------------ MFMA fragments
+// One K step is 32 deep.  Lane l = (r = l & 15, g = l >> 4) holds operand elements
+// k = 8 g + j, j = 0..7, of row r (A: A[r][k]; B: B[k][r]).  For bf16 that is exactly the
+// v_mfma_f32_16x16x32_bf16 operand map; for f32 the same registers feed 8 x
+// v_mfma_f32_16x16x4_f32 (element j of every lane forms k-slice {j, 8+j, 16+j, 24+j}), so both
+// dtypes share every address computation.  C/D: acc[i] = D[row 4 g + i][col r].
+template <typename T> struct Frag;
+template <> struct Frag<bf16> { bf16x8 v; };
+template <> struct Frag<float> { float v[8]; };
+
+// 8 contiguous elements
+AMT_DEV Frag<bf16> frag_row(const bf16* p) { Frag<bf16> f; f.v = *reinterpret_cast<const bf16x8*>(p); return f; }
+AMT_DEV Frag<float> frag_row(const float* p) {
+  Frag<float> f;
+  f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f.v[i] = a[i]; f.v[4 + i] = b[i]; }
+  return f;
+}
+// 8 elements at stride `ld` (column of a row-major tile)
+AMT_DEV Frag<bf16> frag_col(const bf16* p, int ld) {
+  Frag<bf16> f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f.v[i] = p[i * ld];
+  return f;
+}
+AMT_DEV Frag<float> frag_col(const float* p, int ld) {
+  Frag<float> f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f.v[i] = p[i * ld];
+  return f;
+}
+template <typename T> AMT_DEV Frag<T> frag_zero();
+template <> AMT_DEV Frag<bf16> frag_zero<bf16>() { Frag<bf16> f; for (int i = 0; i < 8; ++i) f.v[i] = (bf16)0.f; return f; }
+template <> AMT_DEV Frag<float> frag_zero<float>() { Frag<float> f; for (int i = 0; i < 8; ++i) f.v[i] = 0.f; return f; }
+
+AMT_DEV void mma(f32x4& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+AMT_DEV void mma(f32x4& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[i], b.v[i], acc, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------ math
+AMT_DEV float gelu_tanh(float x) {
+  // jax.nn.gelu default (approximate=True): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.f + tanhf(u));
+}
+AMT_DEV float gelu_tanh_grad(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  float t = tanhf(u);
+  float du = k0 * (1.f + 3.f * k1 * x * x);
+  return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
+}
+AMT_DEV float sigmoidf(float z) { return 1.f / (1.f + __expf(-z)); }
+
+// wave-level all-lanes sum over groups of `width` consecutive lanes (width power of two <= 64)
+template <int WIDTH> AMT_DEV float group_sum(float v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int WIDTH> AMT_DEV float group_max(float v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------ counter-based dropout RNG
+// keep(seed, stream, idx) is a pure function, so the backward pass regenerates the forward mask.
+// (JAX's threefry streams cannot be reproduced; SURVEY.md §7 "Dropout parity".)
+AMT_DEV uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+AMT_DEV uint32_t rng_u32(uint64_t seed, uint32_t stream, uint32_t idx) {
+  uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+  uint32_t h = mix32(idx ^ 0x9e3779b9U);
+  h = mix32(h ^ s0 ^ (stream * 0x85ebca6bU));
+  h = mix32(h + s1 + 0x165667b1U);
+  return h;
+}
+// keep with probability (1 - p): threshold on the top 24 bits
+AMT_DEV bool rng_keep(uint64_t seed, uint32_t stream, uint32_t idx, uint32_t drop_thresh24) {
+  return (rng_u32(seed, stream, idx) >> 8) >= drop_thresh24;
+}
+
+}  // namespace amt

@@ -1,0 +1,360 @@
+// MFMA GEMMs for gfx950:  gemm_nt  (Y = X . W^T with fused epilogues)  and  gemm_tn_wgrad.
+//
+// Reference ops served (all of them plain matmuls in XLA):
+//   eqx.nn.Linear / 1x1 Conv1d forward   model.py:141-153,163-165,192,232-236,300-334,369
+//   their data gradients (dY . W)        and weight gradients (dY^T . X)
+//
+// gemm_nt computes D = W_tile . X_tile^T on the matrix cores with FEATURES on the MFMA row axis
+// and TOKENS on the column axis, so that a lane ends up with 4 consecutive output features of one
+// token: bias / gamma / GLU pairing are per-register and stores are 8-byte (bf16) vectors.
+#include "common.h"
+#include "kernels.h"
+
+namespace amt {
+
+constexpr int GBK = 32;       // K step
+constexpr int GLDK = 40;      // LDS row stride (elements): 32 + 8 pad, keeps 16-B alignment
+constexpr int GBF = 64;       // features per workgroup
+
+template <typename T>
+AMT_DEV Chunk8<T> load_k_chunk(const T* rowp, int k, int K) {
+  if (k + 8 <= K) return chunk_load(rowp + k);
+  if (k + 4 <= K) return chunk_load4(rowp + k);
+  return chunk_zero<T>();
+}
+
+// ------------------------------------------------------------------ epilogues
+template <typename T, int EPI>
+AMT_DEV void epi_apply(const GemmArgs& a, int n, int m, float (&v)[4]) {
+  if (a.bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += a.bias[m + i];
+  }
+  if constexpr (EPI == EPI_STORE) {
+    store4f(reinterpret_cast<T*>(a.Y) + (size_t)n * a.ldy + m, v);
+  } else if constexpr (EPI == EPI_STORE_F32) {
+    store4f(reinterpret_cast<float*>(a.Y) + (size_t)n * a.ldy + m, v);
+  } else if constexpr (EPI == EPI_RESID) {
+    float r[4];
+    load4f(reinterpret_cast<const T*>(a.R) + (size_t)n * a.ldr + m, r);
+    if (a.drop_thresh24) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bool keep = rng_keep(a.seed, a.stream, (uint32_t)n * (uint32_t)a.M + (uint32_t)(m + i), a.drop_thresh24);
+        v[i] = keep ? v[i] * a.inv_keep : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += r[i];
+    store4f(reinterpret_cast<T*>(a.Y) + (size_t)n * a.ldy + m, v);
+  } else if constexpr (EPI == EPI_GELU) {
+    float h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = to_f(from_f<T>(v[i])); h[i] = gelu_tanh(v[i]); }
+    store4f(reinterpret_cast<T*>(a.Y) + (size_t)n * a.ldy + m, v);
+    store4f(reinterpret_cast<T*>(a.Y2) + (size_t)n * a.ldy2 + m, h);
+  } else if constexpr (EPI == EPI_SCALE_RESID) {
+    float r[4], y[4];
+    load4f(reinterpret_cast<const T*>(a.R) + (size_t)n * a.ldr + m, r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = to_f(from_f<T>(v[i])); y[i] = r[i] + a.gamma[m + i] * v[i]; }
+    store4f(reinterpret_cast<T*>(a.Y2) + (size_t)n * a.ldy2 + m, v);
+    store4f(reinterpret_cast<T*>(a.Y) + (size_t)n * a.ldy + m, y);
+  } else if constexpr (EPI == EPI_GLU_BWD) {
+    // m indexes dg columns j (0..M-1); u lives in the permuted [.. 16 x u1 | 16 x u2 ..] layout
+    int pm = (m >> 4) * 32 + (m & 15);
+    const T* up = reinterpret_cast<const T*>(a.U) + (size_t)n * a.ldu + pm;
+    float u1[4], u2[4], d1[4], d2[4];
+    load4f(up, u1);
+    load4f(up + 16, u2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      d1[i] = v[i] * u2[i] * gelu_tanh_grad(u1[i]);
+      d2[i] = v[i] * gelu_tanh(u1[i]);
+    }
+    T* yp = reinterpret_cast<T*>(a.Y) + (size_t)n * a.ldy + pm;
+    store4f(yp, d1);
+    store4f(yp + 16, d2);
+  } else if constexpr (EPI == EPI_GELU_BWD) {
+    float u[4];
+    load4f(reinterpret_cast<const T*>(a.U) + (size_t)n * a.ldu + m, u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] *= gelu_tanh_grad(u[i]);
+    store4f(reinterpret_cast<T*>(a.Y) + (size_t)n * a.ldy + m, v);
+  }
+}
+
+// paired epilogue (GLU forward): u1 at permuted feature m (m % 32 < 16), u2 at m + 16
+template <typename T>
+AMT_DEV void epi_glu(const GemmArgs& a, int n, int m, float (&u1)[4], float (&u2)[4]) {
+  float gl[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (a.bias) { u1[i] += a.bias[m + i]; u2[i] += a.bias[m + 16 + i]; }
+    u1[i] = to_f(from_f<T>(u1[i]));
+    u2[i] = to_f(from_f<T>(u2[i]));
+    gl[i] = gelu_tanh(u1[i]) * u2[i];
+  }
+  T* up = reinterpret_cast<T*>(a.Y2) + (size_t)n * a.ldy2 + m;
+  store4f(up, u1);
+  store4f(up + 16, u2);
+  int j = (m >> 5) * 16 + (m & 15);
+  store4f(reinterpret_cast<T*>(a.Y) + (size_t)n * a.ldy + j, gl);
+}
+
+// ------------------------------------------------------------------ gemm_nt kernel
+// workgroup: 256 threads = 4 waves arranged 2 (token halves) x 2 (feature halves);
+// tile BT tokens x 64 features; per wave (BT/2) x 32 = TI x 2 MFMA 16x16 sub-tiles.
+template <typename T, int EPI, int BT>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
+  constexpr int TI = BT / 32;
+  constexpr int FI = 2;
+  constexpr int XCH = BT * 4 / 256;   // X chunks per thread per K step
+  __shared__ __attribute__((aligned(16))) T Xs[2][BT][GLDK];
+  __shared__ __attribute__((aligned(16))) T Ws[2][GBF][GLDK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int wt = wave >> 1, wf = wave & 1;
+  const int n0 = blockIdx.x * BT, m0 = blockIdx.y * GBF;
+  const T* X = reinterpret_cast<const T*>(a.X);
+  const T* W = reinterpret_cast<const T*>(a.W);
+  const int K = a.K;
+
+  f32x4 acc[FI][TI];
+#pragma unroll
+  for (int fi = 0; fi < FI; ++fi)
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) acc[fi][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  Chunk8<T> xr[XCH], wr;
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      int id = tid + i * 256, row = id >> 2, c = id & 3;
+      int n = n0 + row;
+      xr[i] = (n < a.N) ? load_k_chunk(X + (size_t)n * a.ldx, k0 + 8 * c, K) : chunk_zero<T>();
+    }
+    {
+      int row = tid >> 2, c = tid & 3;
+      int m = m0 + row;
+      wr = (m < a.M) ? load_k_chunk(W + (size_t)m * a.ldw, k0 + 8 * c, K) : chunk_zero<T>();
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      int id = tid + i * 256, row = id >> 2, c = id & 3;
+      chunk_store(&Xs[buf][row][8 * c], xr[i]);
+    }
+    chunk_store(&Ws[buf][tid >> 2][8 * (tid & 3)], wr);
+  };
+
+  const int nk = (K + GBK - 1) / GBK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tiles((kt + 1) * GBK);
+    Frag<T> wfr[FI], xfr[TI];
+#pragma unroll
+    for (int fi = 0; fi < FI; ++fi) wfr[fi] = frag_row(&Ws[cur][wf * 32 + fi * 16 + r][8 * g]);
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) xfr[ti] = frag_row(&Xs[cur][wt * (BT / 2) + ti * 16 + r][8 * g]);
+#pragma unroll
+    for (int fi = 0; fi < FI; ++fi)
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) mma(acc[fi][ti], wfr[fi], xfr[ti]);
+    if (kt + 1 < nk) store_tiles(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue: acc[fi][ti][i] = Y[n0 + wt*BT/2 + ti*16 + r][m0 + wf*32 + fi*16 + 4g + i]
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) {
+    int n = n0 + wt * (BT / 2) + ti * 16 + r;
+    if (n >= a.N) continue;
+    if constexpr (EPI == EPI_GLU) {
+      int m = m0 + wf * 32 + 4 * g;
+      if (m < a.M) {
+        float u1[4], u2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { u1[i] = acc[0][ti][i]; u2[i] = acc[1][ti][i]; }
+        epi_glu<T>(a, n, m, u1, u2);
+      }
+    } else {
+#pragma unroll
+      for (int fi = 0; fi < FI; ++fi) {
+        int m = m0 + wf * 32 + fi * 16 + 4 * g;
+        if (m < a.M) {
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = acc[fi][ti][i];
+          epi_apply<T, EPI>(a, n, m, v);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int EPI>
+static void launch_nt(hipStream_t s, const GemmArgs& a) {
+  // 128-token tiles when that still yields >= 2 workgroups per CU, else 64-token tiles
+  long tiles128 = (long)((a.N + 127) / 128) * ((a.M + GBF - 1) / GBF);
+  if (tiles128 >= 512) {
+    dim3 grid((a.N + 127) / 128, (a.M + GBF - 1) / GBF);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, 128>), grid, dim3(256), 0, s, a);
+  } else {
+    dim3 grid((a.N + 63) / 64, (a.M + GBF - 1) / GBF);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, 64>), grid, dim3(256), 0, s, a);
+  }
+}
+
+template <typename T>
+static void dispatch_nt(hipStream_t s, EpiKind epi, const GemmArgs& a) {
+  switch (epi) {
+    case EPI_STORE: launch_nt<T, EPI_STORE>(s, a); break;
+    case EPI_STORE_F32: launch_nt<T, EPI_STORE_F32>(s, a); break;
+    case EPI_RESID: launch_nt<T, EPI_RESID>(s, a); break;
+    case EPI_GELU: launch_nt<T, EPI_GELU>(s, a); break;
+    case EPI_SCALE_RESID: launch_nt<T, EPI_SCALE_RESID>(s, a); break;
+    case EPI_GLU: launch_nt<T, EPI_GLU>(s, a); break;
+    case EPI_GLU_BWD: launch_nt<T, EPI_GLU_BWD>(s, a); break;
+    case EPI_GELU_BWD: launch_nt<T, EPI_GELU_BWD>(s, a); break;
+    default: break;
+  }
+}
+
+void gemm_nt(hipStream_t s, DType dt, EpiKind epi, const GemmArgs& a) {
+  if (a.N <= 0 || a.M <= 0) return;
+  if (dt == DT_F32) dispatch_nt<float>(s, epi, a); else dispatch_nt<bf16>(s, epi, a);
+}
+
+// ------------------------------------------------------------------ gemm_tn_wgrad
+// dW[m][k] += sum_n G[n][m] A[n][k].  Tokens are the MFMA K axis, so both operands are read as
+// COLUMNS of row-major LDS tiles.  Workgroup tile 64 (m) x 64 (k); the token range is split over
+// blockIdx.y and partial tiles are combined with fp32 atomics (unordered: last-bit differences
+// between runs are expected).
+constexpr int WLD = 72;   // LDS row stride (elements) for the [32 tokens][64 features] tiles
+
+template <typename T>
+AMT_DEV Chunk8<T> load_f_chunk(const T* rowp, int f, int F) {
+  if (f + 8 <= F) return chunk_load(rowp + f);
+  if (f + 4 <= F) return chunk_load4(rowp + f);
+  return chunk_zero<T>();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs a, int tiles_k, int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) T Gs[2][32][WLD];
+  __shared__ __attribute__((aligned(16))) T As[2][32][WLD];
+  __shared__ float red[32][65];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wk = wave & 1;
+  const int m0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
+  const int nbeg = blockIdx.y * rows_per_split;
+  const int nend = min(a.N, nbeg + rows_per_split);
+  const T* G = reinterpret_cast<const T*>(a.G);
+  const T* A = reinterpret_cast<const T*>(a.A);
+  const bool do_bias = (a.dbias != nullptr) && (blockIdx.x % tiles_k == 0);
+  const int Mst = a.M_store > 0 ? a.M_store : a.M;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
+
+  const int lrow = tid >> 3, lc = tid & 7;
+  Chunk8<T> gr, ar;
+  auto load_tiles = [&](int nb) {
+    int n = nb + lrow;
+    bool ok = n < nend;
+    gr = ok ? load_f_chunk(G + (size_t)n * a.ldg, m0 + 8 * lc, a.M) : chunk_zero<T>();
+    ar = ok ? load_f_chunk(A + (size_t)n * a.lda, k0 + 8 * lc, a.Kp) : chunk_zero<T>();
+  };
+  auto store_tiles = [&](int buf) {
+    chunk_store(&Gs[buf][lrow][8 * lc], gr);
+    chunk_store(&As[buf][lrow][8 * lc], ar);
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bsum[i] += chunk_get(gr, i);
+    }
+  };
+
+  const int nsteps = (nend - nbeg + 31) / 32;
+  if (nsteps > 0) {
+    load_tiles(nbeg);
+    store_tiles(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int st = 0; st < nsteps; ++st) {
+    if (st + 1 < nsteps) load_tiles(nbeg + (st + 1) * 32);
+    Frag<T> gf[2], af[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) gf[i] = frag_col(&Gs[cur][8 * g][wm * 32 + i * 16 + r], WLD);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) af[j] = frag_col(&As[cur][8 * g][wk * 32 + j * 16 + r], WLD);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) mma(acc[i][j], gf[i], af[j]);
+    if (st + 1 < nsteps) store_tiles(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // acc[i][j][e] = dW[m0 + wm*32 + i*16 + 4g + e][k0 + wk*32 + j*16 + r]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int k = k0 + wk * 32 + j * 16 + r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int m = m0 + wm * 32 + i * 16 + 4 * g + e;
+        if (m < Mst && k < a.Kp) atomicAdd(&a.dW[(size_t)m * a.ldw + k], acc[i][j][e]);
+      }
+    }
+
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[lrow][8 * lc + i] = bsum[i];
+    __syncthreads();
+    if (tid < 64) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int q = 0; q < 32; ++q) s += red[q][tid];
+      int m = m0 + tid;
+      if (m < Mst) atomicAdd(&a.dbias[m], s);
+    }
+  }
+}
+
+void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a) {
+  if (a.N <= 0) return;
+  int tiles_m = (a.M + 63) / 64, tiles_k = (a.Kp + 63) / 64;
+  int tiles = tiles_m * tiles_k;
+  // aim for ~1024 workgroups, at least 128 tokens per split
+  int splits = (1024 + tiles - 1) / tiles;
+  int max_splits = (a.N + 127) / 128;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int rps = ((a.N + splits - 1) / splits + 31) / 32 * 32;
+  splits = (a.N + rps - 1) / rps;
+  dim3 grid(tiles, splits);
+  if (dt == DT_F32)
+    hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, s, a, tiles_k, rps);
+  else
+    hipLaunchKernelGGL((gemm_tn_kernel<bf16>), grid, dim3(256), 0, s, a, tiles_k, rps);
+}
+
+}  // namespace amt

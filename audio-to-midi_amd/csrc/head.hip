@@ -1,0 +1,244 @@
+// Decoder tail, loss, and flat-vector utilities.
+//   head_probs    probs = sigmoid(logits)                                   model.py:192-193
+//   bce_loss      optax.sigmoid_binary_cross_entropy, * scale, sum, mean over batch; dlogits
+//                                                                             train.py:39-47, 60-62
+//   grads_finalize  grads / grad_scale and the all-finite flag               train.py:319-322
+//   adamw_*       optax.adamw + clip_by_global_norm on the updates           train.py:646-729
+#include "common.h"
+#include "kernels.h"
+
+namespace amt {
+
+__global__ void head_probs_kernel(const float* __restrict__ lp, int ldl, float* __restrict__ logits,
+                                  float* __restrict__ probs, long total, int V) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long n = i / V;
+    int v = (int)(i % V);
+    float z = lp[n * ldl + v];
+    if (logits) logits[i] = z;
+    if (probs) probs[i] = 1.f / (1.f + expf(-z));
+  }
+}
+
+void head_probs(hipStream_t s, const float* logits_pad, int ldl, float* logits, float* probs, int N, int V) {
+  long total = (long)N * V;
+  int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(head_probs_kernel, dim3(grid), dim3(256), 0, s, logits_pad, ldl, logits, probs, total, V);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ lp, int ldl,
+                                                  const float* __restrict__ labels, float* __restrict__ loss_acc,
+                                                  T* __restrict__ dl, int ldd, long N, int V, float scale,
+                                                  float inv_b) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const long total = N * ldd;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long n = i / ldd;
+    int v = (int)(i % ldd);
+    float d = 0.f;
+    if (v < V) {
+      float z = lp[n * ldl + v], y = labels[n * V + v];
+      // -y log_sigmoid(z) - (1-y) log_sigmoid(-z) = max(z,0) - z y + log1p(exp(-|z|))
+      acc += fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)));
+      d = (1.f / (1.f + expf(-z)) - y) * scale * inv_b;
+    }
+    dl[i] = from_f<T>(d);
+  }
+  acc = group_sum<64>(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = red[0] + red[1] + red[2] + red[3];
+    atomicAdd(&loss_acc[0], t * inv_b);            // loss: mean over batch of the summed BCE
+    atomicAdd(&loss_acc[1], t * inv_b * scale);    // scaled_loss
+  }
+}
+
+void bce_loss(hipStream_t s, DType dt, const float* logits_pad, int ldl, const float* labels, float* loss_acc,
+              void* dlogits, int ldd, int N, int V, float scale, int B) {
+  long total = (long)N * ldd;
+  int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  if (dt == DT_F32)
+    hipLaunchKernelGGL((bce_kernel<float>), dim3(grid), dim3(256), 0, s, logits_pad, ldl, labels, loss_acc,
+                       (float*)dlogits, ldd, (long)N, V, scale, 1.f / B);
+  else
+    hipLaunchKernelGGL((bce_kernel<bf16>), dim3(grid), dim3(256), 0, s, logits_pad, ldl, labels, loss_acc,
+                       (bf16*)dlogits, ldd, (long)N, V, scale, 1.f / B);
+}
+
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ X, T* __restrict__ Y, size_t n, uint64_t seed, uint32_t stream,
+                               uint32_t thr, float inv_keep) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    bool keep = rng_keep(seed, stream, (uint32_t)i, thr);
+    Y[i] = keep ? from_f<T>(to_f(X[i]) * inv_keep) : from_f<T>(0.f);
+  }
+}
+
+void dropout_apply(hipStream_t s, DType dt, const void* X, void* Y, size_t n, uint64_t seed, uint32_t stream,
+                   uint32_t thr, float inv_keep) {
+  int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  if (dt == DT_F32)
+    hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)X, (float*)Y, n, seed,
+                       stream, thr, inv_keep);
+  else
+    hipLaunchKernelGGL((dropout_kernel<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)X, (bf16*)Y, n, seed, stream,
+                       thr, inv_keep);
+}
+
+__global__ void grads_finalize_kernel(float* __restrict__ g, size_t n, float mul, int* __restrict__ flag) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v = g[i] * mul;
+    g[i] = v;
+    bad |= !isfinite(v);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicAnd(flag, 0);
+}
+
+void grads_finalize(hipStream_t s, float* g, size_t n, float mul, int* valid_flag) {
+  int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(grads_finalize_kernel, dim3(grid), dim3(256), 0, s, g, n, mul, valid_flag);
+}
+
+__global__ void fill_kernel(float* p, float v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+void fill_f32(hipStream_t s, float* p, float v, size_t n) {
+  int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid), dim3(256), 0, s, p, v, n);
+}
+
+template <typename T>
+__global__ void convert_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = from_f<T>(src[i]);
+}
+void convert_f32(hipStream_t s, DType dt, const float* src, void* dst, size_t n) {
+  int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  if (grid < 1) grid = 1;
+  if (dt == DT_F32) hipLaunchKernelGGL((convert_kernel<float>), dim3(grid), dim3(256), 0, s, src, (float*)dst, n);
+  else hipLaunchKernelGGL((convert_kernel<bf16>), dim3(grid), dim3(256), 0, s, src, (bf16*)dst, n);
+}
+
+template <typename T>
+__global__ void convert_transpose_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int C) {
+  __shared__ float tile[32][33];
+  int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    int r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < R && c < C) dst[(size_t)c * R + r] = from_f<T>(tile[threadIdx.x][i]);
+  }
+}
+void convert_transpose(hipStream_t s, DType dt, const float* src, void* dst, int R, int C) {
+  dim3 grid((C + 31) / 32, (R + 31) / 32), block(32, 8);
+  if (dt == DT_F32) hipLaunchKernelGGL((convert_transpose_kernel<float>), grid, block, 0, s, src, (float*)dst, R, C);
+  else hipLaunchKernelGGL((convert_transpose_kernel<bf16>), grid, block, 0, s, src, (bf16*)dst, R, C);
+}
+
+// One launch converts every GEMM weight of the model: descriptor d covers tiles
+// [tile_prefix[d], tile_prefix[d+1]) of 32x32 elements of its [rows x cols] destination.
+// dst is [rows][cols]; source is fp32 [src_rows][cols] (plain; rows >= src_rows are zero-filled)
+// or, when transpose != 0, fp32 [cols][rows] with dst[r][c] = src[c][r] (cols >= src_rows zero-filled).
+template <typename T>
+__global__ __launch_bounds__(256) void convert_batch_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                            const ConvDesc* __restrict__ descs,
+                                                            const int* __restrict__ prefix, int n_desc) {
+  __shared__ float tile[32][33];
+  int t = blockIdx.x;
+  int lo = 0, hi = n_desc - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (prefix[mid] <= t) lo = mid; else hi = mid - 1;
+  }
+  const ConvDesc d = descs[lo];
+  int lt = t - prefix[lo];
+  int tiles_c = (d.cols + 31) / 32;
+  int r0 = (lt / tiles_c) * 32, c0 = (lt % tiles_c) * 32;
+  const float* sp = src + d.src_off;
+  T* dp = dst + d.dst_off;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (!d.transpose) {
+    for (int i = ty; i < 32; i += 8) {
+      int r = r0 + i, c = c0 + tx;
+      if (r < d.rows && c < d.cols) dp[(size_t)r * d.cols + c] = from_f<T>(r < d.src_rows ? sp[(size_t)r * d.cols + c] : 0.f);
+    }
+  } else {
+    // src is [src_rows(valid cols of dst)][rows]
+    for (int i = ty; i < 32; i += 8) {
+      int c = c0 + i, r = r0 + tx;     // read src[c][r], coalesced over r
+      tile[i][tx] = (c < d.src_rows && c < d.cols && r < d.rows) ? sp[(size_t)c * d.rows + r] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+      int r = r0 + i, c = c0 + tx;
+      if (r < d.rows && c < d.cols) dp[(size_t)r * d.cols + c] = from_f<T>(tile[tx][i]);
+    }
+  }
+}
+
+void convert_batch(hipStream_t s, DType dt, const float* src, void* dst, const ConvDesc* descs_dev,
+                   const int* tile_prefix_dev, int n_desc, int total_tiles) {
+  if (total_tiles <= 0) return;
+  if (dt == DT_F32)
+    hipLaunchKernelGGL((convert_batch_kernel<float>), dim3(total_tiles), dim3(256), 0, s, src, (float*)dst, descs_dev,
+                       tile_prefix_dev, n_desc);
+  else
+    hipLaunchKernelGGL((convert_batch_kernel<bf16>), dim3(total_tiles), dim3(256), 0, s, src, (bf16*)dst, descs_dev,
+                       tile_prefix_dev, n_desc);
+}
+
+// ------------------------------------------------------------------ AdamW
+__global__ __launch_bounds__(256) void adamw_compute_kernel(const float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v,
+                                                            float* __restrict__ upd, const float* __restrict__ lr_scale,
+                                                            size_t n, float lr, float b1, float b2, float eps, float wd,
+                                                            float bc1, float bc2, float* __restrict__ norm2) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float u = (mi / bc1) / (sqrtf(vi / bc2) + eps);      // optax.scale_by_adam
+    u += wd * p[i];                                      // add_decayed_weights
+    u *= -lr * (lr_scale ? lr_scale[i] : 1.f);           // scale_by_learning_rate
+    upd[i] = u;
+    acc += u * u;
+  }
+  acc = group_sum<64>(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(norm2, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void adamw_apply_kernel(float* __restrict__ p, const float* __restrict__ upd, size_t n,
+                                   const float* __restrict__ norm2, float clip) {
+  float nrm = sqrtf(norm2[0]);
+  float f = (clip > 0.f && nrm > clip) ? clip / nrm : 1.f;   // optax.clip_by_global_norm
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] += upd[i] * f;
+}
+
+void adamw_compute(hipStream_t s, const float* params, const float* grads, float* m, float* v, float* upd,
+                   const float* lr_scale, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
+                   float* norm2) {
+  float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+  hipLaunchKernelGGL(adamw_compute_kernel, dim3(2048), dim3(256), 0, s, params, grads, m, v, upd, lr_scale, n, lr, b1,
+                     b2, eps, wd, bc1, bc2, norm2);
+}
+void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, const float* norm2, float clip) {
+  hipLaunchKernelGGL(adamw_apply_kernel, dim3(2048), dim3(256), 0, s, params, upd, n, norm2, clip);
+}
+
+}  // namespace amt

@@ -1,0 +1,132 @@
+// Host-side launcher declarations for every HIP kernel of the hot path.
+// All tensors are channels-last / token-major: [rows][features], row-major.
+// T (activation dtype) is float (verification mode) or bf16 (production mode).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace amt {
+
+enum DType { DT_F32 = 0, DT_BF16 = 1 };
+
+// ----------------------------------------------------------------------------- GEMM  Y = X . W^T
+enum EpiKind {
+  EPI_STORE = 0,        // Y(T)   = acc + bias
+  EPI_STORE_F32 = 1,    // Y(f32) = acc + bias
+  EPI_RESID = 2,        // Y(T)   = R + dropout(acc + bias)
+  EPI_GELU = 3,         // Y(T)   = u = acc + bias ; Y2(T) = gelu(u)
+  EPI_SCALE_RESID = 4,  // Y2(T)  = z = acc + bias ; Y(T)  = R + gamma[m] * z
+  EPI_GLU = 5,          // rows of W in (16 x u1 | 16 x u2) blocks: Y2 = u (permuted), Y = gelu(u1) * u2
+  EPI_GLU_BWD = 6,      // acc = dg ; Y(T)[.. permuted ..] = (dg*u2*gelu'(u1), dg*gelu(u1)), u read from U
+  EPI_GELU_BWD = 7,     // Y(T) = acc * gelu'(U)
+  EPI_COUNT
+};
+
+struct GemmArgs {
+  const void* X; int ldx;   // [N x K] (T)
+  const void* W; int ldw;   // [M x K] (T)
+  int N, M, K;
+  const float* bias;        // [M] or nullptr
+  void* Y; int ldy;
+  void* Y2; int ldy2;
+  const void* R; int ldr;   // residual (T)
+  const void* U; int ldu;   // saved pre-activation (T)
+  const float* gamma;       // [M]
+  uint64_t seed; uint32_t stream; uint32_t drop_thresh24; float inv_keep;  // dropout (drop_thresh24 == 0: off)
+};
+// requirements: M % 4 == 0; (K % 8 == 0 and ldx, ldw % 8 == 0) or (K == 4 and ldx, ldw % 4 == 0)
+void gemm_nt(hipStream_t s, DType dt, EpiKind epi, const GemmArgs& a);
+
+// ----------------------------------------------------------------------------- weight-grad GEMM
+// dW[m][k] += sum_n G[n][m] * A[n][k]  (fp32 atomics) ; dbias[m] += sum_n G[n][m]
+struct WgradArgs {
+  const void* G; int ldg;   // [N x M]  (T)
+  const void* A; int lda;   // [N x Kp] (T)
+  int N, M, Kp;
+  float* dW; int ldw;       // [M x Kp] fp32
+  float* dbias;             // [M] fp32 or nullptr
+  int M_store;              // rows of dW / dbias actually written (0 = M); G may be zero-padded past it
+};
+void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a);
+
+// ----------------------------------------------------------------------------- LayerNorm over the last dim
+// C in {4, 8, 16, 32, 64, 128, 256}
+void layernorm_fwd(hipStream_t s, DType dt, const void* X, const float* w, const float* b,
+                   void* Y, float* mean, float* rstd, int N, int C);
+// dX = (dRes ? dRes : 0) + LN'(dY) ; dw += sum dY*xhat ; db += sum dY
+void layernorm_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const float* mean, const float* rstd,
+                   const float* w, const void* dRes, void* dX, float* dw, float* db, int N, int C);
+
+// ----------------------------------------------------------------------------- CNN pieces
+// audio [B][2][T] (T dtype) -> Y [B][T/5][4] = LN(conv k5 s5)
+void stem_fwd(hipStream_t s, DType dt, const void* audio, const float* w /*[4][2][5]*/, const float* b,
+              const float* lnw, const float* lnb, void* Y, int B, int T);
+void stem_bwd(hipStream_t s, DType dt, const void* audio, const void* dY, const float* w, const float* b,
+              const float* lnw, float* dw, float* db, float* dlnw, float* dlnb, int B, int T);
+// Y = LN(dwconv7(X) + bdw) ; X,Y [B][L][C]; saves mean/rstd [B*L]
+void dwln_fwd(hipStream_t s, DType dt, const void* X, const float* wdw /*[7][C]*/, const float* bdw,
+              const float* lnw, const float* lnb, void* Y, float* mean, float* rstd, int B, int L, int C);
+// dD = LN'(dY) w.r.t. the conv output (recomputed from X) ; dlnw,dlnb accumulated
+void dwln_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const float* wdw, const float* bdw,
+              const float* mean, const float* rstd, const float* lnw, void* dD, float* dlnw, float* dlnb,
+              int B, int L, int C);
+// dX = dRes + conv^T(dD) ; dwdw[k][c] += sum dD[l][c] X[l+k-3][c] ; dbdw[c] += sum dD
+void dwconv_bwd(hipStream_t s, DType dt, const void* dD, const void* X, const float* wdw, const void* dRes,
+                void* dX, float* dwdw, float* dbdw, int B, int L, int C);
+// dZ = gamma * dY ; dgamma[c] += sum dY * Z
+void scale_bwd(hipStream_t s, DType dt, const void* dY, const void* Z, const float* gamma, void* dZ,
+               float* dgamma, int N, int C);
+
+// ----------------------------------------------------------------------------- attention
+struct AttnArgs {
+  const void* QC; int ldqc;   // q = QC[:, 0:256] (un-roped)
+  const void* KV; int ldkv;   // k = KV[:, 0:256] (un-roped), v = KV[:, 256:512]
+  void* O; int ldo;           // [B*S][256]
+  float* LSE;                 // [B][H][S] (global only)
+  const float* cos; const float* sin;  // [n_pos][32]
+  int B, S, H;                // H heads of dim 64
+  uint64_t seed; uint32_t stream; uint32_t drop_thresh24; float inv_keep;
+};
+struct AttnBwdArgs {
+  AttnArgs f;                 // forward tensors (O = forward output, LSE)
+  const void* dO; int lddo;   // [B*S][256]
+  void* dQC; int lddqc;       // dq -> dQC[:, 0:256]
+  void* dKV; int lddkv;       // dk -> [:, 0:256], dv -> [:, 256:512]
+  float* delta;               // [B][H][S] scratch
+};
+void attn_global_fwd(hipStream_t s, DType dt, const AttnArgs& a);
+void attn_global_bwd(hipStream_t s, DType dt, const AttnBwdArgs& a);
+void attn_local_fwd(hipStream_t s, DType dt, const AttnArgs& a);
+void attn_local_bwd(hipStream_t s, DType dt, const AttnBwdArgs& a);
+
+// ----------------------------------------------------------------------------- head / loss / utilities
+// logits_pad [N][ldl] fp32 -> logits/probs [N][V] (optional, fp32)
+void head_probs(hipStream_t s, const float* logits_pad, int ldl, float* logits, float* probs, int N, int V);
+// BCE-with-logits: loss_acc[0] += sum over all (n,v) of bce * scale / B ; dlogits(T)[N][ldd] = (sigmoid(z)-y)*scale/B
+// (columns >= V of dlogits are zeroed)
+void bce_loss(hipStream_t s, DType dt, const float* logits_pad, int ldl, const float* labels, float* loss_acc,
+              void* dlogits, int ldd, int N, int V, float scale, int B);
+// elementwise dropout: Y = X * keep / (1-p)
+void dropout_apply(hipStream_t s, DType dt, const void* X, void* Y, size_t n, uint64_t seed, uint32_t stream,
+                   uint32_t drop_thresh24, float inv_keep);
+// g[i] *= mul ; flag[0] = 0 if any non-finite
+void grads_finalize(hipStream_t s, float* g, size_t n, float mul, int* valid_flag);
+void convert_f32(hipStream_t s, DType dt, const float* src, void* dst, size_t n);
+// dst[c][r] = src[r][c]   (src [R x C] fp32 -> dst [C x R] T)
+void convert_transpose(hipStream_t s, DType dt, const float* src, void* dst, int R, int C);
+void fill_f32(hipStream_t s, float* p, float v, size_t n);
+
+// AdamW (optax.adamw) on the flat parameter vector with per-segment learning rates
+// pass 1: update m, v, write the (unclipped) update into upd, accumulate sum(upd^2) into norm2[0]
+void adamw_compute(hipStream_t s, const float* params, const float* grads, float* m, float* v, float* upd,
+                   const float* lr_scale, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
+                   float* norm2);
+// pass 2: params += upd * min(1, clip / sqrt(norm2))
+void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, const float* norm2, float clip);
+
+// batched fp32 -> T weight conversion (plain copy or transpose), one launch for the whole model
+struct ConvDesc { uint64_t src_off; uint64_t dst_off; int rows, cols; int src_rows; int transpose; };
+void convert_batch(hipStream_t s, DType dt, const float* src, void* dst, const ConvDesc* descs_dev,
+                   const int* tile_prefix_dev, int n_desc, int total_tiles);
+
+}  // namespace amt

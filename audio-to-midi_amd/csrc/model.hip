@@ -1,0 +1,869 @@
+// Context, flat parameter layout, and forward / backward orchestration behind the C ABI (amt.h).
+//
+// Reference path reproduced here:
+//   OutputSequenceGenerator.__call__   model.py:740-769   (forward)
+//   compute_loss / value_and_grad      train.py:39-62     (loss + backward)
+//   compute_training_step (grad part)  train.py:292-322   (fp32 accumulation, unscale, finite flag)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/amt.h"
+#include "kernels.h"
+
+using namespace amt;
+
+namespace {
+
+std::string g_create_error;
+
+struct Seg {
+  std::string name;
+  size_t off;
+  int rows, cols;
+  int lr_depth;
+};
+
+struct BlockP {  // offsets into the flat fp32 vector
+  size_t dw_w, dw_b, ln_w, ln_b, pw1_w, pw1_b, pw2_w, pw2_b, gamma;
+  size_t c_pw1, c_pw1t, c_pw2, c_pw2t;  // compute-copy offsets (elements of T)
+};
+struct StageP {
+  int C, Cin, depth;
+  size_t conv_w, conv_b, ln_w, ln_b;   // stem / downsample
+  size_t c_w, c_wt;                    // downsample compute copies
+  std::vector<BlockP> blocks;
+};
+struct LayerP {
+  size_t ln1_w, ln1_b, wqc, wkv, wo, ln2_w, ln2_b, w1, b1, w2, b2;
+  size_t c_wqc, c_wqct, c_wkv, c_wkvt, c_wo, c_wot, c_w1, c_w1t, c_w2, c_w2t;
+};
+
+struct Layout {
+  std::vector<Seg> segs;
+  std::vector<StageP> stages;
+  std::vector<LayerP> layers;
+  size_t fn_w, fn_b;                       // final CNN norm
+  size_t hd_lnw, hd_lnb, hd_w, hd_b;       // decoder
+  size_t c_hw, c_hwt;                      // head compute copies ([96][H], [H][96])
+  size_t n_params = 0;
+  size_t n_compute = 0;                    // elements of the compute-copy buffer
+  std::vector<ConvDesc> conv;
+  int H = 0, QC = 0, KVW = 0, I2 = 0, VP = 0;   // hidden, q+c width, k+v width, 2*inter, padded events
+};
+
+size_t align8(size_t x) { return (x + 7) & ~(size_t)7; }
+
+bool validate(const amt_config& c, std::string& err) {
+  if (c.n_stages < 1 || c.n_stages > AMT_MAX_STAGES) { err = "n_stages out of range"; return false; }
+  for (int i = 0; i < c.n_stages; ++i) {
+    if (c.dims[i] != (4 << i)) { err = "dims[i] must equal 4 << i"; return false; }
+    if (c.depths[i] < 0) { err = "negative depth"; return false; }
+  }
+  int H = c.dims[c.n_stages - 1];
+  if (H != 256) { err = "hidden size (dims[-1]) must be 256"; return false; }
+  if (c.n_heads * c.head_dim != H || c.head_dim != 64) { err = "n_heads*head_dim must be 256 with head_dim 64"; return false; }
+  if (c.kv_compress != 64) { err = "kv_compress must be 64"; return false; }
+  if (c.ffn_inter % 16 != 0 || c.ffn_inter <= 0) { err = "ffn_inter must be a positive multiple of 16"; return false; }
+  if (c.n_events <= 0 || c.n_events > 1024) { err = "n_events out of range"; return false; }
+  if (c.local_window != 16) { err = "local_window must be 16"; return false; }
+  if (c.act_dtype != AMT_F32 && c.act_dtype != AMT_BF16) { err = "act_dtype must be AMT_F32 or AMT_BF16"; return false; }
+  if (!(c.dropout_rate >= 0.f && c.dropout_rate < 1.f)) { err = "dropout_rate must be in [0,1)"; return false; }
+  if (c.n_layer_pairs < 0) { err = "n_layer_pairs negative"; return false; }
+  return true;
+}
+
+Layout build_layout(const amt_config& c) {
+  Layout L;
+  size_t off = 0, coff = 0;
+  auto seg = [&](const std::string& name, int rows, int cols, int depth) {
+    size_t o = off;
+    L.segs.push_back(Seg{name, o, rows, cols, depth});
+    off += (size_t)rows * cols;
+    return o;
+  };
+  auto cbuf = [&](size_t n) { size_t o = coff; coff += align8(n); return o; };
+  auto cpair = [&](size_t src, int rows, int cols, size_t& cw, size_t& cwt) {
+    cw = cbuf((size_t)rows * cols);
+    cwt = cbuf((size_t)rows * cols);
+    L.conv.push_back(ConvDesc{src, cw, rows, cols, rows, 0});
+    L.conv.push_back(ConvDesc{src, cwt, cols, rows, rows, 1});
+  };
+  int depth_base = 0;
+  for (int s = 0; s < c.n_stages; ++s) {
+    StageP st;
+    st.C = c.dims[s];
+    st.Cin = s == 0 ? 2 : c.dims[s - 1];
+    st.depth = c.depths[s];
+    std::string p = "layers." + std::to_string(s) + ".0.";
+    int d0 = depth_base;  // Sequential index 0 (train.py:646-672: depth = sum(depths[:s]) + idx)
+    if (s == 0) {
+      st.conv_w = seg(p + "conv.weight", st.C, 10, d0);
+      st.conv_b = seg(p + "conv.bias", st.C, 1, d0);
+      st.ln_w = seg(p + "norm.weight", st.C, 1, d0);
+      st.ln_b = seg(p + "norm.bias", st.C, 1, d0);
+      st.c_w = st.c_wt = 0;
+    } else {
+      st.ln_w = seg(p + "norm.weight", st.Cin, 1, d0);
+      st.ln_b = seg(p + "norm.bias", st.Cin, 1, d0);
+      st.conv_w = seg(p + "conv.weight", st.C, 2 * st.Cin, d0);
+      st.conv_b = seg(p + "conv.bias", st.C, 1, d0);
+      cpair(st.conv_w, st.C, 2 * st.Cin, st.c_w, st.c_wt);
+    }
+    for (int j = 1; j <= st.depth; ++j) {
+      BlockP b;
+      std::string q = "layers." + std::to_string(s) + "." + std::to_string(j) + ".";
+      int d = depth_base + j;
+      int C = st.C;
+      b.dw_w = seg(q + "depth_conv.weight", 7, C, d);
+      b.dw_b = seg(q + "depth_conv.bias", C, 1, d);
+      b.ln_w = seg(q + "norm.weight", C, 1, d);
+      b.ln_b = seg(q + "norm.bias", C, 1, d);
+      b.pw1_w = seg(q + "point_conv_1.weight", 2 * C, C, d);
+      b.pw1_b = seg(q + "point_conv_1.bias", 2 * C, 1, d);
+      b.pw2_w = seg(q + "point_conv_2.weight", C, 2 * C, d);
+      b.pw2_b = seg(q + "point_conv_2.bias", C, 1, d);
+      b.gamma = seg(q + "gamma", C, 1, d);
+      cpair(b.pw1_w, 2 * C, C, b.c_pw1, b.c_pw1t);
+      cpair(b.pw2_w, C, 2 * C, b.c_pw2, b.c_pw2t);
+      st.blocks.push_back(b);
+    }
+    depth_base += st.depth;
+    L.stages.push_back(st);
+  }
+  const int H = c.dims[c.n_stages - 1];
+  const int HD = c.n_heads * c.head_dim;
+  L.H = H;
+  L.QC = HD + c.kv_compress;
+  L.KVW = 2 * HD;
+  L.I2 = 2 * c.ffn_inter;
+  L.VP = (c.n_events + 31) / 32 * 32;
+  L.fn_w = seg("norm.weight", H, 1, -1);
+  L.fn_b = seg("norm.bias", H, 1, -1);
+  for (int li = 0; li < 2 * c.n_layer_pairs; ++li) {
+    LayerP l;
+    std::string t = "tl." + std::to_string(li) + ".";
+    l.ln1_w = seg(t + "ln1.weight", H, 1, -1);
+    l.ln1_b = seg(t + "ln1.bias", H, 1, -1);
+    l.wqc = seg(t + "wqc", L.QC, H, -1);
+    l.wkv = seg(t + "wkv", L.KVW, c.kv_compress, -1);
+    l.wo = seg(t + "wo", H, HD, -1);
+    l.ln2_w = seg(t + "ln2.weight", H, 1, -1);
+    l.ln2_b = seg(t + "ln2.bias", H, 1, -1);
+    l.w1 = seg(t + "w1", L.I2, H, -1);
+    l.b1 = seg(t + "b1", L.I2, 1, -1);
+    l.w2 = seg(t + "w2", H, c.ffn_inter, -1);
+    l.b2 = seg(t + "b2", H, 1, -1);
+    cpair(l.wqc, L.QC, H, l.c_wqc, l.c_wqct);
+    cpair(l.wkv, L.KVW, c.kv_compress, l.c_wkv, l.c_wkvt);
+    cpair(l.wo, H, HD, l.c_wo, l.c_wot);
+    cpair(l.w1, L.I2, H, l.c_w1, l.c_w1t);
+    cpair(l.w2, H, c.ffn_inter, l.c_w2, l.c_w2t);
+    L.layers.push_back(l);
+  }
+  L.hd_lnw = seg("decoder.norm.weight", H, 1, -1);
+  L.hd_lnb = seg("decoder.norm.bias", H, 1, -1);
+  L.hd_w = seg("decoder.decoder_pooling.weight", c.n_events, H, -1);
+  L.hd_b = seg("decoder.decoder_pooling.bias", c.n_events, 1, -1);
+  // head: padded to VP rows so that every GEMM has M % 4 == 0 and K % 8 == 0
+  L.c_hw = cbuf((size_t)L.VP * H);
+  L.c_hwt = cbuf((size_t)L.VP * H);
+  L.conv.push_back(ConvDesc{L.hd_w, L.c_hw, L.VP, H, c.n_events, 0});
+  L.conv.push_back(ConvDesc{L.hd_w, L.c_hwt, H, L.VP, c.n_events, 1});
+  L.n_params = off;
+  L.n_compute = coff;
+  return L;
+}
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0, peak = 0;
+  bool dry = false;
+  void* alloc(size_t bytes) {
+    size_t o = (off + 255) & ~(size_t)255;
+    off = o + bytes;
+    if (off > peak) peak = off;
+    if (dry) return reinterpret_cast<void*>(o + 4096);  // fake non-null address, never dereferenced
+    return base + o;
+  }
+};
+
+struct BlockSave { void *x, *ln, *u, *h, *z; float *mean, *rstd; };
+struct StageSave { void *x, *ln; float *mean, *rstd; std::vector<BlockSave> blocks; };
+struct LayerSave { void *x, *xn, *qc, *kv, *ao, *h, *hn, *u, *g; float *m1, *r1, *m2, *r2, *lse; };
+
+}  // namespace
+
+struct amt_ctx {
+  amt_config cfg;
+  Layout L;
+  DType dt;
+  int device;
+  size_t esz;
+  std::string err;
+  float* params = nullptr;      // fp32 master [n_params]
+  void* wc = nullptr;           // compute copies (T)
+  float* head_bias = nullptr;   // [VP] fp32 (padded)
+  ConvDesc* conv_dev = nullptr;
+  int* conv_prefix_dev = nullptr;
+  int conv_tiles = 0;
+  float *rope_cos = nullptr, *rope_sin = nullptr;
+  int rope_pos = 0;
+  bool rope_user = false;
+  Arena arena;
+  int plan_B = 0, plan_T = 0, plan_train = -1;
+  // optimizer state
+  float *adam_m = nullptr, *adam_v = nullptr, *adam_upd = nullptr, *lr_scale = nullptr, *norm2 = nullptr;
+  float lr_scale_decay = -1.f;
+  // saved forward state
+  std::vector<StageSave> ssave;
+  std::vector<LayerSave> lsave;
+  void *fn_x = nullptr, *fn_y = nullptr; float *fn_mean = nullptr, *fn_rstd = nullptr;
+  void *hd_x = nullptr, *hd_n = nullptr; float *hd_mean = nullptr, *hd_rstd = nullptr;
+  float* logits_pad = nullptr;
+  float* loss_acc = nullptr;    // device float[2]
+
+  const float* P(size_t off) const { return params + off; }
+  const void* WC(size_t off) const { return static_cast<const char*>(wc) + off * esz; }
+};
+
+namespace {
+
+#define HIPCHK(c, call)                                                                     \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+      return 1;                                                                             \
+    }                                                                                       \
+  } while (0)
+
+void build_rope(int hd, int n_pos, std::vector<float>& cs, std::vector<float>& sn) {
+  // rope.py:12-22 in float32 arithmetic
+  int half = hd / 2;
+  cs.resize((size_t)n_pos * half);
+  sn.resize((size_t)n_pos * half);
+  for (int i = 0; i < half; ++i) {
+    float e = (float)(2 * i) / (float)hd;
+    float inv = 1.0f / powf(10000.0f, e);
+    for (int t = 0; t < n_pos; ++t) {
+      float f = (float)t * inv;
+      cs[(size_t)t * half + i] = cosf(f);
+      sn[(size_t)t * half + i] = sinf(f);
+    }
+  }
+}
+
+int upload_rope(amt_ctx* c, const float* cs, const float* sn, int n_pos) {
+  size_t bytes = (size_t)n_pos * (c->cfg.head_dim / 2) * sizeof(float);
+  if (c->rope_cos) { (void)hipFree(c->rope_cos); (void)hipFree(c->rope_sin); c->rope_cos = c->rope_sin = nullptr; }
+  HIPCHK(c, hipMalloc(&c->rope_cos, bytes));
+  HIPCHK(c, hipMalloc(&c->rope_sin, bytes));
+  HIPCHK(c, hipMemcpy(c->rope_cos, cs, bytes, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->rope_sin, sn, bytes, hipMemcpyHostToDevice));
+  c->rope_pos = n_pos;
+  return 0;
+}
+
+int ensure_rope(amt_ctx* c, int S) {
+  if (c->rope_pos >= S) return 0;
+  if (c->rope_user) { c->err = "RoPE table set by amt_set_rope has fewer positions than frames"; return 1; }
+  int n = S > 512 ? S : 512;
+  std::vector<float> cs, sn;
+  build_rope(c->cfg.head_dim, n, cs, sn);
+  return upload_rope(c, cs.data(), sn.data(), n);
+}
+
+struct Drop { uint32_t thr; float inv_keep; };
+Drop drop_params(const amt_ctx* c, bool train) {
+  Drop d{0u, 1.f};
+  if (train && c->cfg.dropout_rate > 0.f) {
+    d.thr = (uint32_t)lrintf(c->cfg.dropout_rate * 16777216.f);
+    d.inv_keep = 1.f / (1.f - (float)d.thr / 16777216.f);
+  }
+  return d;
+}
+// dropout stream ids: layer li -> attention 2*li, ffn 2*li+1
+inline uint32_t stream_attn(int li) { return 2u * (uint32_t)li; }
+inline uint32_t stream_ffn(int li) { return 2u * (uint32_t)li + 1u; }
+
+GemmArgs gargs(const void* X, int ldx, const void* W, int ldw, int N, int M, int K, const float* bias, void* Y,
+               int ldy) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.X = X; g.ldx = ldx; g.W = W; g.ldw = ldw; g.N = N; g.M = M; g.K = K; g.bias = bias; g.Y = Y; g.ldy = ldy;
+  g.inv_keep = 1.f;
+  return g;
+}
+
+// ------------------------------------------------------------------------------------ forward
+// save == true : every activation the backward pass needs stays in the arena.
+// save == false: ping-pong buffers; temporaries are recycled per block / layer.
+int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool save, bool train, uint64_t seed) {
+  const amt_config& cfg = c->cfg;
+  const Layout& L = c->L;
+  Arena& A = c->arena;
+  const DType dt = c->dt;
+  const size_t es = c->esz;
+  const bool dry = A.dry;
+#define RUN(...) do { if (!dry) { __VA_ARGS__; } } while (0)
+  const Drop dp = drop_params(c, train);
+
+  c->ssave.assign(cfg.n_stages, StageSave());
+  c->lsave.assign(L.layers.size(), LayerSave());
+
+  int Lcur = T / 5;
+  const size_t act_elems = (size_t)B * Lcur * 4;   // B * C * L is constant over stages
+  void* pp[2] = {nullptr, nullptr};
+  if (!save) { pp[0] = A.alloc(act_elems * es); pp[1] = A.alloc(act_elems * es); }
+  int ppi = 0;
+  const size_t mark0 = A.off;
+  auto out_buf = [&](size_t elems) -> void* {
+    if (save) return A.alloc(elems * es);
+    void* p = pp[ppi]; ppi ^= 1; return p;
+  };
+
+  void* cur = nullptr;
+  for (int si = 0; si < cfg.n_stages; ++si) {
+    const StageP& st = L.stages[si];
+    StageSave& sv = c->ssave[si];
+    const int C = st.C;
+    if (si == 0) {
+      void* y = out_buf((size_t)B * Lcur * C);
+      RUN(stem_fwd(s, dt, audio, c->P(st.conv_w), c->P(st.conv_b), c->P(st.ln_w), c->P(st.ln_b), y, B, T));
+      cur = y;
+    } else {
+      if (!save) A.off = mark0;
+      const int Lin = Lcur, Cin = st.Cin;
+      Lcur = Lin / 2;
+      sv.x = cur;
+      sv.ln = A.alloc((size_t)B * Lin * Cin * es);
+      sv.mean = (float*)A.alloc((size_t)B * Lin * sizeof(float));
+      sv.rstd = (float*)A.alloc((size_t)B * Lin * sizeof(float));
+      RUN(layernorm_fwd(s, dt, cur, c->P(st.ln_w), c->P(st.ln_b), sv.ln, sv.mean, sv.rstd, B * Lin, Cin));
+      void* y = out_buf((size_t)B * Lcur * C);
+      GemmArgs g = gargs(sv.ln, 2 * Cin, c->WC(st.c_w), 2 * Cin, B * Lcur, C, 2 * Cin, c->P(st.conv_b), y, C);
+      RUN(gemm_nt(s, dt, EPI_STORE, g));
+      cur = y;
+    }
+    const int N = B * Lcur;
+    sv.blocks.assign(st.blocks.size(), BlockSave());
+    for (size_t j = 0; j < st.blocks.size(); ++j) {
+      const BlockP& bp = st.blocks[j];
+      BlockSave& bs = sv.blocks[j];
+      if (!save) A.off = mark0;
+      bs.x = cur;
+      bs.ln = A.alloc((size_t)N * C * es);
+      bs.mean = (float*)A.alloc((size_t)N * sizeof(float));
+      bs.rstd = (float*)A.alloc((size_t)N * sizeof(float));
+      bs.u = A.alloc((size_t)N * 2 * C * es);
+      bs.h = A.alloc((size_t)N * 2 * C * es);
+      bs.z = A.alloc((size_t)N * C * es);
+      RUN(dwln_fwd(s, dt, cur, c->P(bp.dw_w), c->P(bp.dw_b), c->P(bp.ln_w), c->P(bp.ln_b), bs.ln, bs.mean, bs.rstd, B,
+                   Lcur, C));
+      GemmArgs g1 = gargs(bs.ln, C, c->WC(bp.c_pw1), C, N, 2 * C, C, c->P(bp.pw1_b), bs.u, 2 * C);
+      g1.Y2 = bs.h; g1.ldy2 = 2 * C;
+      RUN(gemm_nt(s, dt, EPI_GELU, g1));
+      void* y = out_buf((size_t)N * C);
+      GemmArgs g2 = gargs(bs.h, 2 * C, c->WC(bp.c_pw2), 2 * C, N, C, 2 * C, c->P(bp.pw2_b), y, C);
+      g2.Y2 = bs.z; g2.ldy2 = C; g2.R = cur; g2.ldr = C; g2.gamma = c->P(bp.gamma);
+      RUN(gemm_nt(s, dt, EPI_SCALE_RESID, g2));
+      cur = y;
+    }
+  }
+  // final LayerNorm; channels-last means the reference's transpose (model.py:762) is free
+  const int S = Lcur, N = B * S, H = L.H;
+  if (!save) A.off = mark0;
+  c->fn_x = cur;
+  c->fn_mean = (float*)A.alloc((size_t)N * sizeof(float));
+  c->fn_rstd = (float*)A.alloc((size_t)N * sizeof(float));
+  {
+    void* y = out_buf((size_t)N * H);
+    RUN(layernorm_fwd(s, dt, cur, c->P(L.fn_w), c->P(L.fn_b), y, c->fn_mean, c->fn_rstd, N, H));
+    cur = y;
+  }
+  c->fn_y = cur;
+  const size_t mark1 = A.off;
+  for (size_t li = 0; li < L.layers.size(); ++li) {
+    const LayerP& lp = L.layers[li];
+    LayerSave& ls = c->lsave[li];
+    const bool local = (li % 2 == 0);   // model.py:609-611: local layer first, then global
+    if (!save) A.off = mark1;
+    ls.x = cur;
+    ls.xn = A.alloc((size_t)N * H * es);
+    ls.m1 = (float*)A.alloc((size_t)N * sizeof(float));
+    ls.r1 = (float*)A.alloc((size_t)N * sizeof(float));
+    ls.qc = A.alloc((size_t)N * L.QC * es);
+    ls.kv = A.alloc((size_t)N * L.KVW * es);
+    ls.ao = A.alloc((size_t)N * H * es);
+    ls.lse = local ? nullptr : (float*)A.alloc((size_t)B * cfg.n_heads * S * sizeof(float));
+    ls.hn = A.alloc((size_t)N * H * es);
+    ls.m2 = (float*)A.alloc((size_t)N * sizeof(float));
+    ls.r2 = (float*)A.alloc((size_t)N * sizeof(float));
+    ls.u = A.alloc((size_t)N * L.I2 * es);
+    ls.g = A.alloc((size_t)N * (L.I2 / 2) * es);
+    RUN(layernorm_fwd(s, dt, cur, c->P(lp.ln1_w), c->P(lp.ln1_b), ls.xn, ls.m1, ls.r1, N, H));
+    GemmArgs gq = gargs(ls.xn, H, c->WC(lp.c_wqc), H, N, L.QC, H, nullptr, ls.qc, L.QC);
+    RUN(gemm_nt(s, dt, EPI_STORE, gq));
+    const void* cptr = static_cast<const char*>(ls.qc) + (size_t)(L.QC - cfg.kv_compress) * es;
+    GemmArgs gk = gargs(cptr, L.QC, c->WC(lp.c_wkv), cfg.kv_compress, N, L.KVW, cfg.kv_compress, nullptr, ls.kv, L.KVW);
+    RUN(gemm_nt(s, dt, EPI_STORE, gk));
+    AttnArgs aa;
+    memset(&aa, 0, sizeof(aa));
+    aa.QC = ls.qc; aa.ldqc = L.QC; aa.KV = ls.kv; aa.ldkv = L.KVW; aa.O = ls.ao; aa.ldo = H; aa.LSE = ls.lse;
+    aa.cos = c->rope_cos; aa.sin = c->rope_sin; aa.B = B; aa.S = S; aa.H = cfg.n_heads;
+    aa.seed = seed; aa.stream = stream_attn((int)li); aa.drop_thresh24 = dp.thr; aa.inv_keep = dp.inv_keep;
+    if (local) RUN(attn_local_fwd(s, dt, aa)); else RUN(attn_global_fwd(s, dt, aa));
+    // h = x + attn . Wo^T
+    ls.h = save ? A.alloc((size_t)N * H * es) : out_buf(0);
+    GemmArgs go = gargs(ls.ao, H, c->WC(lp.c_wo), H, N, H, H, nullptr, ls.h, H);
+    go.R = cur; go.ldr = H;
+    RUN(gemm_nt(s, dt, EPI_RESID, go));
+    RUN(layernorm_fwd(s, dt, ls.h, c->P(lp.ln2_w), c->P(lp.ln2_b), ls.hn, ls.m2, ls.r2, N, H));
+    GemmArgs g1 = gargs(ls.hn, H, c->WC(lp.c_w1), H, N, L.I2, H, c->P(lp.b1), ls.g, L.I2 / 2);
+    g1.Y2 = ls.u; g1.ldy2 = L.I2;
+    RUN(gemm_nt(s, dt, EPI_GLU, g1));
+    void* y = save ? A.alloc((size_t)N * H * es) : out_buf(0);
+    GemmArgs g2 = gargs(ls.g, L.I2 / 2, c->WC(lp.c_w2), L.I2 / 2, N, H, L.I2 / 2, c->P(lp.b2), y, H);
+    g2.R = ls.h; g2.ldr = H;
+    g2.seed = seed; g2.stream = stream_ffn((int)li); g2.drop_thresh24 = dp.thr; g2.inv_keep = dp.inv_keep;
+    RUN(gemm_nt(s, dt, EPI_RESID, g2));
+    cur = y;
+  }
+  // decoder (model.py:185-198)
+  if (!save) A.off = mark1;
+  c->hd_x = cur;
+  c->hd_n = A.alloc((size_t)N * H * es);
+  c->hd_mean = (float*)A.alloc((size_t)N * sizeof(float));
+  c->hd_rstd = (float*)A.alloc((size_t)N * sizeof(float));
+  c->logits_pad = (float*)A.alloc((size_t)N * L.VP * sizeof(float));
+  RUN(layernorm_fwd(s, dt, cur, c->P(L.hd_lnw), c->P(L.hd_lnb), c->hd_n, c->hd_mean, c->hd_rstd, N, H));
+  GemmArgs gh = gargs(c->hd_n, H, c->WC(L.c_hw), H, N, L.VP, H, c->head_bias, c->logits_pad, L.VP);
+  RUN(gemm_nt(s, dt, EPI_STORE_F32, gh));
+#undef RUN
+  return 0;
+}
+
+__global__ void set_int_kernel(int* p, int v) { *p = v; }
+
+// ------------------------------------------------------------------------------------ backward
+int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labels, int B, int T, float scale,
+                 bool train, uint64_t seed, float* grads, int* grads_valid) {
+  const amt_config& cfg = c->cfg;
+  const Layout& L = c->L;
+  Arena& A = c->arena;
+  const DType dt = c->dt;
+  const size_t es = c->esz;
+  const bool dry = A.dry;
+#define RUN(...) do { if (!dry) { __VA_ARGS__; } } while (0)
+  const Drop dp = drop_params(c, train);
+  const int S = T / 320, N = B * S, H = L.H;
+  auto G = [&](size_t off) { return grads + off; };
+  auto wgrad = [&](const void* Gm, int ldg, const void* Am, int lda, int n, int M, int Kp, size_t w_off, int ldw,
+                   long b_off, int m_store) {
+    WgradArgs w;
+    memset(&w, 0, sizeof(w));
+    w.G = Gm; w.ldg = ldg; w.A = Am; w.lda = lda; w.N = n; w.M = M; w.Kp = Kp;
+    w.dW = G(w_off); w.ldw = ldw; w.dbias = b_off >= 0 ? G((size_t)b_off) : nullptr; w.M_store = m_store;
+    RUN(gemm_tn_wgrad(s, dt, w));
+  };
+
+  RUN((void)hipMemsetAsync(grads, 0, L.n_params * sizeof(float), s));
+  RUN((void)hipMemsetAsync(c->loss_acc, 0, 2 * sizeof(float), s));
+
+  // two ping-pong gradient buffers for the residual stream / CNN activations
+  const size_t act_elems = (size_t)B * (T / 5) * 4;
+  const size_t res_elems = act_elems > (size_t)N * H ? act_elems : (size_t)N * H;
+  void* dbuf[2] = {A.alloc(res_elems * es), A.alloc(res_elems * es)};
+  int di = 0;
+  const size_t mark = A.off;
+
+  // loss + dlogits
+  void* dlog = A.alloc((size_t)N * L.VP * es);
+  RUN(bce_loss(s, dt, c->logits_pad, L.VP, labels, c->loss_acc, dlog, L.VP, N, cfg.n_events, scale, B));
+  // decoder backward
+  wgrad(dlog, L.VP, c->hd_n, H, N, L.VP, H, L.hd_w, H, (long)L.hd_b, cfg.n_events);
+  void* dhn = A.alloc((size_t)N * H * es);
+  {
+    GemmArgs g = gargs(dlog, L.VP, c->WC(L.c_hwt), L.VP, N, H, L.VP, nullptr, dhn, H);
+    RUN(gemm_nt(s, dt, EPI_STORE, g));
+  }
+  void* dcur = dbuf[di];
+  RUN(layernorm_bwd(s, dt, dhn, c->hd_x, c->hd_mean, c->hd_rstd, c->P(L.hd_lnw), nullptr, dcur, G(L.hd_lnw),
+                    G(L.hd_lnb), N, H));
+
+  for (int li = (int)L.layers.size() - 1; li >= 0; --li) {
+    const LayerP& lp = L.layers[li];
+    const LayerSave& ls = c->lsave[li];
+    const bool local = (li % 2 == 0);
+    A.off = mark;
+    const void* dy = dcur;
+    const void* dyd = dy;
+    if (dp.thr) {
+      void* t = A.alloc((size_t)N * H * es);
+      RUN(dropout_apply(s, dt, dy, t, (size_t)N * H, seed, stream_ffn(li), dp.thr, dp.inv_keep));
+      dyd = t;
+    }
+    // FFN
+    wgrad(dyd, H, ls.g, L.I2 / 2, N, H, L.I2 / 2, lp.w2, L.I2 / 2, (long)lp.b2, 0);
+    void* du = A.alloc((size_t)N * L.I2 * es);
+    {
+      GemmArgs g = gargs(dyd, H, c->WC(lp.c_w2t), H, N, L.I2 / 2, H, nullptr, du, L.I2);
+      g.U = ls.u; g.ldu = L.I2;
+      RUN(gemm_nt(s, dt, EPI_GLU_BWD, g));
+    }
+    wgrad(du, L.I2, ls.hn, H, N, L.I2, H, lp.w1, H, (long)lp.b1, 0);
+    void* dhn2 = A.alloc((size_t)N * H * es);
+    {
+      GemmArgs g = gargs(du, L.I2, c->WC(lp.c_w1t), L.I2, N, H, L.I2, nullptr, dhn2, H);
+      RUN(gemm_nt(s, dt, EPI_STORE, g));
+    }
+    void* dh = A.alloc((size_t)N * H * es);
+    RUN(layernorm_bwd(s, dt, dhn2, ls.h, ls.m2, ls.r2, c->P(lp.ln2_w), dy, dh, G(lp.ln2_w), G(lp.ln2_b), N, H));
+    // attention output projection
+    wgrad(dh, H, ls.ao, H, N, H, H, lp.wo, H, -1, 0);
+    void* dao = A.alloc((size_t)N * H * es);
+    {
+      GemmArgs g = gargs(dh, H, c->WC(lp.c_wot), H, N, H, H, nullptr, dao, H);
+      RUN(gemm_nt(s, dt, EPI_STORE, g));
+    }
+    void* dqc = A.alloc((size_t)N * L.QC * es);
+    void* dkv = A.alloc((size_t)N * L.KVW * es);
+    float* delta = (float*)A.alloc((size_t)B * cfg.n_heads * S * sizeof(float));
+    AttnBwdArgs ab;
+    memset(&ab, 0, sizeof(ab));
+    ab.f.QC = ls.qc; ab.f.ldqc = L.QC; ab.f.KV = ls.kv; ab.f.ldkv = L.KVW; ab.f.O = ls.ao; ab.f.ldo = H;
+    ab.f.LSE = ls.lse; ab.f.cos = c->rope_cos; ab.f.sin = c->rope_sin; ab.f.B = B; ab.f.S = S; ab.f.H = cfg.n_heads;
+    ab.f.seed = seed; ab.f.stream = stream_attn(li); ab.f.drop_thresh24 = dp.thr; ab.f.inv_keep = dp.inv_keep;
+    ab.dO = dao; ab.lddo = H; ab.dQC = dqc; ab.lddqc = L.QC; ab.dKV = dkv; ab.lddkv = L.KVW; ab.delta = delta;
+    if (local) RUN(attn_local_bwd(s, dt, ab)); else RUN(attn_global_bwd(s, dt, ab));
+    // k/v up-projection
+    const int ckv = cfg.kv_compress;
+    const void* cptr = static_cast<const char*>(ls.qc) + (size_t)(L.QC - ckv) * es;
+    wgrad(dkv, L.KVW, cptr, L.QC, N, L.KVW, ckv, lp.wkv, ckv, -1, 0);
+    {
+      void* dcp = static_cast<char*>(dqc) + (size_t)(L.QC - ckv) * es;
+      GemmArgs g = gargs(dkv, L.KVW, c->WC(lp.c_wkvt), L.KVW, N, ckv, L.KVW, nullptr, dcp, L.QC);
+      RUN(gemm_nt(s, dt, EPI_STORE, g));
+    }
+    // q / kv-down projection
+    wgrad(dqc, L.QC, ls.xn, H, N, L.QC, H, lp.wqc, H, -1, 0);
+    void* dxn = A.alloc((size_t)N * H * es);
+    {
+      GemmArgs g = gargs(dqc, L.QC, c->WC(lp.c_wqct), L.QC, N, H, L.QC, nullptr, dxn, H);
+      RUN(gemm_nt(s, dt, EPI_STORE, g));
+    }
+    di ^= 1;
+    void* dx = dbuf[di];
+    RUN(layernorm_bwd(s, dt, dxn, ls.x, ls.m1, ls.r1, c->P(lp.ln1_w), dh, dx, G(lp.ln1_w), G(lp.ln1_b), N, H));
+    dcur = dx;
+  }
+  // final CNN LayerNorm
+  {
+    A.off = mark;
+    di ^= 1;
+    void* dx = dbuf[di];
+    RUN(layernorm_bwd(s, dt, dcur, c->fn_x, c->fn_mean, c->fn_rstd, c->P(L.fn_w), nullptr, dx, G(L.fn_w), G(L.fn_b), N,
+                      H));
+    dcur = dx;
+  }
+  // CNN stages, last to first
+  int Lcur = S;
+  for (int si = cfg.n_stages - 1; si >= 0; --si) {
+    const StageP& st = L.stages[si];
+    const StageSave& sv = c->ssave[si];
+    const int C = st.C;
+    const int Nn = B * Lcur;
+    for (int j = (int)st.blocks.size() - 1; j >= 0; --j) {
+      const BlockP& bp = st.blocks[j];
+      const BlockSave& bs = sv.blocks[j];
+      A.off = mark;
+      const void* dy = dcur;
+      void* dz = A.alloc((size_t)Nn * C * es);
+      RUN(scale_bwd(s, dt, dy, bs.z, c->P(bp.gamma), dz, G(bp.gamma), Nn, C));
+      wgrad(dz, C, bs.h, 2 * C, Nn, C, 2 * C, bp.pw2_w, 2 * C, (long)bp.pw2_b, 0);
+      void* du = A.alloc((size_t)Nn * 2 * C * es);
+      {
+        GemmArgs g = gargs(dz, C, c->WC(bp.c_pw2t), C, Nn, 2 * C, C, nullptr, du, 2 * C);
+        g.U = bs.u; g.ldu = 2 * C;
+        RUN(gemm_nt(s, dt, EPI_GELU_BWD, g));
+      }
+      wgrad(du, 2 * C, bs.ln, C, Nn, 2 * C, C, bp.pw1_w, C, (long)bp.pw1_b, 0);
+      void* dln = A.alloc((size_t)Nn * C * es);
+      {
+        GemmArgs g = gargs(du, 2 * C, c->WC(bp.c_pw1t), 2 * C, Nn, C, 2 * C, nullptr, dln, C);
+        RUN(gemm_nt(s, dt, EPI_STORE, g));
+      }
+      void* dD = A.alloc((size_t)Nn * C * es);
+      RUN(dwln_bwd(s, dt, dln, bs.x, c->P(bp.dw_w), c->P(bp.dw_b), bs.mean, bs.rstd, c->P(bp.ln_w), dD, G(bp.ln_w),
+                   G(bp.ln_b), B, Lcur, C));
+      di ^= 1;
+      void* dx = dbuf[di];
+      RUN(dwconv_bwd(s, dt, dD, bs.x, c->P(bp.dw_w), dy, dx, G(bp.dw_w), G(bp.dw_b), B, Lcur, C));
+      dcur = dx;
+    }
+    if (si > 0) {
+      A.off = mark;
+      const int Cin = st.Cin, Lin = Lcur * 2;
+      wgrad(dcur, C, sv.ln, 2 * Cin, Nn, C, 2 * Cin, st.conv_w, 2 * Cin, (long)st.conv_b, 0);
+      void* dln = A.alloc((size_t)Nn * 2 * Cin * es);
+      {
+        GemmArgs g = gargs(dcur, C, c->WC(st.c_wt), C, Nn, 2 * Cin, C, nullptr, dln, 2 * Cin);
+        RUN(gemm_nt(s, dt, EPI_STORE, g));
+      }
+      di ^= 1;
+      void* dx = dbuf[di];
+      RUN(layernorm_bwd(s, dt, dln, sv.x, sv.mean, sv.rstd, c->P(st.ln_w), nullptr, dx, G(st.ln_w), G(st.ln_b), B * Lin,
+                        Cin));
+      dcur = dx;
+      Lcur = Lin;
+    } else {
+      RUN(stem_bwd(s, dt, audio, dcur, c->P(st.conv_w), c->P(st.conv_b), c->P(st.ln_w), G(st.conv_w), G(st.conv_b),
+                   G(st.ln_w), G(st.ln_b), B, T));
+    }
+  }
+  // train.py:319-322: grads / grad_scale, all-finite flag
+  RUN(hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, grads_valid, 1));
+  RUN(grads_finalize(s, grads, L.n_params, 1.f / scale, grads_valid));
+#undef RUN
+  return 0;
+}
+
+int plan(amt_ctx* c, int B, int T, int train_mode, hipStream_t s) {
+  // train_mode: 0 = inference (recycled buffers), 1 = training (everything saved + backward scratch)
+  if (c->plan_B == B && c->plan_T == T && c->plan_train == train_mode && c->arena.base) return 0;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cs);
+  if (cs != hipStreamCaptureStatusNone) {
+    c->err = "workspace for this (B, T) is not planned yet: run once outside stream capture";
+    return 1;
+  }
+  Arena dryA;
+  dryA.dry = true;
+  Arena keep = c->arena;
+  c->arena = dryA;
+  run_forward(c, s, nullptr, B, T, train_mode == 1, false, 0);
+  if (train_mode == 1) run_backward(c, s, nullptr, nullptr, B, T, 1.f, false, 0, nullptr, nullptr);
+  size_t need = c->arena.peak + 4096;
+  c->arena = keep;
+  if (need > c->arena.cap) {
+    HIPCHK(c, hipDeviceSynchronize());
+    if (c->arena.base) (void)hipFree(c->arena.base);
+    c->arena.base = nullptr;
+    c->arena.cap = 0;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->arena.base), need));
+    c->arena.cap = need;
+  }
+  c->arena.off = 0;
+  c->arena.peak = 0;
+  c->arena.dry = false;
+  c->plan_B = B; c->plan_T = T; c->plan_train = train_mode;
+  return 0;
+}
+
+int check_shape(amt_ctx* c, int B, int T) {
+  if (B <= 0) { c->err = "B must be positive"; return 1; }
+  if (T <= 0 || T % 320 != 0) { c->err = "T must be a positive multiple of 320 (5 * 2^6 samples per frame)"; return 1; }
+  if (T / 320 < c->cfg.local_window) { c->err = "clip shorter than one local-attention window (16 frames)"; return 1; }
+  return 0;
+}
+
+int refresh(amt_ctx* c, hipStream_t s) {
+  const Layout& L = c->L;
+  convert_batch(s, c->dt, c->params, c->wc, c->conv_dev, c->conv_prefix_dev, (int)L.conv.size(), c->conv_tiles);
+  // padded head bias
+  (void)hipMemsetAsync(c->head_bias, 0, L.VP * sizeof(float), s);
+  (void)hipMemcpyAsync(c->head_bias, c->params + L.hd_b, c->cfg.n_events * sizeof(float), hipMemcpyDeviceToDevice, s);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { c->err = std::string("refresh_weights: ") + hipGetErrorString(e); return 1; }
+  return 0;
+}
+
+}  // namespace
+
+// ===================================================================================== C ABI
+extern "C" {
+
+void amt_default_config(amt_config* cfg) {
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->n_stages = 7;
+  const int depths[7] = {3, 3, 3, 3, 3, 21, 3};
+  for (int i = 0; i < 7; ++i) { cfg->dims[i] = 4 << i; cfg->depths[i] = depths[i]; }
+  cfg->n_layer_pairs = 8;
+  cfg->n_heads = 4;
+  cfg->head_dim = 64;
+  cfg->kv_compress = 64;
+  cfg->ffn_inter = 512;
+  cfg->n_events = 90;
+  cfg->local_window = 16;
+  cfg->dropout_rate = 0.1f;
+  cfg->act_dtype = AMT_BF16;
+}
+
+uint64_t amt_param_count(const amt_config* cfg) {
+  std::string e;
+  if (!validate(*cfg, e)) return 0;
+  return build_layout(*cfg).n_params;
+}
+
+int32_t amt_layout_count(const amt_config* cfg) {
+  std::string e;
+  if (!validate(*cfg, e)) return -1;
+  return (int32_t)build_layout(*cfg).segs.size();
+}
+
+int32_t amt_layout_segment(const amt_config* cfg, int32_t index, amt_segment* out) {
+  std::string e;
+  if (!validate(*cfg, e)) return 1;
+  Layout L = build_layout(*cfg);
+  if (index < 0 || index >= (int32_t)L.segs.size()) return 1;
+  const Seg& sg = L.segs[index];
+  memset(out, 0, sizeof(*out));
+  snprintf(out->name, sizeof(out->name), "%s", sg.name.c_str());
+  out->offset = sg.off;
+  out->rows = sg.rows;
+  out->cols = sg.cols;
+  out->lr_depth = sg.lr_depth;
+  return 0;
+}
+
+int32_t amt_num_frames(const amt_config* cfg, int32_t T) {
+  (void)cfg;
+  return (T > 0 && T % 320 == 0) ? T / 320 : -1;
+}
+
+const char* amt_last_error(const amt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
+  *out = nullptr;
+  std::string e;
+  if (!validate(*cfg, e)) { g_create_error = e; return 1; }
+  hipError_t he = hipSetDevice(device);
+  if (he != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(he); return 1; }
+  amt_ctx* c = new amt_ctx();
+  c->cfg = *cfg;
+  c->L = build_layout(*cfg);
+  c->dt = cfg->act_dtype == AMT_F32 ? DT_F32 : DT_BF16;
+  c->esz = c->dt == DT_F32 ? 4 : 2;
+  c->device = device;
+  const Layout& L = c->L;
+  auto fail = [&](const char* what, hipError_t err) {
+    g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+    amt_destroy(c);
+    return 1;
+  };
+  if ((he = hipMalloc(&c->params, L.n_params * sizeof(float))) != hipSuccess) return fail("hipMalloc(params)", he);
+  if ((he = hipMemset(c->params, 0, L.n_params * sizeof(float))) != hipSuccess) return fail("hipMemset", he);
+  if ((he = hipMalloc(&c->wc, L.n_compute * c->esz)) != hipSuccess) return fail("hipMalloc(compute copies)", he);
+  if ((he = hipMalloc(&c->head_bias, L.VP * sizeof(float))) != hipSuccess) return fail("hipMalloc(head bias)", he);
+  if ((he = hipMalloc(&c->loss_acc, 2 * sizeof(float))) != hipSuccess) return fail("hipMalloc(loss)", he);
+  std::vector<int> prefix(L.conv.size() + 1, 0);
+  for (size_t i = 0; i < L.conv.size(); ++i)
+    prefix[i + 1] = prefix[i] + ((L.conv[i].rows + 31) / 32) * ((L.conv[i].cols + 31) / 32);
+  c->conv_tiles = prefix.back();
+  if ((he = hipMalloc(&c->conv_dev, L.conv.size() * sizeof(ConvDesc))) != hipSuccess) return fail("hipMalloc", he);
+  if ((he = hipMalloc(&c->conv_prefix_dev, prefix.size() * sizeof(int))) != hipSuccess) return fail("hipMalloc", he);
+  (void)hipMemcpy(c->conv_dev, L.conv.data(), L.conv.size() * sizeof(ConvDesc), hipMemcpyHostToDevice);
+  (void)hipMemcpy(c->conv_prefix_dev, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice);
+  *out = c;
+  return 0;
+}
+
+void amt_destroy(amt_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  void* ptrs[] = {c->params, c->wc, c->head_bias, c->conv_dev, c->conv_prefix_dev, c->rope_cos, c->rope_sin,
+                  c->arena.base, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, c->norm2, c->loss_acc};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete c;
+}
+
+int32_t amt_load_weights(amt_ctx* c, const float* flat, uint64_t n, int32_t on_device, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n != c->L.n_params) { c->err = "amt_load_weights: wrong parameter count"; return 1; }
+  HIPCHK(c, hipMemcpyAsync(c->params, flat, n * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                           s));
+  return refresh(c, s);
+}
+
+float* amt_weights_ptr(amt_ctx* c) { return c->params; }
+
+int32_t amt_refresh_weights(amt_ctx* c, void* stream) { return refresh(c, static_cast<hipStream_t>(stream)); }
+
+int32_t amt_set_rope(amt_ctx* c, const float* cos_table, const float* sin_table, int32_t n_pos) {
+  if (n_pos <= 0) { c->err = "amt_set_rope: n_pos must be positive"; return 1; }
+  c->rope_user = true;
+  return upload_rope(c, cos_table, sin_table, n_pos);
+}
+
+int32_t amt_forward(amt_ctx* c, const void* audio, int32_t B, int32_t T, float* logits, float* probs, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (check_shape(c, B, T)) return 1;
+  if (ensure_rope(c, T / 320)) return 1;
+  if (plan(c, B, T, 0, s)) return 1;
+  c->arena.off = 0;
+  if (run_forward(c, s, audio, B, T, false, false, 0)) return 1;
+  head_probs(s, c->logits_pad, c->L.VP, logits, probs, B * (T / 320), c->cfg.n_events);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { c->err = std::string("amt_forward: ") + hipGetErrorString(e); return 1; }
+  return 0;
+}
+
+int32_t amt_forward_backward(amt_ctx* c, const void* audio, const float* labels, int32_t B, int32_t T, float scale,
+                             uint64_t seed, int32_t train, float* loss_out, float* grads_flat, int32_t* grads_valid,
+                             float* logits, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (check_shape(c, B, T)) return 1;
+  if (!(scale > 0.f)) { c->err = "scale must be positive"; return 1; }
+  if (ensure_rope(c, T / 320)) return 1;
+  if (plan(c, B, T, 1, s)) return 1;
+  c->arena.off = 0;
+  if (run_forward(c, s, audio, B, T, true, train != 0, seed)) return 1;
+  if (logits) head_probs(s, c->logits_pad, c->L.VP, logits, nullptr, B * (T / 320), c->cfg.n_events);
+  if (run_backward(c, s, audio, labels, B, T, scale, train != 0, seed, grads_flat, grads_valid)) return 1;
+  (void)hipMemcpyAsync(loss_out, c->loss_acc, 2 * sizeof(float), hipMemcpyDeviceToDevice, s);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { c->err = std::string("amt_forward_backward: ") + hipGetErrorString(e); return 1; }
+  return 0;
+}
+
+uint64_t amt_workspace_bytes(const amt_ctx* c) { return c->arena.cap; }
+
+int32_t amt_adamw_step(amt_ctx* c, const float* grads_flat, float lr_base, float layer_lr_decay, float b1, float b2,
+                       float eps, float weight_decay, float clip_norm, int32_t step, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const Layout& L = c->L;
+  const size_t n = L.n_params;
+  if (!c->adam_m) {
+    HIPCHK(c, hipMalloc(&c->adam_m, n * sizeof(float)));
+    HIPCHK(c, hipMalloc(&c->adam_v, n * sizeof(float)));
+    HIPCHK(c, hipMalloc(&c->adam_upd, n * sizeof(float)));
+    HIPCHK(c, hipMalloc(&c->lr_scale, n * sizeof(float)));
+    HIPCHK(c, hipMalloc(&c->norm2, sizeof(float)));
+    HIPCHK(c, hipMemset(c->adam_m, 0, n * sizeof(float)));
+    HIPCHK(c, hipMemset(c->adam_v, 0, n * sizeof(float)));
+  }
+  if (c->lr_scale_decay != layer_lr_decay) {
+    int max_depth = 0;
+    for (const Seg& sg : L.segs) if (sg.lr_depth > max_depth) max_depth = sg.lr_depth;
+    std::vector<float> sc(n, 1.f);
+    for (const Seg& sg : L.segs) {
+      float f = sg.lr_depth >= 0 ? powf(layer_lr_decay, (float)(max_depth - sg.lr_depth)) : 1.f;
+      for (size_t i = 0; i < (size_t)sg.rows * sg.cols; ++i) sc[sg.off + i] = f;
+    }
+    HIPCHK(c, hipMemcpy(c->lr_scale, sc.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    c->lr_scale_decay = layer_lr_decay;
+  }
+  HIPCHK(c, hipMemsetAsync(c->norm2, 0, sizeof(float), s));
+  adamw_compute(s, c->params, grads_flat, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, n, lr_base, b1, b2, eps,
+                weight_decay, step, c->norm2);
+  adamw_apply(s, c->params, c->adam_upd, n, c->norm2, clip_norm);
+  return refresh(c, s);
+}
+
+}  // extern "C"

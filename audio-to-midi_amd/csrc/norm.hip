@@ -1,0 +1,110 @@
+// Row LayerNorm forward / backward (fp32 statistics via wavefront shuffles).
+// Reference: eqx.nn.LayerNorm under jax.vmap over positions / tokens, computed in float32
+// (model.py:100,117,162,190,539,546,759).
+#include "rowops.h"
+#include "kernels.h"
+
+namespace amt {
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, const float* __restrict__ w,
+                                                     const float* __restrict__ b, T* __restrict__ Y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int N) {
+  using R = RowCfg<C>;
+  constexpr int VEC = R::VEC, LPR = R::LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, rw = lane / LPR;
+  float wv[VEC], bv[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { wv[i] = w[sub * VEC + i]; bv[i] = b[sub * VEC + i]; }
+  for (long row = ((long)blockIdx.x * 4 + wave) * R::RPW + rw; row < N; row += (long)gridDim.x * R::RPB) {
+    float x[VEC];
+    loadvf<VEC>(X + row * C + sub * VEC, x);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s += x[i];
+    float mu = group_sum<LPR>(s) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { x[i] -= mu; q += x[i] * x[i]; }
+    float var = group_sum<LPR>(q) * (1.f / C);
+    float rs = 1.f / sqrtf(var + kLnEps);
+    float y[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) y[i] = x[i] * rs * wv[i] + bv[i];
+    storevf<VEC>(Y + row * C + sub * VEC, y);
+    if (sub == 0 && mean != nullptr) { mean[row] = mu; rstd[row] = rs; }
+  }
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dY, const T* __restrict__ X,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ w, const T* dRes,
+                                                     T* dX, float* __restrict__ dw,
+                                                     float* __restrict__ db, int N) {
+  using R = RowCfg<C>;
+  constexpr int VEC = R::VEC, LPR = R::LPR;
+  __shared__ float smem[C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, rw = lane / LPR;
+  float wv[VEC], aw[VEC], ab[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { wv[i] = w[sub * VEC + i]; aw[i] = 0.f; ab[i] = 0.f; }
+  for (long row = ((long)blockIdx.x * 4 + wave) * R::RPW + rw; row < N; row += (long)gridDim.x * R::RPB) {
+    float x[VEC], dy[VEC];
+    loadvf<VEC>(X + row * C + sub * VEC, x);
+    loadvf<VEC>(dY + row * C + sub * VEC, dy);
+    float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f, gy[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      x[i] = (x[i] - mu) * rs;          // xhat
+      gy[i] = dy[i] * wv[i];
+      s1 += gy[i];
+      s2 += gy[i] * x[i];
+      aw[i] += dy[i] * x[i];
+      ab[i] += dy[i];
+    }
+    s1 = group_sum<LPR>(s1) * (1.f / C);
+    s2 = group_sum<LPR>(s2) * (1.f / C);
+    float o[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = rs * (gy[i] - s1 - x[i] * s2);
+    if (dRes != nullptr) {
+      float rr[VEC];
+      loadvf<VEC>(dRes + row * C + sub * VEC, rr);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o[i] += rr[i];
+    }
+    storevf<VEC>(dX + row * C + sub * VEC, o);
+  }
+  reduce_cols_to_global<VEC, LPR>(aw, dw, smem);
+  reduce_cols_to_global<VEC, LPR>(ab, db, smem);
+}
+
+template <typename T>
+static void ln_fwd_t(hipStream_t s, const void* X, const float* w, const float* b, void* Y, float* mean, float* rstd,
+                     int N, int C) {
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((ln_fwd_kernel<T, CC>), dim3(row_grid(N, RowCfg<CC>::RPB)), dim3(256), 0, s,
+                                       (const T*)X, w, b, (T*)Y, mean, rstd, N));
+}
+template <typename T>
+static void ln_bwd_t(hipStream_t s, const void* dY, const void* X, const float* mean, const float* rstd,
+                     const float* w, const void* dRes, void* dX, float* dw, float* db, int N, int C) {
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd_kernel<T, CC>), dim3(row_grid(N, RowCfg<CC>::RPB, 512)), dim3(256), 0,
+                                       s, (const T*)dY, (const T*)X, mean, rstd, w, (const T*)dRes, (T*)dX, dw, db, N));
+}
+
+void layernorm_fwd(hipStream_t s, DType dt, const void* X, const float* w, const float* b, void* Y, float* mean,
+                   float* rstd, int N, int C) {
+  if (dt == DT_F32) ln_fwd_t<float>(s, X, w, b, Y, mean, rstd, N, C);
+  else ln_fwd_t<bf16>(s, X, w, b, Y, mean, rstd, N, C);
+}
+void layernorm_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const float* mean, const float* rstd,
+                   const float* w, const void* dRes, void* dX, float* dw, float* db, int N, int C) {
+  if (dt == DT_F32) ln_bwd_t<float>(s, dY, X, mean, rstd, w, dRes, dX, dw, db, N, C);
+  else ln_bwd_t<bf16>(s, dY, X, mean, rstd, w, dRes, dX, dw, db, N, C);
+}
+
+}  // namespace amt

@@ -1,0 +1,61 @@
+// Shared helpers for the row-wise (per token / per position) kernels: a row of C features is
+// spread over LPR = C / VEC consecutive lanes, VEC = 8 (4 for C = 4) contiguous features each,
+// so every global access is a 16-byte (bf16: 8-byte for C = 4) vector and LayerNorm statistics
+// are wavefront shuffles over LPR lanes.
+#pragma once
+#include "common.h"
+
+namespace amt {
+
+template <int C> struct RowCfg {
+  static constexpr int VEC = (C >= 8) ? 8 : 4;
+  static constexpr int LPR = C / VEC;       // lanes per row (1..32)
+  static constexpr int RPW = 64 / LPR;      // rows per wave
+  static constexpr int RPB = 4 * RPW;       // rows per 256-thread block
+};
+
+// Sum per-lane partial column sums over every lane of the block that owns the same feature
+// chunk, then atomically add the C results to global memory.  All 256 threads must call it.
+template <int VEC, int LPR>
+AMT_DEV void reduce_cols_to_global(const float (&acc)[VEC], float* gdst, float* smem /* >= VEC*LPR floats */) {
+  constexpr int C = VEC * LPR;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int sub = lane % LPR, rw = lane / LPR;
+  __syncthreads();
+  for (int t = tid; t < C; t += 256) smem[t] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    float v = acc[i];
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    if (rw == 0) atomicAdd(&smem[sub * VEC + i], v);
+  }
+  __syncthreads();
+  if (gdst != nullptr)
+    for (int t = tid; t < C; t += 256) atomicAdd(&gdst[t], smem[t]);
+}
+
+static inline int row_grid(long N, int rows_per_block, int max_blocks = 2048) {
+  long nb = (N + rows_per_block - 1) / rows_per_block;
+  if (nb > max_blocks) nb = max_blocks;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+#define AMT_DISPATCH_C(C_, ...)                         \
+  switch (C_) {                                         \
+    case 4: { constexpr int CC = 4; __VA_ARGS__; } break;     \
+    case 8: { constexpr int CC = 8; __VA_ARGS__; } break;     \
+    case 16: { constexpr int CC = 16; __VA_ARGS__; } break;   \
+    case 32: { constexpr int CC = 32; __VA_ARGS__; } break;   \
+    case 64: { constexpr int CC = 64; __VA_ARGS__; } break;   \
+    case 128: { constexpr int CC = 128; __VA_ARGS__; } break; \
+    case 256: { constexpr int CC = 256; __VA_ARGS__; } break; \
+    default: break;                                     \
+  }
+
+
+constexpr float kLnEps = 1e-5f;   // eqx.nn.LayerNorm default eps
+
+}  // namespace amt

@@ -1,0 +1,233 @@
+"""Host-side mirror of the reference's model API for the hot path.
+
+Mirrors, name for name:
+  * ``model_config``                         model.py:20-34
+  * ``OutputSequenceGenerator(conf, key)``   model.py:673-738
+      ``__call__(samples, state, rope_freqs, key, enable_dropout) -> ((logits, probs), state)``
+                                              model.py:740-769
+      ``predict(state, samples, rope_freqs) -> (logits, probs)``   model.py:771-773
+  * ``compute_loss`` (value + grads)         train.py:49-62   -> ``loss_and_grads``
+
+The reference calls the model under ``jax.vmap`` over the leading batch/window axis
+(train.py:56-58, infer.py:40); here the batch axis is part of the call: ``samples`` is
+``[B, 2, T]`` and outputs are ``[B, S, 90]``.  All compute happens in libamt_hip.so (HIP, gfx950);
+torch is used for device memory and streams only.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from . import params as _params
+from .rope import RopeFreqs, precompute_frequencies
+
+# model.py:20-34
+model_config = {
+    "dims": [4 * (2 ** i) for i in range(7)],
+    "depths": [3, 3, 3, 3, 3, 21, 3],
+    "cnn_hidden_expansion": 2.0,
+    "num_transformer_layers": 8,
+    "num_transformer_heads": 4,
+    "attention_size": 64,
+    "compressed_attention_q_size": 64,
+    "compressed_attention_kv_size": 64,
+    "transformer_dropout_rate": 0.1,
+    "transformer_hidden_expansion": 2.0,
+    "sdd_rate": 0.1,
+}
+
+_TORCH_DTYPE = {"float32": torch.float32, "bfloat16": torch.bfloat16}
+
+
+class StepOutput(NamedTuple):
+    loss: float                 # mean over the batch of the summed BCE (train.py:62, /grad_scale)
+    scaled_loss: float          # loss * scale
+    grads_flat: torch.Tensor    # fp32 [n_params], device layout, already divided by scale
+    grads_valid: bool           # train.py:320-322
+    logits: Optional[torch.Tensor]
+
+
+class OutputSequenceGenerator:
+    """The reference's model class, backed by the HIP library.
+
+    ``key`` (a JAX PRNG key in the reference) is an integer seed for the random init here;
+    pass ``key=None`` to start from zeros and load weights explicitly.
+    """
+
+    def __init__(self, conf=None, key: Optional[int] = None, *, dtype: str = "bfloat16", device="cuda:0",
+                 gamma: float = 1e-6):
+        conf = dict(model_config if conf is None else conf)
+        if dtype not in _TORCH_DTYPE:
+            raise ValueError("dtype must be 'float32' or 'bfloat16'")
+        self.conf = conf
+        self.dtype = dtype
+        self.torch_dtype = _TORCH_DTYPE[dtype]
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("OutputSequenceGenerator runs on an AMD GPU only (device must be cuda:N)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: the HIP hot path has no CPU fallback")
+        self._L = _lib.load()
+        self._cfg = _lib.make_config(conf, dtype)
+        self.n_params = int(self._L.amt_param_count(self._cfg))
+        if self.n_params == 0:
+            raise ValueError("configuration rejected by libamt_hip (see include/amt.h for constraints)")
+        self.n_events = int(self._cfg.n_events)
+        h = C.c_void_p()
+        torch.cuda.set_device(self.device)
+        if self._L.amt_create(self._cfg, self.device.index or 0, C.byref(h)) != 0:
+            raise RuntimeError("amt_create failed: " + self._L.amt_last_error(None).decode())
+        self._h = h
+        self._rope_key = None
+        if key is not None:
+            self.load_equinox_params(_params.init_equinox(conf, seed=int(key), gamma=gamma))
+
+    # ------------------------------------------------------------------ lifetime / errors
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.amt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed: {self._L.amt_last_error(self._h).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ parameters
+    def load_flat(self, flat):
+        """flat fp32 parameters in device layout (numpy array or torch tensor)."""
+        if isinstance(flat, np.ndarray):
+            flat = torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float32))
+        flat = flat.to(torch.float32).contiguous()
+        if flat.numel() != self.n_params:
+            raise ValueError(f"expected {self.n_params} parameters, got {flat.numel()}")
+        on_dev = 1 if flat.is_cuda else 0
+        self._check(self._L.amt_load_weights(self._h, _lib.ptr(flat), flat.numel(), on_dev, self._stream()),
+                    "amt_load_weights")
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def load_equinox_params(self, p):
+        """Parameters as the reference's pytree (dict of Equinox-shaped leaves)."""
+        self.load_flat(_params.equinox_to_flat(p, self.conf))
+
+    def grads_to_equinox(self, flat):
+        return _params.flat_to_equinox(np.asarray(flat), self.conf)
+
+    def weights_tensor(self) -> torch.Tensor:
+        """Zero-copy fp32 view of the context's master parameters (device layout)."""
+        ptr = self._L.amt_weights_ptr(self._h)
+        return _DevView(ptr, self.n_params, self.device).tensor()
+
+    def refresh_weights(self):
+        self._check(self._L.amt_refresh_weights(self._h, self._stream()), "amt_refresh_weights")
+
+    def set_rope(self, rope_freqs: RopeFreqs):
+        cos = np.ascontiguousarray(rope_freqs.cos_freq, dtype=np.float32)
+        sin = np.ascontiguousarray(rope_freqs.sin_freq, dtype=np.float32)
+        if cos.shape != sin.shape or cos.ndim != 2 or cos.shape[1] != self._cfg.head_dim // 2:
+            raise ValueError("rope_freqs must hold (max_pos, head_dim/2) cos/sin tables")
+        key = (cos.shape[0], float(cos[-1, -1]), float(sin[-1, 0]))
+        if key == self._rope_key:
+            return
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._L.amt_set_rope(self._h, cos.ctypes.data_as(C.c_void_p), sin.ctypes.data_as(C.c_void_p),
+                                         cos.shape[0]), "amt_set_rope")
+        self._rope_key = key
+
+    # ------------------------------------------------------------------ shape checks
+    def _prep_audio(self, samples):
+        if not torch.is_tensor(samples):
+            samples = torch.as_tensor(np.asarray(samples))
+        if samples.dim() == 2:
+            samples = samples[None]
+        if samples.dim() != 3 or samples.shape[1] != 2:
+            raise ValueError(f"samples must be [B, 2, T] (stereo), got {tuple(samples.shape)}")
+        T = samples.shape[2]
+        if T % 320 != 0 or T // 320 < 16:
+            raise ValueError("T must be a multiple of 320 samples and at least 16 frames long")
+        return samples.to(device=self.device, dtype=self.torch_dtype).contiguous()
+
+    def _ensure_rope(self, rope_freqs, S):
+        if rope_freqs is not None:
+            if rope_freqs.cos_freq.shape[0] < S:
+                # the reference would fail to broadcast here (rope.py:40-41); refuse as well
+                raise ValueError(f"rope_freqs has {rope_freqs.cos_freq.shape[0]} positions but the clip has {S} frames")
+            self.set_rope(rope_freqs)
+
+    # ------------------------------------------------------------------ inference
+    def predict(self, state, samples, rope_freqs: Optional[RopeFreqs] = None):
+        """model.predict(state, samples, rope_freqs) under vmap -> (logits, probs), fp32 [B,S,90]."""
+        del state
+        a = self._prep_audio(samples)
+        B, _, T = a.shape
+        S = T // 320
+        self._ensure_rope(rope_freqs, S)
+        logits = torch.empty(B, S, self.n_events, dtype=torch.float32, device=self.device)
+        probs = torch.empty_like(logits)
+        self._check(self._L.amt_forward(self._h, _lib.ptr(a), B, T, _lib.ptr(logits), _lib.ptr(probs),
+                                        self._stream()), "amt_forward")
+        return logits, probs
+
+    def __call__(self, samples, state=None, rope_freqs: Optional[RopeFreqs] = None, key=None,
+                 enable_dropout: bool = False):
+        if enable_dropout:
+            raise NotImplementedError("training-mode forward is exposed through loss_and_grads(train=True)")
+        return self.predict(state, samples, rope_freqs), state
+
+    # ------------------------------------------------------------------ training forward + backward
+    def loss_and_grads(self, audio, labels, scale: float = 1.0, seed: int = 0, train: bool = True,
+                       rope_freqs: Optional[RopeFreqs] = None, return_logits: bool = False,
+                       grads_out: Optional[torch.Tensor] = None, sync: bool = True):
+        """compute_loss + the gradient half of compute_training_step (train.py:49-62, 292-322)."""
+        a = self._prep_audio(audio)
+        B, _, T = a.shape
+        S = T // 320
+        y = torch.as_tensor(labels).to(device=self.device, dtype=torch.float32).contiguous()
+        if tuple(y.shape) != (B, S, self.n_events):
+            raise ValueError(f"labels must be [{B}, {S}, {self.n_events}], got {tuple(y.shape)}")
+        self._ensure_rope(rope_freqs, S)
+        grads = grads_out if grads_out is not None else torch.empty(self.n_params, dtype=torch.float32,
+                                                                    device=self.device)
+        loss = torch.empty(2, dtype=torch.float32, device=self.device)
+        valid = torch.empty(1, dtype=torch.int32, device=self.device)
+        logits = torch.empty(B, S, self.n_events, dtype=torch.float32, device=self.device) if return_logits else None
+        self._check(self._L.amt_forward_backward(self._h, _lib.ptr(a), _lib.ptr(y), B, T, float(scale), int(seed),
+                                                 1 if train else 0, _lib.ptr(loss), _lib.ptr(grads), _lib.ptr(valid),
+                                                 _lib.ptr(logits), self._stream()), "amt_forward_backward")
+        if not sync:
+            return loss, grads, valid, logits
+        lv = loss.cpu().numpy()
+        return StepOutput(float(lv[0]), float(lv[1]), grads, bool(int(valid.item())), logits)
+
+    def adamw_step(self, grads_flat, lr_base, step, layer_lr_decay=0.7, b1=0.9, b2=0.999, eps=1e-3,
+                   weight_decay=0.005, clip_norm=1.0):
+        """optimizer half of compute_training_step (train.py:324-325, 646-729)."""
+        self._check(self._L.amt_adamw_step(self._h, _lib.ptr(grads_flat), float(lr_base), float(layer_lr_decay),
+                                           float(b1), float(b2), float(eps), float(weight_decay), float(clip_norm),
+                                           int(step), self._stream()), "amt_adamw_step")
+
+    def workspace_bytes(self) -> int:
+        return int(self._L.amt_workspace_bytes(self._h))
+
+
+class _DevView:
+    """Wrap a raw device pointer as a torch tensor through __cuda_array_interface__."""
+
+    def __init__(self, ptr, n, device):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 3}
+        self._device = device
+
+    def tensor(self):
+        return torch.as_tensor(self, device=self._device)

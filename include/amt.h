@@ -1,0 +1,123 @@
+/* amt.h — C ABI of the MI355X-native audio-to-MIDI hot path (libamt_hip.so).
+ *
+ * What this boundary replaces in the reference (kasper0406/audio-to-midi @ 2025-03-28):
+ *   - OutputSequenceGenerator.__call__ / .predict            model.py:740-773
+ *     (always called under jax.vmap over the batch/window axis: train.py:56-58, infer.py:40)
+ *   - compute_loss (value_and_grad of the batched BCE loss)   train.py:39-62
+ *   - the fwd/bwd part of compute_training_step               train.py:259-332
+ *     (scale, accumulate in fp32, unscale, finite check)
+ * The reference has no FFI under the model (it is JAX/XLA); the conventions below copy the only
+ * native boundary it has, rust-plugins/src/cbinds.rs:9-91: POD structs, plain pointers + sizes,
+ * dtype implied by configuration, paired create/free, no global state, re-entrant per context.
+ * Improvement over cbinds.rs: errors are returned as codes + amt_last_error() instead of a panic.
+ *
+ * Conventions
+ *   - All tensor pointers are DEVICE pointers, contiguous, row-major; the CALLER owns them.
+ *   - The context owns weights, the RoPE table and the activation workspace.
+ *   - Every call is asynchronous on the given HIP stream; nothing synchronises internally
+ *     (the workspace is (re)allocated on the first call with a new (B, T): do that call outside
+ *     hipGraph capture).
+ *   - One context per device per process; a context is not thread-safe.
+ *   - Activation dtype (AMT_F32 or AMT_BF16) is fixed at creation: `audio` uses it; logits,
+ *     probs, labels, losses and gradients are always float32.
+ *   - Return value 0 = success; otherwise amt_last_error(ctx) (or amt_last_error(NULL) for a
+ *     failed amt_create) describes the failure.
+ */
+#ifndef AMT_H_
+#define AMT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMT_F32 0
+#define AMT_BF16 1
+#define AMT_MAX_STAGES 8
+
+/* mirrors model_config (model.py:20-34) + MIDI_EVENT_VOCCAB_SIZE (audio_to_midi_dataset.py:26) */
+typedef struct amt_config {
+  int32_t n_stages;                 /* 7 */
+  int32_t dims[AMT_MAX_STAGES];     /* 4,8,16,32,64,128,256 (dims[i] = 4 << i is required) */
+  int32_t depths[AMT_MAX_STAGES];   /* 3,3,3,3,3,21,3 */
+  int32_t n_layer_pairs;            /* num_transformer_layers = 8 (local + global each) */
+  int32_t n_heads;                  /* 4 */
+  int32_t head_dim;                 /* attention_size = 64 */
+  int32_t kv_compress;              /* compressed_attention_kv_size = 64 */
+  int32_t ffn_inter;                /* hidden * transformer_hidden_expansion = 512 */
+  int32_t n_events;                 /* 90 */
+  int32_t local_window;             /* 16 (model.py:635) */
+  float dropout_rate;               /* transformer_dropout_rate = 0.1 */
+  int32_t act_dtype;                /* AMT_F32 | AMT_BF16 */
+} amt_config;
+
+typedef struct amt_ctx amt_ctx;
+
+/* one leaf (or fused group of leaves) of the flat parameter vector, in device layout */
+typedef struct amt_segment {
+  char name[96];      /* e.g. "layers.5.3.point_conv_1.weight", "tl.4.wqc" */
+  uint64_t offset;    /* element offset into the flat fp32 vector */
+  int32_t rows, cols; /* device-layout shape (cols == 1 for vectors) */
+  int32_t lr_depth;   /* conv depth label for layer-wise LR decay (train.py:646-672), -1 = default */
+} amt_segment;
+
+void amt_default_config(amt_config* cfg);
+
+/* Flat parameter layout (no GPU needed). */
+uint64_t amt_param_count(const amt_config* cfg);
+int32_t amt_layout_count(const amt_config* cfg);
+int32_t amt_layout_segment(const amt_config* cfg, int32_t index, amt_segment* out);
+
+int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out);
+void amt_destroy(amt_ctx* ctx);
+const char* amt_last_error(const amt_ctx* ctx);
+
+/* Copy `n` fp32 parameters (device layout) into the context and derive the compute copies.
+ * `flat` is a host pointer if on_device == 0, else a device pointer. */
+int32_t amt_load_weights(amt_ctx* ctx, const float* flat, uint64_t n, int32_t on_device, void* stream);
+/* Device pointer to the context's fp32 master parameters (for in-place optimizer updates)... */
+float* amt_weights_ptr(amt_ctx* ctx);
+/* ...after which the bf16 / transposed compute copies must be re-derived: */
+int32_t amt_refresh_weights(amt_ctx* ctx, void* stream);
+
+/* RoPE table (rope.py:12-22): host pointers, [n_pos][head_dim/2] each.  If never called the
+ * context builds the table itself for max(512, frames) positions with the reference's float32
+ * arithmetic. */
+int32_t amt_set_rope(amt_ctx* ctx, const float* cos_table, const float* sin_table, int32_t n_pos);
+
+/* frames produced for T samples (T must be a multiple of 320) */
+int32_t amt_num_frames(const amt_config* cfg, int32_t T);
+
+/* Inference: model.predict under vmap (model.py:771-773, infer.py:40).
+ * audio [B][2][T] (act dtype) -> logits, probs [B][S][n_events] float32 (either may be NULL). */
+int32_t amt_forward(amt_ctx* ctx, const void* audio, int32_t B, int32_t T, float* logits, float* probs,
+                    void* stream);
+
+/* Training forward + backward: compute_loss + the gradient half of compute_training_step.
+ *   labels     [B][S][n_events] float32
+ *   scale      loss scale (reference grad_scale; 1.0 for bf16)
+ *   seed       dropout seed; train != 0 enables attention-weight and FFN-output dropout
+ *   loss_out   device float[2]: {loss (mean over batch of the summed BCE), scaled_loss}
+ *   grads_flat device float[amt_param_count]: d loss / d params, already divided by `scale`
+ *   grads_valid device int32: 1 if every gradient is finite, else 0
+ *   logits     optional [B][S][n_events] float32 */
+int32_t amt_forward_backward(amt_ctx* ctx, const void* audio, const float* labels, int32_t B, int32_t T,
+                             float scale, uint64_t seed, int32_t train, float* loss_out, float* grads_flat,
+                             int32_t* grads_valid, float* logits, void* stream);
+
+/* Bytes of activation workspace currently held (diagnostics). */
+uint64_t amt_workspace_bytes(const amt_ctx* ctx);
+
+/* ---- next-row: optimizer step of compute_training_step (train.py:324-325, 646-729) ----------
+ * optax.adamw(b1, b2, eps, weight_decay) per depth label, then clip_by_global_norm(1.0) on the
+ * UPDATES, then apply.  lr_base is the scheduled base learning rate for this step; conv leaves
+ * use lr_base * layer_lr_decay^(max_depth - depth).  State (m, v) lives in the context. */
+int32_t amt_adamw_step(amt_ctx* ctx, const float* grads_flat, float lr_base, float layer_lr_decay, float b1,
+                       float b2, float eps, float weight_decay, float clip_norm, int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMT_H_ */

@@ -1,0 +1,68 @@
+/* amt_ops.h — op-level C entry points of libamt_hip.so.
+ *
+ * These expose the individual HIP kernels behind amt.h so that tests/ can check each of them
+ * against the oracle in isolation (same conventions as amt.h: device pointers, row-major,
+ * channels-last activations, asynchronous on `stream`, return 0 on success).  `dtype` is the
+ * activation dtype (AMT_F32 | AMT_BF16) of every `void*` tensor unless stated otherwise.
+ * Reference op for each entry point is cited in the kernel sources (audio-to-midi_amd/csrc/).
+ */
+#ifndef AMT_OPS_H_
+#define AMT_OPS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Y = epilogue(X[N,K] . W[M,K]^T)  — eqx.nn.Linear / 1x1 Conv1d (model.py:141-153, 213-222, 300-334) */
+int32_t amt_op_gemm_nt(int32_t dtype, int32_t epi, const void* X, int32_t ldx, const void* W, int32_t ldw,
+                       int32_t N, int32_t M, int32_t K, const float* bias, void* Y, int32_t ldy, void* Y2,
+                       int32_t ldy2, const void* R, int32_t ldr, const void* U, int32_t ldu, const float* gamma,
+                       uint64_t seed, uint32_t stream_id, float drop_p, void* stream);
+/* dW[M,Kp] += G[N,M]^T . A[N,Kp] ; dbias[M] += colsum(G) */
+int32_t amt_op_gemm_tn_wgrad(int32_t dtype, const void* G, int32_t ldg, const void* A, int32_t lda, int32_t N,
+                             int32_t M, int32_t Kp, float* dW, int32_t ldw, float* dbias, int32_t M_store,
+                             void* stream);
+int32_t amt_op_layernorm_fwd(int32_t dtype, const void* X, const float* w, const float* b, void* Y, float* mean,
+                             float* rstd, int32_t N, int32_t C, void* stream);
+int32_t amt_op_layernorm_bwd(int32_t dtype, const void* dY, const void* X, const float* mean, const float* rstd,
+                             const float* w, const void* dRes, void* dX, float* dw, float* db, int32_t N, int32_t C,
+                             void* stream);
+int32_t amt_op_stem_fwd(int32_t dtype, const void* audio, const float* w, const float* b, const float* lnw,
+                        const float* lnb, void* Y, int32_t B, int32_t T, void* stream);
+int32_t amt_op_stem_bwd(int32_t dtype, const void* audio, const void* dY, const float* w, const float* b,
+                        const float* lnw, float* dw, float* db, float* dlnw, float* dlnb, int32_t B, int32_t T,
+                        void* stream);
+int32_t amt_op_dwln_fwd(int32_t dtype, const void* X, const float* wdw, const float* bdw, const float* lnw,
+                        const float* lnb, void* Y, float* mean, float* rstd, int32_t B, int32_t L, int32_t C,
+                        void* stream);
+int32_t amt_op_dwln_bwd(int32_t dtype, const void* dY, const void* X, const float* wdw, const float* bdw,
+                        const float* mean, const float* rstd, const float* lnw, void* dD, float* dlnw, float* dlnb,
+                        int32_t B, int32_t L, int32_t C, void* stream);
+int32_t amt_op_dwconv_bwd(int32_t dtype, const void* dD, const void* X, const float* wdw, const void* dRes, void* dX,
+                          float* dwdw, float* dbdw, int32_t B, int32_t L, int32_t C, void* stream);
+int32_t amt_op_scale_bwd(int32_t dtype, const void* dY, const void* Z, const float* gamma, void* dZ, float* dgamma,
+                         int32_t N, int32_t C, void* stream);
+/* attention core on raw projections; local != 0 selects the windowed kernel */
+int32_t amt_op_attn_fwd(int32_t dtype, int32_t local, const void* QC, int32_t ldqc, const void* KV, int32_t ldkv,
+                        void* O, int32_t ldo, float* LSE, const float* cos_t, const float* sin_t, int32_t B, int32_t S,
+                        int32_t H, uint64_t seed, uint32_t stream_id, float drop_p, void* stream);
+int32_t amt_op_attn_bwd(int32_t dtype, int32_t local, const void* QC, int32_t ldqc, const void* KV, int32_t ldkv,
+                        const void* O, int32_t ldo, const float* LSE, const float* cos_t, const float* sin_t,
+                        int32_t B, int32_t S, int32_t H, uint64_t seed, uint32_t stream_id, float drop_p,
+                        const void* dO, int32_t lddo, void* dQC, int32_t lddqc, void* dKV, int32_t lddkv, float* delta,
+                        void* stream);
+int32_t amt_op_bce_loss(int32_t dtype, const float* logits_pad, int32_t ldl, const float* labels, float* loss_acc,
+                        void* dlogits, int32_t ldd, int32_t N, int32_t V, float scale, int32_t B, void* stream);
+int32_t amt_op_dropout(int32_t dtype, const void* X, void* Y, uint64_t n, uint64_t seed, uint32_t stream_id,
+                       float drop_p, void* stream);
+/* host mirrors of the counter-based dropout RNG (so the oracle can rebuild the device's masks) */
+uint32_t amt_rng_u32(uint64_t seed, uint32_t stream_id, uint32_t idx);
+uint32_t amt_drop_threshold24(float drop_p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMT_OPS_H_ */
