@@ -1,0 +1,99 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, the
+flat layout restated in Python equals the library's, and the Equinox <-> device mapping is a
+bijection.  (No compute calls: there is no GPU here.)"""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import audio_to_midi_amd as amt
+from audio_to_midi_amd import lib, params
+from oracle import np_model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = lib.load()
+    declared = set()
+    for h in ("amt.h", "amt_ops.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        declared |= set(re.findall(r"\b(amt_[a-z0-9_]+)\s*\(", src))
+    assert declared, "no declarations found"
+    for name in sorted(declared):
+        assert hasattr(L, name), f"libamt_hip.so does not export {name}"
+    assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
+
+
+def test_layout_python_equals_library(small_conf):
+    for conf in (amt.model_config, small_conf):
+        a, b = params.device_layout(conf), params.library_layout(conf)
+        assert a == b
+        cfg = lib.make_config(conf, "bfloat16")
+        assert lib.load().amt_param_count(cfg) == params.param_count(conf)
+    assert params.param_count(amt.model_config) == 11_606_230
+
+
+def test_lr_depth_labels_follow_reference():
+    """train.py:646-672: depth = sum(depths[:stage]) + index in the Sequential; 40 conv depths"""
+    segs = params.device_layout(amt.model_config)
+    depth = {s.name: s.lr_depth for s in segs}
+    assert depth["layers.0.0.conv.weight"] == 0 and depth["layers.0.3.gamma"] == 3
+    assert depth["layers.1.0.conv.weight"] == 3 and depth["layers.5.21.gamma"] == 36
+    assert depth["layers.6.0.norm.weight"] == 36 and depth["layers.6.3.gamma"] == 39
+    assert depth["tl.0.wqc"] == -1 and depth["decoder.norm.bias"] == -1
+    assert max(depth.values()) == 39
+
+
+def test_equinox_device_mapping_is_a_bijection(small_conf):
+    conf = small_conf
+    p = np_model.init_params(conf, 9, gamma=0.5)
+    flat = params.equinox_to_flat(p, conf)
+    assert flat.dtype == np.float32 and flat.size == params.param_count(conf)
+    back = params.flat_to_equinox(flat, conf)
+    assert list(back) == list(params.equinox_shapes(conf)) == list(np_model.param_shapes(conf))
+    for k, v in p.items():
+        assert back[k].shape == v.shape and np.array_equal(back[k], v.astype(np.float32)), k
+    # every flat element is hit exactly once
+    marks = params.flat_to_equinox(np.arange(flat.size, dtype=np.float64), conf)
+    allv = np.concatenate([v.reshape(-1) for v in marks.values()])
+    assert np.array_equal(np.sort(allv), np.arange(flat.size))
+
+
+def test_glu_permutation_pairs_gate_rows():
+    perm = params.glu_row_perm(512)
+    assert sorted(perm) == list(range(1024))
+    for r in range(0, 1024, 32):
+        assert np.array_equal(perm[r + 16: r + 32], perm[r: r + 16] + 512)
+
+
+def test_rope_table_matches_oracle():
+    a = amt.precompute_frequencies(64, 512)
+    c, s = np_model.precompute_frequencies(64, 512)
+    assert np.array_equal(a.cos_freq, c) and np.array_equal(a.sin_freq, s)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        amt.OutputSequenceGenerator(amt.model_config)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "audio-to-midi_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.replace("the oracle", "").replace("oracle consumes", ""), (f, "mentions oracle")
+
+
+def test_synthetic_inputs_follow_the_data_contract():
+    a, y = amt.synth.make_batch(2, 16000, seed=1)
+    assert a.shape == (2, 2, 16000) and y.shape == (2, 50, 90)
+    assert np.allclose((a.astype(np.float64) ** 2).mean(axis=(1, 2)), 1.0, atol=2e-3)
+    assert np.array_equal(a, a.astype(np.float16).astype(np.float32))
+    assert y.min() >= 0.005 and y.max() <= 0.995 and np.all(y[:, :, 88:] == np.float32(0.005))

@@ -1,0 +1,135 @@
+"""CPU tests that pin the oracle ("parity unpinned" by the reference: it ships no tests):
+two independent restatements must agree, plus hand-derivable known answers."""
+import math
+
+import numpy as np
+import torch
+
+from oracle import np_model as nm
+from oracle import torch_model as tm
+
+
+def test_param_inventory_matches_table_p():
+    assert nm.num_params() == 11_606_230
+    assert len(nm.param_shapes()) == 411
+    sh = nm.param_shapes()
+    cnn = sum(int(np.prod(v)) for k, v in sh.items() if k.startswith("layers.") or k in ("norm.weight", "norm.bias"))
+    tr = sum(int(np.prod(v)) for k, v in sh.items() if k.startswith("transformer."))
+    dec = sum(int(np.prod(v)) for k, v in sh.items() if k.startswith("decoder."))
+    assert (cnn, tr, dec) == (2_370_684, 9_211_904, 23_642)
+
+
+def test_numpy_and_torch_restatements_agree(small_conf):
+    conf = small_conf
+    p = nm.init_params(conf, 1234, gamma=1.0)
+    rng = np.random.default_rng(0)
+    for T in (320 * 50, 320 * 32):          # padded (S=50 -> 6 pad rows) and pad-free (S=32) local windows
+        x = rng.standard_normal((2, 2, T))
+        l_t, p_t = tm.forward(tm.to_torch(p), torch.as_tensor(x), conf)
+        for b in range(2):
+            l_n, p_n = nm.forward(p, x[b], conf)
+            assert np.abs(l_n - l_t[b].numpy()).max() < 1e-10
+            assert np.abs(p_n - p_t[b].numpy()).max() < 1e-10
+    y = rng.uniform(0.005, 0.995, (2, 32, 90))
+    loss_t, _, _ = tm.loss_and_grads(p, x, y, conf, scale=3.0)
+    assert abs(loss_t - nm.batch_loss(p, x, y, conf, scale=3.0)) < 1e-8 * abs(loss_t)
+
+
+def test_autograd_matches_finite_differences(small_conf):
+    conf = small_conf
+    p = nm.init_params(conf, 5, gamma=1.0)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((1, 2, 320 * 18))
+    y = rng.uniform(0.005, 0.995, (1, 18, 90))
+    _, _, g = tm.loss_and_grads(p, x, y, conf)
+    probes = [("layers.0.0.conv.weight", (1, 0, 2)), ("layers.5.2.point_conv_1.weight", (3, 5, 0)),
+              ("layers.3.1.depth_conv.weight", (4, 0, 6)), ("layers.2.1.gamma", (3,)),
+              ("transformer.layers.local_attention.attention_block.self_attention.key_up_proj.weight", (1, 70, 9)),
+              ("transformer.layers.global_attention.feed_forward_block.attention_to_intermediate_proj.bias", (0, 600)),
+              ("decoder.decoder_pooling.weight", (40, 17))]
+    for name, idx in probes:
+        eps = 1e-5
+        hi = {k: v.copy() for k, v in p.items()}; hi[name][idx] += eps
+        lo = {k: v.copy() for k, v in p.items()}; lo[name][idx] -= eps
+        fd = (nm.batch_loss(hi, x, y, conf) - nm.batch_loss(lo, x, y, conf)) / (2 * eps)
+        assert abs(fd - g[name][idx]) <= 1e-5 * max(1.0, abs(fd)), (name, fd, g[name][idx])
+
+
+def test_rope_known_answers():
+    cos, sin = nm.precompute_frequencies(64, 300)
+    assert cos.shape == (300, 32) and cos.dtype == np.float32
+    assert np.all(cos[0] == 1) and np.all(sin[0] == 0)             # position 0 is the identity
+    assert abs(math.cos(1.0) - cos[1, 0]) < 1e-7                    # inv_freq[0] = 1
+    inv31 = 10000.0 ** (-62 / 64)
+    assert abs(math.sin(5 * inv31) - sin[5, 31]) < 1e-6
+    x = np.random.default_rng(0).standard_normal((20, 4, 64))
+    y = nm.calculate_rope(x, cos, sin)
+    assert np.allclose(y[0], x[0])
+    n_in = x[..., 0::2] ** 2 + x[..., 1::2] ** 2
+    n_out = y[..., 0::2] ** 2 + y[..., 1::2] ** 2
+    assert np.allclose(n_in, n_out, rtol=1e-6)                      # pair norms preserved
+
+
+def test_layernorm_and_block_known_answers():
+    w, b = np.arange(1.0, 9.0), np.arange(8.0) * 0.5
+    assert np.allclose(nm.layer_norm(np.full((8, 3), 2.5), w, b, axis=0), np.repeat(b[:, None], 3, 1))
+    conf = dict(nm.MODEL_CONFIG); conf["depths"] = [1] * 7; conf["num_transformer_layers"] = 1
+    p = nm.init_params(conf, 3, gamma=0.0)
+    x = np.random.default_rng(0).standard_normal((16, 100))
+    assert np.array_equal(nm.block(p, "layers.2.1.", x), x)         # gamma = 0: identity
+    p = nm.init_params(conf, 3, gamma=1e-6)
+    p1 = dict(p); p1["layers.2.1.gamma"] = np.ones(16)
+    branch = nm.block(p1, "layers.2.1.", x) - x
+    assert np.linalg.norm(nm.block(p, "layers.2.1.", x) - x) <= 1e-6 * np.linalg.norm(branch) * (1 + 1e-9)
+
+
+def test_frame_counts_and_window_geometry():
+    for T, S in ((80000, 250), (160000, 500)):
+        L = T // 5
+        for _ in range(6):
+            L //= 2
+        assert L == S
+    assert nm.local_window_geometry(250) == (3, 3, 31, 8)
+    assert nm.local_window_geometry(500) == (2, 2, 62, 8)
+    assert nm.local_window_geometry(256) == (0, 0, 31, 8)
+
+
+def _local_count(S):
+    pl, pr, nwin, st = nm.local_window_geometry(S)
+    cnt = np.zeros(S)
+    for w in range(nwin):
+        for o in range(16):
+            if w * st + o < S:
+                cnt[w * st + o] += 1
+    return cnt
+
+
+def test_local_attention_cover_count_and_shift_quirk():
+    assert np.array_equal(_local_count(250), np.array([1] * 8 + [2] * 240 + [1] * 2))
+    assert np.array_equal(_local_count(256), np.array([1] * 8 + [2] * 240 + [1] * 8))
+    # shift-by-3 at S = 250: perturbing input token t moves the local-attention output only in rows
+    # covering padded position t + 3 (model.py:421-471 scatters padded coordinates into an unpadded buffer)
+    rng = np.random.default_rng(0)
+    lp = {"Wq": rng.standard_normal((256, 256)) / 16, "Wkvd": rng.standard_normal((64, 256)) / 16,
+          "Wku": rng.standard_normal((256, 64)) / 8, "Wvu": rng.standard_normal((256, 64)) / 8,
+          "Wo": rng.standard_normal((256, 256)) / 16}
+    cos, sin = nm.precompute_frequencies(64, 300)
+    x = rng.standard_normal((250, 256))
+    base = nm.local_self_attention(lp, x, cos, sin, 4)
+    t = 100
+    x2 = x.copy(); x2[t] += 1.0
+    diff = np.abs(nm.local_self_attention(lp, x2, cos, sin, 4) - base).max(axis=1)
+    changed = np.nonzero(diff > 1e-12)[0]
+    pos = t + 3
+    lo, hi = (pos // 8 - 1) * 8, (pos // 8) * 8 + 15
+    assert changed.min() >= lo and changed.max() <= hi and diff[pos] > 1e-12
+    # rows 0..2 see only zero-pad tokens of their own position: the last three tokens never reach the output
+    x3 = x.copy(); x3[247:] += 1.0
+    d3 = np.abs(nm.local_self_attention(lp, x3, cos, sin, 4) - base).max(axis=1)
+    assert d3[:232].max() == 0 and d3[240:].max() > 0           # they still act as keys/values of window 30
+
+
+def test_bce_known_answer():
+    y = np.random.default_rng(0).uniform(0, 1, (7, 90))
+    assert abs(nm.loss_from_output(np.zeros((7, 90)), y) - 7 * 90 * math.log(2)) < 1e-9
+    assert abs(nm.loss_from_output(np.zeros((7, 90)), y, scale=4.0) - 4 * 7 * 90 * math.log(2)) < 1e-9

@@ -1,0 +1,86 @@
+"""Helpers shared by the GPU parity tests: ctypes calls on torch tensors + numpy mirrors."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import audio_to_midi_amd as amt
+from audio_to_midi_amd import lib as L
+
+TD = {"float32": torch.float32, "bfloat16": torch.bfloat16}
+DT = {"float32": L.AMT_F32, "bfloat16": L.AMT_BF16}
+# (abs + rel*|ref|) tolerances per activation dtype for single ops
+TOL = {"float32": (2e-5, 2e-5), "bfloat16": (2e-2, 2e-2)}
+
+
+def dev(x, dtype="float32"):
+    return torch.as_tensor(np.ascontiguousarray(x)).to(device="cuda", dtype=TD[dtype] if isinstance(dtype, str) else dtype).contiguous()
+
+
+def f32(x):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+
+
+def rounded(x, dtype):
+    """value of x after storage in the activation dtype (numpy float64 out)"""
+    t = torch.as_tensor(np.asarray(x, dtype=np.float64)).to(TD[dtype])
+    return t.to(torch.float64).numpy()
+
+
+def P(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    fn = getattr(L.load(), name)
+    rc = fn(*args)
+    torch.cuda.synchronize()
+    assert rc == 0, f"{name} returned {rc}"
+
+
+def host(t):
+    return t.detach().to(torch.float64).cpu().numpy()
+
+
+def check(got, ref, dtype, scale=1.0, what=""):
+    a, r = TOL[dtype]
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = np.abs(got - ref)
+    bound = (a * scale) + r * np.abs(ref)
+    bad = err > bound
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.size} off; max err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)} (ref {ref.flat[err.argmax()]:.4f})"
+
+
+def rel_l2(got, ref):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30))
+
+
+# ---- numpy mirror of the device's counter-based dropout RNG (csrc/common.h: rng_u32) ----
+def _mix32(x):
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d); x ^= x >> np.uint32(15)
+    x *= np.uint32(0x846ca68b); x ^= x >> np.uint32(16)
+    return x
+
+
+def rng_u32(seed, stream_id, idx):
+    idx = np.asarray(idx, dtype=np.uint32)
+    s0 = np.uint32(seed & 0xFFFFFFFF); s1 = np.uint32((seed >> 32) & 0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        h = _mix32(idx ^ np.uint32(0x9e3779b9))
+        h = _mix32(h ^ s0 ^ np.uint32((stream_id * 0x85ebca6b) & 0xFFFFFFFF))
+        h = _mix32(h + s1 + np.uint32(0x165667b1))
+    return h
+
+
+def keep_mask(seed, stream_id, idx, p):
+    thr = int(np.rint(np.float32(p) * np.float32(16777216.0)))
+    return ((rng_u32(seed, stream_id, idx) >> np.uint32(8)) >= np.uint32(thr)).astype(np.float64), 1.0 - thr / 16777216.0
