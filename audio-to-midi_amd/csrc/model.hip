@@ -183,11 +183,13 @@ struct Arena {
   char* base = nullptr;
   size_t cap = 0, off = 0, peak = 0;
   bool dry = false;
+  bool overflow = false;
   void* alloc(size_t bytes) {
     size_t o = (off + 255) & ~(size_t)255;
     off = o + bytes;
     if (off > peak) peak = off;
     if (dry) return reinterpret_cast<void*>(o + 4096);  // fake non-null address, never dereferenced
+    if (off > cap) { overflow = true; return base; }     // never hand out memory past the plan
     return base + o;
   }
 };
@@ -646,8 +648,8 @@ int plan(amt_ctx* c, int B, int T, int train_mode, hipStream_t s) {
   dryA.dry = true;
   Arena keep = c->arena;
   c->arena = dryA;
-  run_forward(c, s, nullptr, B, T, train_mode == 1, false, 0);
-  if (train_mode == 1) run_backward(c, s, nullptr, nullptr, B, T, 1.f, false, 0, nullptr, nullptr);
+  run_forward(c, s, nullptr, B, T, train_mode == 1, true, 0);
+  if (train_mode == 1) run_backward(c, s, nullptr, nullptr, B, T, 1.f, true, 0, nullptr, nullptr);
   size_t need = c->arena.peak + 4096;
   c->arena = keep;
   if (need > c->arena.cap) {
@@ -808,6 +810,7 @@ int32_t amt_forward(amt_ctx* c, const void* audio, int32_t B, int32_t T, float* 
   if (plan(c, B, T, 0, s)) return 1;
   c->arena.off = 0;
   if (run_forward(c, s, audio, B, T, false, false, 0)) return 1;
+  if (c->arena.overflow) { c->err = "internal error: workspace plan too small"; return 1; }
   head_probs(s, c->logits_pad, c->L.VP, logits, probs, B * (T / 320), c->cfg.n_events);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { c->err = std::string("amt_forward: ") + hipGetErrorString(e); return 1; }
@@ -826,6 +829,7 @@ int32_t amt_forward_backward(amt_ctx* c, const void* audio, const float* labels,
   if (run_forward(c, s, audio, B, T, true, train != 0, seed)) return 1;
   if (logits) head_probs(s, c->logits_pad, c->L.VP, logits, nullptr, B * (T / 320), c->cfg.n_events);
   if (run_backward(c, s, audio, labels, B, T, scale, train != 0, seed, grads_flat, grads_valid)) return 1;
+  if (c->arena.overflow) { c->err = "internal error: workspace plan too small"; return 1; }
   (void)hipMemcpyAsync(loss_out, c->loss_acc, 2 * sizeof(float), hipMemcpyDeviceToDevice, s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { c->err = std::string("amt_forward_backward: ") + hipGetErrorString(e); return 1; }

@@ -27,8 +27,16 @@ def rounded(x, dtype):
     return t.to(torch.float64).numpy()
 
 
+_KEEP = []
+
+
 def P(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    """device pointer of a tensor; the tensor is kept alive until the next call() returns
+    (a temporary passed inline would otherwise be freed, and its block reused, before the launch)"""
+    if t is None:
+        return None
+    _KEEP.append(t)
+    return C.c_void_p(t.data_ptr())
 
 
 def stream():
@@ -39,6 +47,7 @@ def call(name, *args):
     fn = getattr(L.load(), name)
     rc = fn(*args)
     torch.cuda.synchronize()
+    _KEEP.clear()
     assert rc == 0, f"{name} returned {rc}"
 
 
