@@ -15,6 +15,7 @@
 // consecutive head-dim features: row statistics are two xor-shuffles, outputs are 8-byte vectors.
 #include "common.h"
 #include "kernels.h"
+#include "prof.h"
 
 namespace amt {
 
@@ -420,6 +421,8 @@ template <typename K> static void set_max_lds(K kernel, size_t bytes) {
 
 void attn_global_fwd(hipStream_t s, DType dt, const AttnArgs& a) {
   dim3 grid((a.S + 63) / 64, a.H, a.B);
+  ProfScope ps(s, "attn_global_fwd", 4.0 * a.B * a.H * (double)a.S * a.S * 64,
+               4.0 * a.B * a.S * a.H * 64 * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) {
     size_t lds = (size_t)(64 * 2 + 64) * ALD * sizeof(float);
     static bool once = (set_max_lds(attn_global_fwd_kernel<float>, 96 * 1024), true);
@@ -433,6 +436,8 @@ void attn_global_fwd(hipStream_t s, DType dt, const AttnArgs& a) {
 
 void attn_global_bwd(hipStream_t s, DType dt, const AttnBwdArgs& a) {
   dim3 grid((a.f.S + 63) / 64, a.f.H, a.f.B);
+  ProfScope ps(s, "attn_global_bwd", 8.0 * a.f.B * a.f.H * (double)a.f.S * a.f.S * 64,
+               8.0 * a.f.B * a.f.S * a.f.H * 64 * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) {
     size_t lds1 = (size_t)(64 * 2 + 64) * ALD * sizeof(float);
     size_t lds2 = (size_t)(64 * 2 + 128) * ALD * sizeof(float) + 128 * sizeof(float);
@@ -703,6 +708,8 @@ __global__ __launch_bounds__(64) void attn_local_bwd_kernel(AttnBwdArgs ba, int 
 void attn_local_fwd(hipStream_t s, DType dt, const AttnArgs& a) {
   LocalGeom gm = local_geom(a.S, 16);
   dim3 grid((a.S + 7) / 8, a.H, a.B);
+  ProfScope ps(s, "attn_local_fwd", 4.0 * a.B * a.H * gm.nW * 16.0 * 16 * 64,
+               4.0 * a.B * a.S * a.H * 64 * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) hipLaunchKernelGGL((attn_local_fwd_kernel<float>), grid, dim3(64), 0, s, a, gm.padL, gm.nW);
   else hipLaunchKernelGGL((attn_local_fwd_kernel<bf16>), grid, dim3(64), 0, s, a, gm.padL, gm.nW);
 }
@@ -710,6 +717,8 @@ void attn_local_fwd(hipStream_t s, DType dt, const AttnArgs& a) {
 void attn_local_bwd(hipStream_t s, DType dt, const AttnBwdArgs& a) {
   LocalGeom gm = local_geom(a.f.S, 16);
   dim3 grid(gm.Lp / 8, a.f.H, a.f.B);
+  ProfScope ps(s, "attn_local_bwd", 8.0 * a.f.B * a.f.H * gm.nW * 16.0 * 16 * 64,
+               8.0 * a.f.B * a.f.S * a.f.H * 64 * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) hipLaunchKernelGGL((attn_local_bwd_kernel<float>), grid, dim3(64), 0, s, a, gm.padL, gm.nW);
   else hipLaunchKernelGGL((attn_local_bwd_kernel<bf16>), grid, dim3(64), 0, s, a, gm.padL, gm.nW);
 }

@@ -7,6 +7,7 @@
 // channels-last a stride-2 kernel-2 conv is a Linear over two concatenated positions.
 #include "rowops.h"
 #include "kernels.h"
+#include "prof.h"
 
 namespace amt {
 
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const T* __restrict__ aud
 void stem_fwd(hipStream_t s, DType dt, const void* audio, const float* w, const float* b, const float* lnw,
               const float* lnb, void* Y, int B, int T_) {
   int L = T_ / 5, tiles = (L + STEM_POS - 1) / STEM_POS;
+  ProfScope ps(s, "stem_fwd", 2.0 * B * L * 40, ((double)B * 2 * T_ + (double)B * L * 4) * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32)
     hipLaunchKernelGGL((stem_fwd_kernel<float>), dim3(B * tiles), dim3(256), 0, s, (const float*)audio, w, b, lnw, lnb,
                        (float*)Y, B, T_, L, tiles);
@@ -155,6 +157,7 @@ void stem_bwd(hipStream_t s, DType dt, const void* audio, const void* dY, const 
               const float* lnw, float* dw, float* db, float* dlnw, float* dlnb, int B, int T_) {
   int L = T_ / 5, tiles = (L + STEM_POS - 1) / STEM_POS, total = B * tiles;
   int grid = total < 512 ? total : 512;
+  ProfScope ps(s, "stem_bwd", 4.0 * B * L * 40, ((double)B * 2 * T_ + (double)B * L * 4) * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32)
     hipLaunchKernelGGL((stem_bwd_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)audio, (const float*)dY, w,
                        b, lnw, dw, db, dlnw, dlnb, B, T_, L, tiles, total);
@@ -379,22 +382,26 @@ static void scale_bwd_t(hipStream_t s, const void* dY, const void* Z, const floa
 
 void dwln_fwd(hipStream_t s, DType dt, const void* X, const float* wdw, const float* bdw, const float* lnw,
               const float* lnb, void* Y, float* mean, float* rstd, int B, int L, int C) {
+  ProfScope ps(s, "dwln_fwd", 14.0 * B * L * C, 2.0 * B * L * C * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) dwln_fwd_t<float>(s, X, wdw, bdw, lnw, lnb, Y, mean, rstd, B, L, C);
   else dwln_fwd_t<bf16>(s, X, wdw, bdw, lnw, lnb, Y, mean, rstd, B, L, C);
 }
 void dwln_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const float* wdw, const float* bdw,
               const float* mean, const float* rstd, const float* lnw, void* dD, float* dlnw, float* dlnb, int B, int L,
               int C) {
+  ProfScope ps(s, "dwln_bwd", 14.0 * B * L * C, 3.0 * B * L * C * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) dwln_bwd_t<float>(s, dY, X, wdw, bdw, mean, rstd, lnw, dD, dlnw, dlnb, B, L, C);
   else dwln_bwd_t<bf16>(s, dY, X, wdw, bdw, mean, rstd, lnw, dD, dlnw, dlnb, B, L, C);
 }
 void dwconv_bwd(hipStream_t s, DType dt, const void* dD, const void* X, const float* wdw, const void* dRes, void* dX,
                 float* dwdw, float* dbdw, int B, int L, int C) {
+  ProfScope ps(s, "dwconv_bwd", 28.0 * B * L * C, 4.0 * B * L * C * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) dwconv_bwd_t<float>(s, dD, X, wdw, dRes, dX, dwdw, dbdw, B, L, C);
   else dwconv_bwd_t<bf16>(s, dD, X, wdw, dRes, dX, dwdw, dbdw, B, L, C);
 }
 void scale_bwd(hipStream_t s, DType dt, const void* dY, const void* Z, const float* gamma, void* dZ, float* dgamma,
                int N, int C) {
+  ProfScope ps(s, "scale_bwd", 0, 3.0 * N * C * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) scale_bwd_t<float>(s, dY, Z, gamma, dZ, dgamma, N, C);
   else scale_bwd_t<bf16>(s, dY, Z, gamma, dZ, dgamma, N, C);
 }

@@ -9,6 +9,8 @@
 // token: bias / gamma / GLU pairing are per-register and stores are 8-byte (bf16) vectors.
 #include "common.h"
 #include "kernels.h"
+#include "prof.h"
+#include <string>
 
 namespace amt {
 
@@ -201,12 +203,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 
 template <typename T, int EPI>
 static void launch_nt(hipStream_t s, const GemmArgs& a) {
+  static const char* const epi_names[EPI_COUNT] = {"store", "store_f32", "resid", "gelu", "scale_resid", "glu",
+                                                   "glu_bwd", "gelu_bwd"};
+  const size_t es = sizeof(T);
+  const double fl = 2.0 * a.N * (double)a.M * a.K;
+  const double by = ((double)a.N * a.K + (double)a.M * a.K + (double)a.N * a.M) * es;
   // 128-token tiles when that still yields >= 2 workgroups per CU, else 64-token tiles
   long tiles128 = (long)((a.N + 127) / 128) * ((a.M + GBF - 1) / GBF);
   if (tiles128 >= 512) {
+    static const std::string nm = std::string("gemm_nt<") + (es == 4 ? "f32," : "bf16,") + epi_names[EPI] + ",128>";
+    ProfScope ps(s, nm.c_str(), fl, by);
     dim3 grid((a.N + 127) / 128, (a.M + GBF - 1) / GBF);
     hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, 128>), grid, dim3(256), 0, s, a);
   } else {
+    static const std::string nm = std::string("gemm_nt<") + (es == 4 ? "f32," : "bf16,") + epi_names[EPI] + ",64>";
+    ProfScope ps(s, nm.c_str(), fl, by);
     dim3 grid((a.N + 63) / 64, (a.M + GBF - 1) / GBF);
     hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, 64>), grid, dim3(256), 0, s, a);
   }
@@ -351,6 +362,9 @@ void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a) {
   int rps = ((a.N + splits - 1) / splits + 31) / 32 * 32;
   splits = (a.N + rps - 1) / rps;
   dim3 grid(tiles, splits);
+  const double es = dt == DT_F32 ? 4 : 2;
+  ProfScope ps(s, dt == DT_F32 ? "gemm_tn_wgrad<f32>" : "gemm_tn_wgrad<bf16>", 2.0 * a.N * (double)a.M * a.Kp,
+               ((double)a.N * a.M + (double)a.N * a.Kp) * es + (double)a.M * a.Kp * 4);
   if (dt == DT_F32)
     hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, s, a, tiles_k, rps);
   else

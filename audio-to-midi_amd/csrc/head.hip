@@ -6,6 +6,7 @@
 //   adamw_*       optax.adamw + clip_by_global_norm on the updates           train.py:646-729
 #include "common.h"
 #include "kernels.h"
+#include "prof.h"
 
 namespace amt {
 
@@ -60,6 +61,7 @@ void bce_loss(hipStream_t s, DType dt, const float* logits_pad, int ldl, const f
               void* dlogits, int ldd, int N, int V, float scale, int B) {
   long total = (long)N * ldd;
   int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  ProfScope ps(s, "bce_loss", 0, (double)N * V * 8 + (double)N * ldd * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32)
     hipLaunchKernelGGL((bce_kernel<float>), dim3(grid), dim3(256), 0, s, logits_pad, ldl, labels, loss_acc,
                        (float*)dlogits, ldd, (long)N, V, scale, 1.f / B);
@@ -79,6 +81,7 @@ __global__ void dropout_kernel(const T* __restrict__ X, T* __restrict__ Y, size_
 
 void dropout_apply(hipStream_t s, DType dt, const void* X, void* Y, size_t n, uint64_t seed, uint32_t stream,
                    uint32_t thr, float inv_keep) {
+  ProfScope ps(s, "dropout_apply", 0, 2.0 * n * (dt == DT_F32 ? 4 : 2));
   int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   if (dt == DT_F32)
     hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)X, (float*)Y, n, seed,
@@ -100,6 +103,7 @@ __global__ void grads_finalize_kernel(float* __restrict__ g, size_t n, float mul
 
 void grads_finalize(hipStream_t s, float* g, size_t n, float mul, int* valid_flag) {
   int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  ProfScope ps(s, "grads_finalize", 0, 8.0 * n);
   hipLaunchKernelGGL(grads_finalize_kernel, dim3(grid), dim3(256), 0, s, g, n, mul, valid_flag);
 }
 
@@ -188,6 +192,7 @@ __global__ __launch_bounds__(256) void convert_batch_kernel(const float* __restr
 void convert_batch(hipStream_t s, DType dt, const float* src, void* dst, const ConvDesc* descs_dev,
                    const int* tile_prefix_dev, int n_desc, int total_tiles) {
   if (total_tiles <= 0) return;
+  ProfScope ps(s, "convert_batch", 0, 0);
   if (dt == DT_F32)
     hipLaunchKernelGGL((convert_batch_kernel<float>), dim3(total_tiles), dim3(256), 0, s, src, (float*)dst, descs_dev,
                        tile_prefix_dev, n_desc);
@@ -234,11 +239,30 @@ void adamw_compute(hipStream_t s, const float* params, const float* grads, float
                    const float* lr_scale, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
                    float* norm2) {
   float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+  ProfScope ps(s, "adamw_compute", 0, 28.0 * n);
   hipLaunchKernelGGL(adamw_compute_kernel, dim3(2048), dim3(256), 0, s, params, grads, m, v, upd, lr_scale, n, lr, b1,
                      b2, eps, wd, bc1, bc2, norm2);
 }
 void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, const float* norm2, float clip) {
+  ProfScope ps(s, "adamw_apply", 0, 12.0 * n);
   hipLaunchKernelGGL(adamw_apply_kernel, dim3(2048), dim3(256), 0, s, params, upd, n, norm2, clip);
+}
+
+// ------------------------------------------------------------------ profiler (prof.h)
+Profiler& profiler() { static Profiler p; return p; }
+int Profiler::class_id(const char* name) {
+  for (size_t i = 0; i < names.size(); ++i)
+    if (names[i] == name) return (int)i;
+  names.emplace_back(name);
+  return (int)names.size() - 1;
+}
+hipEvent_t Profiler::event() {
+  if (used == pool.size()) {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    pool.push_back(e);
+  }
+  return pool[used++];
 }
 
 }  // namespace amt

@@ -14,6 +14,7 @@
 
 #include "../../include/amt.h"
 #include "kernels.h"
+#include "prof.h"
 
 using namespace amt;
 
@@ -838,9 +839,39 @@ int32_t amt_forward_backward(amt_ctx* c, const void* audio, const float* labels,
 
 uint64_t amt_workspace_bytes(const amt_ctx* c) { return c->arena.cap; }
 
-int32_t amt_adamw_step(amt_ctx* c, const float* grads_flat, float lr_base, float layer_lr_decay, float b1, float b2,
-                       float eps, float weight_decay, float clip_norm, int32_t step, void* stream) {
-  hipStream_t s = static_cast<hipStream_t>(stream);
+void amt_profile_begin(void) {
+  Profiler& p = profiler();
+  p.recs.clear();
+  p.used = 0;
+  p.on = true;
+}
+
+int32_t amt_profile_end(amt_prof_entry* out, int32_t max_entries) {
+  Profiler& p = profiler();
+  p.on = false;
+  (void)hipDeviceSynchronize();
+  std::vector<amt_prof_entry> agg(p.names.size());
+  for (size_t i = 0; i < p.names.size(); ++i) {
+    memset(&agg[i], 0, sizeof(amt_prof_entry));
+    snprintf(agg[i].name, sizeof(agg[i].name), "%s", p.names[i].c_str());
+  }
+  for (const ProfRec& r : p.recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    agg[r.cls].launches += 1;
+    agg[r.cls].total_ms += ms;
+    agg[r.cls].flops += r.flops;
+    agg[r.cls].bytes += r.bytes;
+  }
+  int32_t n = 0;
+  for (const amt_prof_entry& e : agg)
+    if (e.launches > 0 && n < max_entries) out[n++] = e;
+  p.recs.clear();
+  p.used = 0;
+  return n;
+}
+
+int32_t amt_optimizer_init(amt_ctx* c, float layer_lr_decay) {
   const Layout& L = c->L;
   const size_t n = L.n_params;
   if (!c->adam_m) {
@@ -862,6 +893,17 @@ int32_t amt_adamw_step(amt_ctx* c, const float* grads_flat, float lr_base, float
     }
     HIPCHK(c, hipMemcpy(c->lr_scale, sc.data(), n * sizeof(float), hipMemcpyHostToDevice));
     c->lr_scale_decay = layer_lr_decay;
+  }
+  HIPCHK(c, hipDeviceSynchronize());
+  return 0;
+}
+
+int32_t amt_adamw_step(amt_ctx* c, const float* grads_flat, float lr_base, float layer_lr_decay, float b1, float b2,
+                       float eps, float weight_decay, float clip_norm, int32_t step, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t n = c->L.n_params;
+  if (!c->adam_m || c->lr_scale_decay != layer_lr_decay) {
+    if (amt_optimizer_init(c, layer_lr_decay)) return 1;
   }
   HIPCHK(c, hipMemsetAsync(c->norm2, 0, sizeof(float), s));
   adamw_compute(s, c->params, grads_flat, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, n, lr_base, b1, b2, eps,

@@ -3,6 +3,7 @@
 // (model.py:100,117,162,190,539,546,759).
 #include "rowops.h"
 #include "kernels.h"
+#include "prof.h"
 
 namespace amt {
 
@@ -98,11 +99,13 @@ static void ln_bwd_t(hipStream_t s, const void* dY, const void* X, const float* 
 
 void layernorm_fwd(hipStream_t s, DType dt, const void* X, const float* w, const float* b, void* Y, float* mean,
                    float* rstd, int N, int C) {
+  ProfScope ps(s, "layernorm_fwd", 0, 2.0 * N * C * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) ln_fwd_t<float>(s, X, w, b, Y, mean, rstd, N, C);
   else ln_fwd_t<bf16>(s, X, w, b, Y, mean, rstd, N, C);
 }
 void layernorm_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const float* mean, const float* rstd,
                    const float* w, const void* dRes, void* dX, float* dw, float* db, int N, int C) {
+  ProfScope ps(s, "layernorm_bwd", 0, (dRes ? 4.0 : 3.0) * N * C * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) ln_bwd_t<float>(s, dY, X, mean, rstd, w, dRes, dX, dw, db, N, C);
   else ln_bwd_t<bf16>(s, dY, X, mean, rstd, w, dRes, dX, dw, db, N, C);
 }

@@ -43,6 +43,28 @@ class AmtSegment(C.Structure):
     ]
 
 
+class AmtProfEntry(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * 64),
+        ("launches", C.c_int32),
+        ("total_ms", C.c_double),
+        ("flops", C.c_double),
+        ("bytes", C.c_double),
+    ]
+
+
+def profile_begin():
+    load().amt_profile_begin()
+
+
+def profile_end(max_entries: int = 128):
+    """-> list of dict(name, launches, total_ms, flops, bytes), one per kernel class"""
+    buf = (AmtProfEntry * max_entries)()
+    n = load().amt_profile_end(C.cast(buf, C.c_void_p), max_entries)
+    return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), total_ms=float(buf[i].total_ms),
+                 flops=float(buf[i].flops), bytes=float(buf[i].bytes)) for i in range(n)]
+
+
 _lib = None
 _post = None
 
@@ -70,6 +92,9 @@ SIGNATURES = {
     "amt_forward_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _u64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "amt_workspace_bytes": (_u64, [_vp]),
     "amt_adamw_step": (_i32, [_vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "amt_optimizer_init": (_i32, [_vp, _f32]),
+    "amt_profile_begin": (None, []),
+    "amt_profile_end": (_i32, [_vp, _i32]),
     # ops
     "amt_op_gemm_nt": (_i32, [_i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp,
                               _i32, _vp, _i32, _vp, _u64, _u32, _f32, _vp]),

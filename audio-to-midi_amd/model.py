@@ -211,6 +211,10 @@ class OutputSequenceGenerator:
         lv = loss.cpu().numpy()
         return StepOutput(float(lv[0]), float(lv[1]), grads, bool(int(valid.item())), logits)
 
+    def init_optimizer(self, layer_lr_decay=0.7):
+        """Allocate AdamW state (train.py:845 setup_optimizers).  Call before hipGraph capture."""
+        self._check(self._L.amt_optimizer_init(self._h, float(layer_lr_decay)), "amt_optimizer_init")
+
     def adamw_step(self, grads_flat, lr_base, step, layer_lr_decay=0.7, b1=0.9, b2=0.999, eps=1e-3,
                    weight_decay=0.005, clip_norm=1.0):
         """optimizer half of compute_training_step (train.py:324-325, 646-729)."""

@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md §8d "cfg2"): one `train.py` step per GPU =
+forward + BCE loss + backward of the full model on a batch of 8 synthetic stereo 16 kHz 10-s clips
+(bf16 activations, train mode with dropout), + for N > 1 one RCCL all-reduce of the flat fp32
+gradient bucket, + the AdamW/clip update and the refresh of the bf16 compute copies.
+Metric: audio-seconds per second, whole job (N GPUs, weak scaling: 8 clips per GPU).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live (HIP events on the launch stream around
+every kernel, amt_profile_begin/end) on extra steps after the timed region; `cpu_baseline` times the
+oracle's torch-CPU restatement on this box's host cores on a bounded sample (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CLIP_SECONDS = 10.0
+T_SAMPLES = 160000
+B_PER_GPU = 8
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0       # HBM3E spec, MI355X_MICROARCH.md
+FLOPS_PER_STEP = 8 * 50.75e9  # 50.75 GFLOP fwd+bwd per 10 s clip
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(seconds_budget: float = 25.0):
+    """Oracle (torch-CPU fp32 restatement of the reference; JAX is unavailable offline) on the host
+    cores: fwd + bwd of B=2 x 10 s clips (the same per-step batch as one GPU)."""
+    from oracle import np_model, torch_model
+    import audio_to_midi_amd as amt
+    conf = np_model.MODEL_CONFIG
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("AMT_CPU_BASELINE_THREADS", "16"))))  # box CPU share: 16 per GPU
+    torch.set_num_threads(cores)
+    log(f"cpu_baseline: torch-CPU oracle on {cores} threads ...")
+    Bc = 8
+    params = np_model.init_params(conf, seed=1234, gamma=1e-6)
+    audio, labels = amt.synth.make_batch_fast(Bc, T_SAMPLES, seed=1)
+    p = torch_model.to_torch(params, torch.float32, requires_grad=True)
+    a = torch.from_numpy(audio)
+    y = torch.from_numpy(labels)
+
+    def step():
+        for v in p.values():
+            v.grad = None
+        logits, _ = torch_model.forward(p, a, conf)
+        torch_model.loss_fn(logits, y).backward()
+
+    t0 = time.perf_counter()
+    step()                      # warm-up
+    warm = time.perf_counter() - t0
+    log(f"cpu_baseline: warm-up step {warm:.2f} s")
+    n = max(0, min(5, int(seconds_budget / max(warm, 1e-3)) - 1))
+    times = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+        log(f"cpu_baseline: step {times[-1]:.2f} s")
+    med = float(np.median(times)) if times else warm
+    return {"value": round(Bc * CLIP_SECONDS / med, 2), "unit": "audio-sec/s", "cores": int(torch.get_num_threads()),
+            "kind": "port",
+            "sample": f"fwd+bwd of B={Bc} x 10 s clips, fp32, full model, median of {n} after 1 warm-up "
+                      f"({med:.2f} s/step); torch-CPU restatement of the reference (JAX unavailable offline)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
+    ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import audio_to_midi_amd as amt
+    from audio_to_midi_amd import lib as amtlib
+
+    model = amt.OutputSequenceGenerator(amt.model_config, key=1234, dtype="bfloat16", device=dev)
+    audio_np, labels_np = amt.synth.make_batch_fast(B_PER_GPU, T_SAMPLES, seed=100 + rank)
+    audio = torch.from_numpy(audio_np).to(dev, torch.bfloat16)       # inputs resident in HBM
+    labels = torch.from_numpy(labels_np).to(dev)
+    grads = torch.zeros(model.n_params + 2, dtype=torch.float32, device=dev)   # tail: loss, valid flag
+    gflat = grads[: model.n_params]
+    loss_buf = torch.zeros(2, dtype=torch.float32, device=dev)
+    step_no = [0]
+
+    def fwd_bwd(seed):
+        loss, _, valid, _ = model.loss_and_grads(audio, labels, scale=1.0, seed=seed, train=True, grads_out=gflat,
+                                                 sync=False)
+        grads[model.n_params] = loss[0]
+        grads[model.n_params + 1] = valid[0].to(torch.float32)
+        loss_buf.copy_(loss)
+
+    # every allocation happens before graph capture: optimizer state, then the workspace plan
+    if not args.no_optimizer:
+        model.init_optimizer()
+    fwd_bwd(0)
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fwd_bwd(0)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            fwd_bwd(12345)
+
+    def one_step():
+        step_no[0] += 1
+        if graph is not None:
+            graph.replay()
+        else:
+            fwd_bwd(step_no[0])
+        if world > 1:
+            dist.all_reduce(grads, op=dist.ReduceOp.SUM)        # ONE bucket: grads + loss + finite flag
+            grads.mul_(1.0 / world)                              # mean over the global batch (train.py:62)
+        if not args.no_optimizer:
+            model.adamw_step(gflat, lr_base=1e-4, step=step_no[0])
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B_PER_GPU * CLIP_SECONDS / (elapsed / args.steps)
+    loss_val = float(loss_buf[0].item())
+
+    # ---- roofline leg: per-kernel HIP-event timing on the launch stream (eager, extra steps)
+    roofline, breakdown = None, []
+    if rank == 0 and args.profile_steps > 0:
+        amtlib.profile_begin()
+        for i in range(args.profile_steps):
+            fwd_bwd(1000 + i)
+            if not args.no_optimizer:
+                model.adamw_step(gflat, lr_base=1e-4, step=step_no[0] + 1 + i)
+        ents = amtlib.profile_end()
+        tot = sum(e["total_ms"] for e in ents) or 1.0
+        ents.sort(key=lambda e: -e["total_ms"])
+        for e in ents:
+            avg_us = 1e3 * e["total_ms"] / e["launches"]
+            breakdown.append({"kernel": e["name"], "launches_per_step": e["launches"] // args.profile_steps,
+                              "avg_us": round(avg_us, 2), "share": round(e["total_ms"] / tot, 4),
+                              "tflops": round(e["flops"] / e["total_ms"] / 1e9, 2) if e["flops"] else None,
+                              "gbs": round(e["bytes"] / e["total_ms"] / 1e6, 1)})
+        log("kernel class breakdown (HIP events, eager):")
+        for b in breakdown:
+            log(f"  {b['kernel']:32s} x{b['launches_per_step']:4d}  avg {b['avg_us']:9.2f} us  share {100*b['share']:5.1f}%"
+                f"  {b['tflops']} TFLOP/s  {b['gbs']} GB/s")
+        log(f"  sum of kernel time per step: {tot / args.profile_steps:.3f} ms (timed step {ms_per_step:.3f} ms)")
+        top = ents[0]
+        if top["flops"] > 0:
+            ach = top["flops"] / top["total_ms"] / 1e9
+            roofline = {"bound": "mfma", "kernel": top["name"], "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 5), "traffic": None,
+                        "avg_launch_us": round(1e3 * top["total_ms"] / top["launches"], 2),
+                        "flops_per_launch": top["flops"] / top["launches"]}
+        else:
+            ach = top["bytes"] / top["total_ms"] / 1e6
+            roofline = {"bound": "hbm", "kernel": top["name"], "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5), "traffic": None,
+                        "avg_launch_us": round(1e3 * top["total_ms"] / top["launches"], 2),
+                        "bytes_per_launch": top["bytes"] / top["launches"]}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        out = {
+            "metric": "audio-sec/s (fwd+bwd, 10 s clips)", "value": round(value, 1), "unit": "audio-sec/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "train.py step: fwd + BCE + bwd of the full model, 8 clips x 10 s @ 16 kHz stereo per "
+                                   "GPU, train mode (dropout 0.1)" + (", RCCL all-reduce of the fp32 grad bucket" if world > 1 else "")
+                                   + ("" if args.no_optimizer else ", AdamW + global-norm clip + bf16 weight refresh"),
+                       "global_batch": world * B_PER_GPU, "clip_seconds": CLIP_SECONDS, "frames": T_SAMPLES // 320,
+                       "parallelism": f"dp{world}", "hipgraph": graph is not None,
+                       "weights": "random init (Equinox distributions), 11606230 params"},
+            "model_tflops": round(world * FLOPS_PER_STEP / (elapsed / args.steps) / 1e12, 2),
+            "loss": round(loss_val, 3),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "breakdown": breakdown[:12],
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

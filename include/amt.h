@@ -113,9 +113,25 @@ uint64_t amt_workspace_bytes(const amt_ctx* ctx);
 /* ---- next-row: optimizer step of compute_training_step (train.py:324-325, 646-729) ----------
  * optax.adamw(b1, b2, eps, weight_decay) per depth label, then clip_by_global_norm(1.0) on the
  * UPDATES, then apply.  lr_base is the scheduled base learning rate for this step; conv leaves
- * use lr_base * layer_lr_decay^(max_depth - depth).  State (m, v) lives in the context. */
+ * use lr_base * layer_lr_decay^(max_depth - depth).  State (m, v) lives in the context.
+ * amt_optimizer_init allocates that state (synchronous; call it before any hipGraph capture —
+ * amt_adamw_step calls it on first use otherwise). */
+int32_t amt_optimizer_init(amt_ctx* ctx, float layer_lr_decay);
 int32_t amt_adamw_step(amt_ctx* ctx, const float* grads_flat, float lr_base, float layer_lr_decay, float b1,
                        float b2, float eps, float weight_decay, float clip_norm, int32_t step, void* stream);
+
+/* ---- measurement aid (bench.py roofline leg): per-kernel-class timing with HIP events recorded
+ * on the launch stream around every kernel launch.  Process-global; off by default. */
+typedef struct amt_prof_entry {
+  char name[64];      /* kernel class, e.g. "gemm_nt<bf16,store,64>" */
+  int32_t launches;
+  double total_ms;    /* sum of launch durations */
+  double flops;       /* algorithmic flops summed over launches (2*M*N*K per GEMM) */
+  double bytes;       /* algorithmic HBM bytes summed over launches */
+} amt_prof_entry;
+void amt_profile_begin(void);
+/* synchronises the device, aggregates per class, returns the number of entries written */
+int32_t amt_profile_end(amt_prof_entry* out, int32_t max_entries);
 
 #ifdef __cplusplus
 }
