@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void attn_global_fwd_kernel(AttnArgs a) {
     for (int ks = 0; ks < 2; ++ks) {
       Frag<T> pf = frag_row(Pw + r * ALD + 32 * ks + 8 * g);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) mma(oacc[dt], frag_col(Vs + (32 * ks + 8 * g) * ALD + 16 * dt + r, ALD), pf);
+      for (int dt = 0; dt < 4; ++dt) mma(oacc[dt], frag_col16(Vs + (32 * ks + 8 * g) * ALD + 16 * dt, ALD, r), pf);
     }
   }
   if (qrow < S) {
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void attn_global_bwd_dq_kernel(AttnBwdArgs ba)
     for (int ks = 0; ks < 2; ++ks) {
       Frag<T> dsf = frag_row(Pw + r * ALD + 32 * ks + 8 * g);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) mma(dqacc[dt], frag_col(Ks + (32 * ks + 8 * g) * ALD + 16 * dt + r, ALD), dsf);
+      for (int dt = 0; dt < 4; ++dt) mma(dqacc[dt], frag_col16(Ks + (32 * ks + 8 * g) * ALD + 16 * dt, ALD, r), dsf);
     }
   }
   if (qrow < S) {
@@ -395,8 +395,8 @@ __global__ __launch_bounds__(256) void attn_global_bwd_dkv_kernel(AttnBwdArgs ba
       Frag<T> dsf = frag_row(dSTw + r * ALD + 32 * ks + 8 * g);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        mma(dvacc[dt], frag_col(dOs + (32 * ks + 8 * g) * ALD + 16 * dt + r, ALD), pf);   // dV^T[d][key]
-        mma(dkacc[dt], frag_col(Qs + (32 * ks + 8 * g) * ALD + 16 * dt + r, ALD), dsf);   // dK^T[d][key]
+        mma(dvacc[dt], frag_col16(dOs + (32 * ks + 8 * g) * ALD + 16 * dt, ALD, r), pf);   // dV^T[d][key]
+        mma(dkacc[dt], frag_col16(Qs + (32 * ks + 8 * g) * ALD + 16 * dt, ALD, r), dsf);   // dK^T[d][key]
       }
     }
   }

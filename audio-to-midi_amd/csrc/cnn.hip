@@ -362,7 +362,7 @@ static void dwln_bwd_t(hipStream_t s, const void* dY, const void* X, const float
                        const float* mean, const float* rstd, const float* lnw, void* dD, float* dlnw, float* dlnb,
                        int B, int L, int C) {
   long N = (long)B * L;
-  AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwln_bwd_kernel<T, CC>), dim3(row_grid(N, RowCfg<CC>::RPB, 512)), dim3(256), 0,
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwln_bwd_kernel<T, CC>), dim3(bwd_row_grid(N, RowCfg<CC>::RPB)), dim3(256), 0,
                                        s, (const T*)dY, (const T*)X, wdw, bdw, mean, rstd, lnw, (T*)dD, dlnw, dlnb, B,
                                        L));
 }
@@ -370,13 +370,13 @@ template <typename T>
 static void dwconv_bwd_t(hipStream_t s, const void* dD, const void* X, const float* wdw, const void* dRes, void* dX,
                          float* dwdw, float* dbdw, int B, int L, int C) {
   long N = (long)B * L;
-  AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwconv_bwd_kernel<T, CC>), dim3(row_grid(N, RowCfg<CC>::RPB, 512)), dim3(256),
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwconv_bwd_kernel<T, CC>), dim3(bwd_row_grid(N, RowCfg<CC>::RPB)), dim3(256),
                                        0, s, (const T*)dD, (const T*)X, wdw, (const T*)dRes, (T*)dX, dwdw, dbdw, B, L));
 }
 template <typename T>
 static void scale_bwd_t(hipStream_t s, const void* dY, const void* Z, const float* gamma, void* dZ, float* dgamma,
                         int N, int C) {
-  AMT_DISPATCH_C(C, hipLaunchKernelGGL((scale_bwd_kernel<T, CC>), dim3(row_grid(N, RowCfg<CC>::RPB, 512)), dim3(256), 0,
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((scale_bwd_kernel<T, CC>), dim3(bwd_row_grid(N, RowCfg<CC>::RPB)), dim3(256), 0,
                                        s, (const T*)dY, (const T*)Z, gamma, (T*)dZ, dgamma, (long)N));
 }
 

@@ -144,6 +144,23 @@ AMT_DEV Frag<float> frag_col(const float* p, int ld) {
   for (int i = 0; i < 8; ++i) f.v[i] = p[i * ld];
   return f;
 }
+// Column fragment of a 16-column sub-tile: p0 = &tile[first of this lane group's 8 rows][first
+// column of the sub-tile], r = lane & 15 selects the column.  bf16 uses the gfx950 transposing
+// LDS read (ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block is delivered
+// column-major; lane 4q+p supplies the address of row q, columns 4p..4p+3), two reads per
+// fragment instead of eight 16-bit reads.  Needs all 64 lanes active and 8-byte aligned rows.
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+AMT_DEV Frag<bf16> frag_col16(const bf16* p0, int ld, int r) {
+  const bf16* a0 = p0 + (r >> 2) * ld + 4 * (r & 3);
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0 + 4 * ld));
+  Frag<bf16> f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f.v[i] = lo[i]; f.v[4 + i] = hi[i]; }
+  return f;
+}
+AMT_DEV Frag<float> frag_col16(const float* p0, int ld, int r) { return frag_col(p0 + r, ld); }
+
 template <typename T> AMT_DEV Frag<T> frag_zero();
 template <> AMT_DEV Frag<bf16> frag_zero<bf16>() { Frag<bf16> f; for (int i = 0; i < 8; ++i) f.v[i] = (bf16)0.f; return f; }
 template <> AMT_DEV Frag<float> frag_zero<float>() { Frag<float> f; for (int i = 0; i < 8; ++i) f.v[i] = 0.f; return f; }

@@ -311,9 +311,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs a, int tiles_k, 
     if (st + 1 < nsteps) load_tiles(nbeg + (st + 1) * 32);
     Frag<T> gf[2], af[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) gf[i] = frag_col(&Gs[cur][8 * g][wm * 32 + i * 16 + r], WLD);
+    for (int i = 0; i < 2; ++i) gf[i] = frag_col16(&Gs[cur][8 * g][wm * 32 + i * 16], WLD, r);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) af[j] = frag_col(&As[cur][8 * g][wk * 32 + j * 16 + r], WLD);
+    for (int j = 0; j < 2; ++j) af[j] = frag_col16(&As[cur][8 * g][wk * 32 + j * 16], WLD, r);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -354,10 +354,13 @@ void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a) {
   if (a.N <= 0) return;
   int tiles_m = (a.M + 63) / 64, tiles_k = (a.Kp + 63) / 64;
   int tiles = tiles_m * tiles_k;
-  // aim for ~1024 workgroups, at least 128 tokens per split
+  // aim for ~1024 workgroups with at least 128 tokens per split, but never more than 48 splits:
+  // every split adds its partial tile into the same dW addresses and contended float atomics are
+  // an order of magnitude slower than spread ones (MI355X_MICROARCH.md, Global float atomics)
   int splits = (1024 + tiles - 1) / tiles;
   int max_splits = (a.N + 127) / 128;
   if (splits > max_splits) splits = max_splits;
+  if (splits > 48) splits = 48;
   if (splits < 1) splits = 1;
   int rps = ((a.N + splits - 1) / splits + 31) / 32 * 32;
   splits = (a.N + rps - 1) / rps;

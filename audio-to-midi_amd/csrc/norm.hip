@@ -93,7 +93,7 @@ static void ln_fwd_t(hipStream_t s, const void* X, const float* w, const float* 
 template <typename T>
 static void ln_bwd_t(hipStream_t s, const void* dY, const void* X, const float* mean, const float* rstd,
                      const float* w, const void* dRes, void* dX, float* dw, float* db, int N, int C) {
-  AMT_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd_kernel<T, CC>), dim3(row_grid(N, RowCfg<CC>::RPB, 512)), dim3(256), 0,
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd_kernel<T, CC>), dim3(bwd_row_grid(N, RowCfg<CC>::RPB)), dim3(256), 0,
                                        s, (const T*)dY, (const T*)X, mean, rstd, w, (const T*)dRes, (T*)dX, dw, db, N));
 }
 

@@ -43,7 +43,18 @@ static inline int row_grid(long N, int rows_per_block, int max_blocks = 2048) {
   return (int)nb;
 }
 
-#define AMT_DISPATCH_C(C_, ...)                         \
+// Backward row kernels end with one atomic per feature per block into the SAME C addresses
+// (parameter gradients).  Contended float atomics run ~14x below the uncontended rate
+// (MI355X_MICROARCH.md, Global float atomics), so keep the number of adding blocks small and give
+// every block at least 8 row groups of streaming work.
+static inline int bwd_row_grid(long N, int rows_per_block, int max_blocks = 128) {
+  long nb = (N + (long)rows_per_block * 8 - 1) / ((long)rows_per_block * 8);
+  if (nb > max_blocks) nb = max_blocks;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+#define AMT_DISPATCH_C(C_, ...)                       \
   switch (C_) {                                         \
     case 4: { constexpr int CC = 4; __VA_ARGS__; } break;     \
     case 8: { constexpr int CC = 8; __VA_ARGS__; } break;     \
