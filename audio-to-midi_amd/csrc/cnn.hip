@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void dwln_bwd_kernel(const T* __restrict__ dY,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ lnw, T* __restrict__ dD,
                                                        float* __restrict__ dlnw, float* __restrict__ dlnb, int B,
-                                                       int L) {
+                                                       int L, int pstride) {
   using R = RowCfg<C>;
   constexpr int VEC = R::VEC, LPR = R::LPR;
   __shared__ float smem[C];
@@ -266,15 +266,15 @@ __global__ __launch_bounds__(256) void dwln_bwd_kernel(const T* __restrict__ dY,
     for (int i = 0; i < VEC; ++i) o[i] = rs * (gy[i] - s1 - d[i] * s2);
     storevf<VEC>(dD + row * C + sub * VEC, o);
   }
-  reduce_cols_to_global<VEC, LPR>(aw, dlnw, smem);
-  reduce_cols_to_global<VEC, LPR>(ab, dlnb, smem);
+  reduce_cols_to_global<VEC, LPR>(aw, dlnw, smem, pstride);
+  reduce_cols_to_global<VEC, LPR>(ab, dlnb, smem, pstride);
 }
 
 template <typename T, int C>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ dD, const T* __restrict__ X,
                                                          const float* __restrict__ wdw, const T* dRes, T* dX,
                                                          float* __restrict__ dwdw, float* __restrict__ dbdw, int B,
-                                                         int L) {
+                                                         int L, int pstride) {
   using R = RowCfg<C>;
   constexpr int VEC = R::VEC, LPR = R::LPR;
   __shared__ float smem[C];
@@ -323,14 +323,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
     storevf<VEC>(dX + row * C + sub * VEC, o);
   }
 #pragma unroll
-  for (int k = 0; k < 7; ++k) reduce_cols_to_global<VEC, LPR>(aw[k], dwdw + k * C, smem);
-  reduce_cols_to_global<VEC, LPR>(ab, dbdw, smem);
+  for (int k = 0; k < 7; ++k) reduce_cols_to_global<VEC, LPR>(aw[k], dwdw + k * C, smem, pstride);
+  reduce_cols_to_global<VEC, LPR>(ab, dbdw, smem, pstride);
 }
 
 template <typename T, int C>
 __global__ __launch_bounds__(256) void scale_bwd_kernel(const T* __restrict__ dY, const T* __restrict__ Z,
                                                         const float* __restrict__ gamma, T* __restrict__ dZ,
-                                                        float* __restrict__ dgamma, long N) {
+                                                        float* __restrict__ dgamma, long N, int pstride) {
   using R = RowCfg<C>;
   constexpr int VEC = R::VEC, LPR = R::LPR;
   __shared__ float smem[C];
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void scale_bwd_kernel(const T* __restrict__ dY
     for (int i = 0; i < VEC; ++i) { ag[i] += dy[i] * z[i]; o[i] = gv[i] * dy[i]; }
     storevf<VEC>(dZ + row * C + sub * VEC, o);
   }
-  reduce_cols_to_global<VEC, LPR>(ag, dgamma, smem);
+  reduce_cols_to_global<VEC, LPR>(ag, dgamma, smem, pstride);
 }
 
 template <typename T>
@@ -360,24 +360,21 @@ static void dwln_fwd_t(hipStream_t s, const void* X, const float* wdw, const flo
 template <typename T>
 static void dwln_bwd_t(hipStream_t s, const void* dY, const void* X, const float* wdw, const float* bdw,
                        const float* mean, const float* rstd, const float* lnw, void* dD, float* dlnw, float* dlnb,
-                       int B, int L, int C) {
-  long N = (long)B * L;
-  AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwln_bwd_kernel<T, CC>), dim3(bwd_row_grid(N, RowCfg<CC>::RPB)), dim3(256), 0,
-                                       s, (const T*)dY, (const T*)X, wdw, bdw, mean, rstd, lnw, (T*)dD, dlnw, dlnb, B,
-                                       L));
+                       int B, int L, int C, int nb, int pstride) {
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwln_bwd_kernel<T, CC>), dim3(nb), dim3(256), 0, s, (const T*)dY, (const T*)X,
+                                       wdw, bdw, mean, rstd, lnw, (T*)dD, dlnw, dlnb, B, L, pstride));
 }
 template <typename T>
 static void dwconv_bwd_t(hipStream_t s, const void* dD, const void* X, const float* wdw, const void* dRes, void* dX,
-                         float* dwdw, float* dbdw, int B, int L, int C) {
-  long N = (long)B * L;
-  AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwconv_bwd_kernel<T, CC>), dim3(bwd_row_grid(N, RowCfg<CC>::RPB)), dim3(256),
-                                       0, s, (const T*)dD, (const T*)X, wdw, (const T*)dRes, (T*)dX, dwdw, dbdw, B, L));
+                         float* dwdw, float* dbdw, int B, int L, int C, int nb, int pstride) {
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwconv_bwd_kernel<T, CC>), dim3(nb), dim3(256), 0, s, (const T*)dD,
+                                       (const T*)X, wdw, (const T*)dRes, (T*)dX, dwdw, dbdw, B, L, pstride));
 }
 template <typename T>
 static void scale_bwd_t(hipStream_t s, const void* dY, const void* Z, const float* gamma, void* dZ, float* dgamma,
-                        int N, int C) {
-  AMT_DISPATCH_C(C, hipLaunchKernelGGL((scale_bwd_kernel<T, CC>), dim3(bwd_row_grid(N, RowCfg<CC>::RPB)), dim3(256), 0,
-                                       s, (const T*)dY, (const T*)Z, gamma, (T*)dZ, dgamma, (long)N));
+                        int N, int C, int nb, int pstride) {
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((scale_bwd_kernel<T, CC>), dim3(nb), dim3(256), 0, s, (const T*)dY, (const T*)Z,
+                                       gamma, (T*)dZ, dgamma, (long)N, pstride));
 }
 
 void dwln_fwd(hipStream_t s, DType dt, const void* X, const float* wdw, const float* bdw, const float* lnw,
@@ -388,22 +385,53 @@ void dwln_fwd(hipStream_t s, DType dt, const void* X, const float* wdw, const fl
 }
 void dwln_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const float* wdw, const float* bdw,
               const float* mean, const float* rstd, const float* lnw, void* dD, float* dlnw, float* dlnb, int B, int L,
-              int C) {
+              int C, PartialSink* sink) {
+  const int nb = bwd_blocks((long)B * L, C, sink);
+  int pstride = 0;
+  if (sink) {   // records [nb][lnw(C) | lnb(C)]
+    size_t o = sink->take((size_t)nb * 2 * C);
+    sink->add(o, nb, 2 * C, C, dlnw);
+    sink->add(o + C, nb, 2 * C, C, dlnb);
+    if (sink->dry) return;
+    pstride = 2 * C;
+    dlnw = sink->ws + o;
+    dlnb = dlnw + C;
+  }
   ProfScope ps(s, "dwln_bwd", 14.0 * B * L * C, 3.0 * B * L * C * (dt == DT_F32 ? 4 : 2));
-  if (dt == DT_F32) dwln_bwd_t<float>(s, dY, X, wdw, bdw, mean, rstd, lnw, dD, dlnw, dlnb, B, L, C);
-  else dwln_bwd_t<bf16>(s, dY, X, wdw, bdw, mean, rstd, lnw, dD, dlnw, dlnb, B, L, C);
+  if (dt == DT_F32) dwln_bwd_t<float>(s, dY, X, wdw, bdw, mean, rstd, lnw, dD, dlnw, dlnb, B, L, C, nb, pstride);
+  else dwln_bwd_t<bf16>(s, dY, X, wdw, bdw, mean, rstd, lnw, dD, dlnw, dlnb, B, L, C, nb, pstride);
 }
 void dwconv_bwd(hipStream_t s, DType dt, const void* dD, const void* X, const float* wdw, const void* dRes, void* dX,
-                float* dwdw, float* dbdw, int B, int L, int C) {
+                float* dwdw, float* dbdw, int B, int L, int C, PartialSink* sink) {
+  const int nb = bwd_blocks((long)B * L, C, sink);
+  int pstride = 0;
+  if (sink) {   // records [nb][taps(7C) | bias(C)]
+    size_t o = sink->take((size_t)nb * 8 * C);
+    sink->add(o, nb, 8 * C, 7 * C, dwdw);
+    sink->add(o + 7 * C, nb, 8 * C, C, dbdw);
+    if (sink->dry) return;
+    pstride = 8 * C;
+    dwdw = sink->ws + o;
+    dbdw = dwdw + 7 * C;
+  }
   ProfScope ps(s, "dwconv_bwd", 28.0 * B * L * C, 4.0 * B * L * C * (dt == DT_F32 ? 4 : 2));
-  if (dt == DT_F32) dwconv_bwd_t<float>(s, dD, X, wdw, dRes, dX, dwdw, dbdw, B, L, C);
-  else dwconv_bwd_t<bf16>(s, dD, X, wdw, dRes, dX, dwdw, dbdw, B, L, C);
+  if (dt == DT_F32) dwconv_bwd_t<float>(s, dD, X, wdw, dRes, dX, dwdw, dbdw, B, L, C, nb, pstride);
+  else dwconv_bwd_t<bf16>(s, dD, X, wdw, dRes, dX, dwdw, dbdw, B, L, C, nb, pstride);
 }
 void scale_bwd(hipStream_t s, DType dt, const void* dY, const void* Z, const float* gamma, void* dZ, float* dgamma,
-               int N, int C) {
+               int N, int C, PartialSink* sink) {
+  const int nb = bwd_blocks(N, C, sink);
+  int pstride = 0;
+  if (sink) {
+    size_t o = sink->take((size_t)nb * C);
+    sink->add(o, nb, C, C, dgamma);
+    if (sink->dry) return;
+    pstride = C;
+    dgamma = sink->ws + o;
+  }
   ProfScope ps(s, "scale_bwd", 0, 3.0 * N * C * (dt == DT_F32 ? 4 : 2));
-  if (dt == DT_F32) scale_bwd_t<float>(s, dY, Z, gamma, dZ, dgamma, N, C);
-  else scale_bwd_t<bf16>(s, dY, Z, gamma, dZ, dgamma, N, C);
+  if (dt == DT_F32) scale_bwd_t<float>(s, dY, Z, gamma, dZ, dgamma, N, C, nb, pstride);
+  else scale_bwd_t<bf16>(s, dY, Z, gamma, dZ, dgamma, N, C, nb, pstride);
 }
 
 }  // namespace amt

@@ -11,6 +11,7 @@
 #include "kernels.h"
 #include "prof.h"
 #include <string>
+#include <cstring>
 
 namespace amt {
 
@@ -258,7 +259,7 @@ AMT_DEV Chunk8<T> load_f_chunk(const T* rowp, int f, int F) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs a, int tiles_k, int rows_per_split) {
+AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx, int by) {
   __shared__ __attribute__((aligned(16))) T Gs[2][32][WLD];
   __shared__ __attribute__((aligned(16))) T As[2][32][WLD];
   __shared__ float red[32][65];
@@ -266,12 +267,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs a, int tiles_k, 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int wm = wave >> 1, wk = wave & 1;
-  const int m0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
-  const int nbeg = blockIdx.y * rows_per_split;
+  const int m0 = (bx / tiles_k) * 64, k0 = (bx % tiles_k) * 64;
+  const int nbeg = by * rows_per_split;
   const int nend = min(a.N, nbeg + rows_per_split);
   const T* G = reinterpret_cast<const T*>(a.G);
   const T* A = reinterpret_cast<const T*>(a.A);
-  const bool do_bias = (a.dbias != nullptr) && (blockIdx.x % tiles_k == 0);
+  const bool do_bias = (a.dbias != nullptr) && (bx % tiles_k == 0);
   const int Mst = a.M_store > 0 ? a.M_store : a.M;
 
   f32x4 acc[2][2];
@@ -332,7 +333,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs a, int tiles_k, 
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         int m = m0 + wm * 32 + i * 16 + 4 * g + e;
-        if (m < Mst && k < a.Kp) atomicAdd(&a.dW[(size_t)m * a.ldw + k], acc[i][j][e]);
+        if (m < Mst && k < a.Kp) {
+          if (a.part) a.part[(size_t)by * a.part_stride + (size_t)m * a.Kp + k] = acc[i][j][e];
+          else atomicAdd(&a.dW[(size_t)m * a.ldw + k], acc[i][j][e]);
+        }
       }
     }
 
@@ -345,15 +349,57 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs a, int tiles_k, 
 #pragma unroll 8
       for (int q = 0; q < 32; ++q) s += red[q][tid];
       int m = m0 + tid;
-      if (m < Mst) atomicAdd(&a.dbias[m], s);
+      if (m < Mst) {
+        if (a.part) a.part[(size_t)by * a.part_stride + (size_t)Mst * a.Kp + m] = s;
+        else atomicAdd(&a.dbias[m], s);
+      }
     }
   }
 }
 
-void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a) {
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs a, int tiles_k, int rows_per_split) {
+  tn_body<T>(a, tiles_k, rows_per_split, blockIdx.x, blockIdx.y);
+}
+
+// several independent weight-gradient problems in ONE launch (all wgrads of a transformer layer or
+// of a CNN block): blockIdx.x -> (problem, tile, token split)
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_group_kernel(WgradGroup g) {
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.n && b >= g.prefix[i + 1]) ++i;
+  const int local = b - g.prefix[i];
+  tn_body<T>(g.p[i], g.tiles_k[i], g.rps[i], local % g.tiles[i], local / g.tiles[i]);
+}
+
+void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a_in, PartialSink* sink) {
+  WgradArgs a = a_in;
   if (a.N <= 0) return;
   int tiles_m = (a.M + 63) / 64, tiles_k = (a.Kp + 63) / 64;
   int tiles = tiles_m * tiles_k;
+  const int Mst = a.M_store > 0 ? a.M_store : a.M;
+  if (sink && tiles == 1 && a.N >= 16384 && a.ldw == a.Kp) {
+    // skinny weight gradient (one 64x64 tile, very long token axis): many short splits, each
+    // writing one record; reduce_partials sums them (no same-address atomics)
+    int rps = 256;
+    int splits = (a.N + rps - 1) / rps;
+    if (splits > 1024) { splits = 1024; rps = ((a.N + splits - 1) / splits + 31) / 32 * 32; splits = (a.N + rps - 1) / rps; }
+    const size_t rec = (size_t)Mst * a.Kp + (a.dbias ? Mst : 0);
+    size_t o = sink->take((size_t)splits * rec);
+    sink->add(o, splits, (uint32_t)rec, (uint32_t)(Mst * a.Kp), a.dW);
+    if (a.dbias) sink->add(o + (size_t)Mst * a.Kp, splits, (uint32_t)rec, (uint32_t)Mst, a.dbias);
+    if (sink->dry) return;
+    a.part = sink->ws + o;
+    a.part_stride = (int)rec;
+    ProfScope ps(s, dt == DT_F32 ? "gemm_tn_wgrad_skinny<f32>" : "gemm_tn_wgrad_skinny<bf16>",
+                 2.0 * a.N * (double)a.M * a.Kp, ((double)a.N * a.M + (double)a.N * a.Kp) * (dt == DT_F32 ? 4 : 2));
+    dim3 grid(1, splits);
+    if (dt == DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, s, a, 1, rps);
+    else hipLaunchKernelGGL((gemm_tn_kernel<bf16>), grid, dim3(256), 0, s, a, 1, rps);
+    return;
+  }
+  if (sink && sink->dry) return;
   // aim for ~1024 workgroups with at least 128 tokens per split, but never more than 48 splits:
   // every split adds its partial tile into the same dW addresses and contended float atomics are
   // an order of magnitude slower than spread ones (MI355X_MICROARCH.md, Global float atomics)
@@ -372,6 +418,42 @@ void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a) {
     hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, s, a, tiles_k, rps);
   else
     hipLaunchKernelGGL((gemm_tn_kernel<bf16>), grid, dim3(256), 0, s, a, tiles_k, rps);
+}
+
+void gemm_tn_wgrad_group(hipStream_t s, DType dt, const WgradArgs* probs, int n, PartialSink* sink) {
+  if (n <= 0) return;
+  if (sink && sink->dry) return;
+  if (n == 1) { gemm_tn_wgrad(s, dt, probs[0], nullptr); return; }
+  WgradGroup g;
+  memset(&g, 0, sizeof(g));
+  g.n = n;
+  int total_tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    g.p[i] = probs[i];
+    g.tiles_k[i] = (probs[i].Kp + 63) / 64;
+    g.tiles[i] = ((probs[i].M + 63) / 64) * g.tiles_k[i];
+    total_tiles += g.tiles[i];
+  }
+  double fl = 0, by = 0;
+  const double es = dt == DT_F32 ? 4 : 2;
+  for (int i = 0; i < n; ++i) {
+    const WgradArgs& a = probs[i];
+    int splits = (1536 + total_tiles - 1) / total_tiles;
+    int max_splits = (a.N + 127) / 128;
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 48) splits = 48;
+    if (splits < 1) splits = 1;
+    int rps = ((a.N + splits - 1) / splits + 31) / 32 * 32;
+    splits = (a.N + rps - 1) / rps;
+    g.rps[i] = rps;
+    g.prefix[i + 1] = g.prefix[i] + g.tiles[i] * splits;
+    fl += 2.0 * a.N * (double)a.M * a.Kp;
+    by += ((double)a.N * a.M + (double)a.N * a.Kp) * es + (double)a.M * a.Kp * 4;
+  }
+  ProfScope ps(s, dt == DT_F32 ? "gemm_tn_wgrad_group<f32>" : "gemm_tn_wgrad_group<bf16>", fl, by);
+  dim3 grid(g.prefix[n]);
+  if (dt == DT_F32) hipLaunchKernelGGL((gemm_tn_group_kernel<float>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_tn_group_kernel<bf16>), grid, dim3(256), 0, s, g);
 }
 
 }  // namespace amt

@@ -201,6 +201,35 @@ void convert_batch(hipStream_t s, DType dt, const float* src, void* dst, const C
                        tile_prefix_dev, n_desc);
 }
 
+// ------------------------------------------------------------------ per-block records -> gradients
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const PartDesc* __restrict__ descs,
+                                                              const float* __restrict__ ws, float* __restrict__ grads) {
+  const PartDesc d = descs[blockIdx.x];
+  const float* src = ws + d.ws_off;
+  // blockIdx.y takes one of gridDim.y contiguous slices of the records
+  const uint32_t per = (d.nblocks + gridDim.y - 1) / gridDim.y;
+  const uint32_t b_beg = blockIdx.y * per;
+  const uint32_t b_end = min(d.nblocks, b_beg + per);
+  if (b_beg >= b_end) return;
+  for (uint32_t e = threadIdx.x; e < d.count; e += 256) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    uint32_t b = b_beg;
+    for (; b + 4 <= b_end; b += 4) {
+      a0 += src[(size_t)b * d.stride + e];
+      a1 += src[(size_t)(b + 1) * d.stride + e];
+      a2 += src[(size_t)(b + 2) * d.stride + e];
+      a3 += src[(size_t)(b + 3) * d.stride + e];
+    }
+    for (; b < b_end; ++b) a0 += src[(size_t)b * d.stride + e];
+    atomicAdd(&grads[d.dst_off + e], (a0 + a1) + (a2 + a3));
+  }
+}
+void reduce_partials(hipStream_t s, const PartDesc* descs_dev, int n_desc, const float* ws, float* grads) {
+  if (n_desc <= 0) return;
+  ProfScope ps(s, "reduce_partials", 0, 0);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_desc, 8), dim3(256), 0, s, descs_dev, ws, grads);
+}
+
 // ------------------------------------------------------------------ AdamW
 __global__ __launch_bounds__(256) void adamw_compute_kernel(const float* __restrict__ p, const float* __restrict__ g,
                                                             float* __restrict__ m, float* __restrict__ v,

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace amt {
 
 enum DType { DT_F32 = 0, DT_BF16 = 1 };
@@ -46,8 +48,31 @@ struct WgradArgs {
   float* dW; int ldw;       // [M x Kp] fp32
   float* dbias;             // [M] fp32 or nullptr
   int M_store;              // rows of dW / dbias actually written (0 = M); G may be zero-padded past it
+  float* part; int part_stride;   // set by the launcher: per-split records instead of atomics
 };
-void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a);
+struct PartialSink;
+void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a, PartialSink* sink = nullptr);
+// up to 8 independent problems in one launch
+struct WgradGroup { int n; int prefix[9]; int tiles[8]; int tiles_k[8]; int rps[8]; WgradArgs p[8]; };
+void gemm_tn_wgrad_group(hipStream_t s, DType dt, const WgradArgs* probs, int n, PartialSink* sink = nullptr);
+
+// ----------------------------------------------------------------------------- per-block partial sums
+// Row kernels that produce parameter gradients (LayerNorm w/b, depthwise conv w/b, gamma) can write
+// one record of partial column sums per block instead of atomically adding into the gradient;
+// reduce_partials sums all records of the step in one launch.
+struct PartDesc { uint64_t ws_off; uint64_t dst_off; uint32_t nblocks, stride, count, pad; };
+struct PartialSink {
+  float* ws = nullptr;            // records workspace (device); may be null while planning
+  size_t off = 0;                 // bump pointer (floats)
+  const float* grads_base = nullptr;
+  std::vector<PartDesc>* descs = nullptr;   // filled while planning
+  bool dry = false;               // planning pass: account, do not launch
+  size_t take(size_t n) { size_t o = off; off += n; return o; }
+  void add(size_t ws_off, uint32_t nblocks, uint32_t stride, uint32_t count, const float* dst) {
+    if (descs) descs->push_back(PartDesc{ws_off, (uint64_t)(dst - grads_base), nblocks, stride, count, 0});
+  }
+};
+void reduce_partials(hipStream_t s, const PartDesc* descs_dev, int n_desc, const float* ws, float* grads);
 
 // ----------------------------------------------------------------------------- LayerNorm over the last dim
 // C in {4, 8, 16, 32, 64, 128, 256}
@@ -55,7 +80,8 @@ void layernorm_fwd(hipStream_t s, DType dt, const void* X, const float* w, const
                    void* Y, float* mean, float* rstd, int N, int C);
 // dX = (dRes ? dRes : 0) + LN'(dY) ; dw += sum dY*xhat ; db += sum dY
 void layernorm_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const float* mean, const float* rstd,
-                   const float* w, const void* dRes, void* dX, float* dw, float* db, int N, int C);
+                   const float* w, const void* dRes, void* dX, float* dw, float* db, int N, int C,
+                   PartialSink* sink = nullptr);
 
 // ----------------------------------------------------------------------------- CNN pieces
 // audio [B][2][T] (T dtype) -> Y [B][T/5][4] = LN(conv k5 s5)
@@ -69,13 +95,13 @@ void dwln_fwd(hipStream_t s, DType dt, const void* X, const float* wdw /*[7][C]*
 // dD = LN'(dY) w.r.t. the conv output (recomputed from X) ; dlnw,dlnb accumulated
 void dwln_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const float* wdw, const float* bdw,
               const float* mean, const float* rstd, const float* lnw, void* dD, float* dlnw, float* dlnb,
-              int B, int L, int C);
+              int B, int L, int C, PartialSink* sink = nullptr);
 // dX = dRes + conv^T(dD) ; dwdw[k][c] += sum dD[l][c] X[l+k-3][c] ; dbdw[c] += sum dD
 void dwconv_bwd(hipStream_t s, DType dt, const void* dD, const void* X, const float* wdw, const void* dRes,
-                void* dX, float* dwdw, float* dbdw, int B, int L, int C);
+                void* dX, float* dwdw, float* dbdw, int B, int L, int C, PartialSink* sink = nullptr);
 // dZ = gamma * dY ; dgamma[c] += sum dY * Z
 void scale_bwd(hipStream_t s, DType dt, const void* dY, const void* Z, const float* gamma, void* dZ,
-               float* dgamma, int N, int C);
+               float* dgamma, int N, int C, PartialSink* sink = nullptr);
 
 // ----------------------------------------------------------------------------- attention
 struct AttnArgs {

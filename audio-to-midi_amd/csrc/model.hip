@@ -6,6 +6,7 @@
 //   compute_training_step (grad part)  train.py:292-322   (fp32 accumulation, unscale, finite flag)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -229,6 +230,12 @@ struct amt_ctx {
   void *hd_x = nullptr, *hd_n = nullptr; float *hd_mean = nullptr, *hd_rstd = nullptr;
   float* logits_pad = nullptr;
   float* loss_acc = nullptr;    // device float[2]
+  // per-block partial-sum records of the backward row kernels (kernels.h: PartialSink)
+  float* partials = nullptr;
+  size_t partials_cap = 0, part_total = 0;
+  std::vector<PartDesc> part_descs;
+  PartDesc* part_desc_dev = nullptr;
+  int n_part_desc = 0;
 
   const float* P(size_t off) const { return params + off; }
   const void* WC(size_t off) const { return static_cast<const char*>(wc) + off * esz; }
@@ -465,14 +472,32 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
 #define RUN(...) do { if (!dry) { __VA_ARGS__; } } while (0)
   const Drop dp = drop_params(c, train);
   const int S = T / 320, N = B * S, H = L.H;
+  PartialSink sink;
+  sink.ws = c->partials;
+  sink.grads_base = grads;
+  sink.dry = dry;
+  if (dry) { c->part_descs.clear(); sink.descs = &c->part_descs; }
+
   auto G = [&](size_t off) { return grads + off; };
+  std::vector<WgradArgs> pending;
   auto wgrad = [&](const void* Gm, int ldg, const void* Am, int lda, int n, int M, int Kp, size_t w_off, int ldw,
                    long b_off, int m_store) {
     WgradArgs w;
     memset(&w, 0, sizeof(w));
     w.G = Gm; w.ldg = ldg; w.A = Am; w.lda = lda; w.N = n; w.M = M; w.Kp = Kp;
     w.dW = G(w_off); w.ldw = ldw; w.dbias = b_off >= 0 ? G((size_t)b_off) : nullptr; w.M_store = m_store;
-    RUN(gemm_tn_wgrad(s, dt, w));
+    const int tiles = ((M + 63) / 64) * ((Kp + 63) / 64);
+    if (tiles == 1 && n >= 16384) gemm_tn_wgrad(s, dt, w, &sink);   // skinny: per-split records
+    else pending.push_back(w);                                       // grouped launch at the end of the layer
+  };
+  // all queued weight gradients of a layer / block in one launch; must run before the layer's
+  // scratch tensors are recycled
+  auto flush_wgrads = [&]() {
+    for (size_t i = 0; i < pending.size(); i += 8) {
+      int cnt = (int)std::min<size_t>(8, pending.size() - i);
+      gemm_tn_wgrad_group(s, dt, pending.data() + i, cnt, &sink);
+    }
+    pending.clear();
   };
 
   RUN((void)hipMemsetAsync(grads, 0, L.n_params * sizeof(float), s));
@@ -496,8 +521,9 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     RUN(gemm_nt(s, dt, EPI_STORE, g));
   }
   void* dcur = dbuf[di];
-  RUN(layernorm_bwd(s, dt, dhn, c->hd_x, c->hd_mean, c->hd_rstd, c->P(L.hd_lnw), nullptr, dcur, G(L.hd_lnw),
-                    G(L.hd_lnb), N, H));
+  flush_wgrads();
+  layernorm_bwd(s, dt, dhn, c->hd_x, c->hd_mean, c->hd_rstd, c->P(L.hd_lnw), nullptr, dcur, G(L.hd_lnw),
+                    G(L.hd_lnb), N, H, &sink);
 
   for (int li = (int)L.layers.size() - 1; li >= 0; --li) {
     const LayerP& lp = L.layers[li];
@@ -526,7 +552,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       RUN(gemm_nt(s, dt, EPI_STORE, g));
     }
     void* dh = A.alloc((size_t)N * H * es);
-    RUN(layernorm_bwd(s, dt, dhn2, ls.h, ls.m2, ls.r2, c->P(lp.ln2_w), dy, dh, G(lp.ln2_w), G(lp.ln2_b), N, H));
+    layernorm_bwd(s, dt, dhn2, ls.h, ls.m2, ls.r2, c->P(lp.ln2_w), dy, dh, G(lp.ln2_w), G(lp.ln2_b), N, H, &sink);
     // attention output projection
     wgrad(dh, H, ls.ao, H, N, H, H, lp.wo, H, -1, 0);
     void* dao = A.alloc((size_t)N * H * es);
@@ -562,16 +588,17 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     }
     di ^= 1;
     void* dx = dbuf[di];
-    RUN(layernorm_bwd(s, dt, dxn, ls.x, ls.m1, ls.r1, c->P(lp.ln1_w), dh, dx, G(lp.ln1_w), G(lp.ln1_b), N, H));
+    layernorm_bwd(s, dt, dxn, ls.x, ls.m1, ls.r1, c->P(lp.ln1_w), dh, dx, G(lp.ln1_w), G(lp.ln1_b), N, H, &sink);
     dcur = dx;
+    flush_wgrads();
   }
   // final CNN LayerNorm
   {
     A.off = mark;
     di ^= 1;
     void* dx = dbuf[di];
-    RUN(layernorm_bwd(s, dt, dcur, c->fn_x, c->fn_mean, c->fn_rstd, c->P(L.fn_w), nullptr, dx, G(L.fn_w), G(L.fn_b), N,
-                      H));
+    layernorm_bwd(s, dt, dcur, c->fn_x, c->fn_mean, c->fn_rstd, c->P(L.fn_w), nullptr, dx, G(L.fn_w), G(L.fn_b), N,
+                      H, &sink);
     dcur = dx;
   }
   // CNN stages, last to first
@@ -587,7 +614,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       A.off = mark;
       const void* dy = dcur;
       void* dz = A.alloc((size_t)Nn * C * es);
-      RUN(scale_bwd(s, dt, dy, bs.z, c->P(bp.gamma), dz, G(bp.gamma), Nn, C));
+      scale_bwd(s, dt, dy, bs.z, c->P(bp.gamma), dz, G(bp.gamma), Nn, C, &sink);
       wgrad(dz, C, bs.h, 2 * C, Nn, C, 2 * C, bp.pw2_w, 2 * C, (long)bp.pw2_b, 0);
       void* du = A.alloc((size_t)Nn * 2 * C * es);
       {
@@ -602,12 +629,13 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
         RUN(gemm_nt(s, dt, EPI_STORE, g));
       }
       void* dD = A.alloc((size_t)Nn * C * es);
-      RUN(dwln_bwd(s, dt, dln, bs.x, c->P(bp.dw_w), c->P(bp.dw_b), bs.mean, bs.rstd, c->P(bp.ln_w), dD, G(bp.ln_w),
-                   G(bp.ln_b), B, Lcur, C));
+      dwln_bwd(s, dt, dln, bs.x, c->P(bp.dw_w), c->P(bp.dw_b), bs.mean, bs.rstd, c->P(bp.ln_w), dD, G(bp.ln_w),
+                   G(bp.ln_b), B, Lcur, C, &sink);
       di ^= 1;
       void* dx = dbuf[di];
-      RUN(dwconv_bwd(s, dt, dD, bs.x, c->P(bp.dw_w), dy, dx, G(bp.dw_w), G(bp.dw_b), B, Lcur, C));
+      dwconv_bwd(s, dt, dD, bs.x, c->P(bp.dw_w), dy, dx, G(bp.dw_w), G(bp.dw_b), B, Lcur, C, &sink);
       dcur = dx;
+      flush_wgrads();
     }
     if (si > 0) {
       A.off = mark;
@@ -620,10 +648,11 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       }
       di ^= 1;
       void* dx = dbuf[di];
-      RUN(layernorm_bwd(s, dt, dln, sv.x, sv.mean, sv.rstd, c->P(st.ln_w), nullptr, dx, G(st.ln_w), G(st.ln_b), B * Lin,
-                        Cin));
+      layernorm_bwd(s, dt, dln, sv.x, sv.mean, sv.rstd, c->P(st.ln_w), nullptr, dx, G(st.ln_w), G(st.ln_b), B * Lin,
+                        Cin, &sink);
       dcur = dx;
       Lcur = Lin;
+      flush_wgrads();
     } else {
       RUN(stem_bwd(s, dt, audio, dcur, c->P(st.conv_w), c->P(st.conv_b), c->P(st.ln_w), G(st.conv_w), G(st.conv_b),
                    G(st.ln_w), G(st.ln_b), B, T));
@@ -631,6 +660,9 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   }
   // train.py:319-322: grads / grad_scale, all-finite flag
   RUN(hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, grads_valid, 1));
+  flush_wgrads();
+  c->part_total = sink.off;
+  RUN(reduce_partials(s, c->part_desc_dev, c->n_part_desc, c->partials, grads));
   RUN(grads_finalize(s, grads, L.n_params, 1.f / scale, grads_valid));
 #undef RUN
   return 0;
@@ -652,6 +684,23 @@ int plan(amt_ctx* c, int B, int T, int train_mode, hipStream_t s) {
   run_forward(c, s, nullptr, B, T, train_mode == 1, true, 0);
   if (train_mode == 1) run_backward(c, s, nullptr, nullptr, B, T, 1.f, true, 0, nullptr, nullptr);
   size_t need = c->arena.peak + 4096;
+  if (train_mode == 1) {
+    if (c->part_total > c->partials_cap) {
+      HIPCHK(c, hipDeviceSynchronize());
+      if (c->partials) (void)hipFree(c->partials);
+      c->partials = nullptr;
+      HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->partials), c->part_total * sizeof(float)));
+      c->partials_cap = c->part_total;
+    }
+    if (c->part_desc_dev) (void)hipFree(c->part_desc_dev);
+    c->part_desc_dev = nullptr;
+    c->n_part_desc = (int)c->part_descs.size();
+    if (c->n_part_desc > 0) {
+      HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->part_desc_dev), c->part_descs.size() * sizeof(PartDesc)));
+      HIPCHK(c, hipMemcpy(c->part_desc_dev, c->part_descs.data(), c->part_descs.size() * sizeof(PartDesc),
+                          hipMemcpyHostToDevice));
+    }
+  }
   c->arena = keep;
   if (need > c->arena.cap) {
     HIPCHK(c, hipDeviceSynchronize());
@@ -780,7 +829,8 @@ void amt_destroy(amt_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   void* ptrs[] = {c->params, c->wc, c->head_bias, c->conv_dev, c->conv_prefix_dev, c->rope_cos, c->rope_sin,
-                  c->arena.base, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, c->norm2, c->loss_acc};
+                  c->arena.base, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, c->norm2, c->loss_acc,
+                  c->partials, c->part_desc_dev};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete c;

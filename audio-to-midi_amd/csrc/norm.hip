@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dY, c
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ w, const T* dRes,
                                                      T* dX, float* __restrict__ dw,
-                                                     float* __restrict__ db, int N) {
+                                                     float* __restrict__ db, int N, int pstride) {
   using R = RowCfg<C>;
   constexpr int VEC = R::VEC, LPR = R::LPR;
   __shared__ float smem[C];
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dY, c
     }
     storevf<VEC>(dX + row * C + sub * VEC, o);
   }
-  reduce_cols_to_global<VEC, LPR>(aw, dw, smem);
-  reduce_cols_to_global<VEC, LPR>(ab, db, smem);
+  reduce_cols_to_global<VEC, LPR>(aw, dw, smem, pstride);
+  reduce_cols_to_global<VEC, LPR>(ab, db, smem, pstride);
 }
 
 template <typename T>
@@ -92,9 +92,10 @@ static void ln_fwd_t(hipStream_t s, const void* X, const float* w, const float* 
 }
 template <typename T>
 static void ln_bwd_t(hipStream_t s, const void* dY, const void* X, const float* mean, const float* rstd,
-                     const float* w, const void* dRes, void* dX, float* dw, float* db, int N, int C) {
-  AMT_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd_kernel<T, CC>), dim3(bwd_row_grid(N, RowCfg<CC>::RPB)), dim3(256), 0,
-                                       s, (const T*)dY, (const T*)X, mean, rstd, w, (const T*)dRes, (T*)dX, dw, db, N));
+                     const float* w, const void* dRes, void* dX, float* dw, float* db, int N, int C, int nb,
+                     int pstride) {
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd_kernel<T, CC>), dim3(nb), dim3(256), 0, s, (const T*)dY, (const T*)X,
+                                       mean, rstd, w, (const T*)dRes, (T*)dX, dw, db, N, pstride));
 }
 
 void layernorm_fwd(hipStream_t s, DType dt, const void* X, const float* w, const float* b, void* Y, float* mean,
@@ -104,10 +105,22 @@ void layernorm_fwd(hipStream_t s, DType dt, const void* X, const float* w, const
   else ln_fwd_t<bf16>(s, X, w, b, Y, mean, rstd, N, C);
 }
 void layernorm_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const float* mean, const float* rstd,
-                   const float* w, const void* dRes, void* dX, float* dw, float* db, int N, int C) {
+                   const float* w, const void* dRes, void* dX, float* dw, float* db, int N, int C,
+                   PartialSink* sink) {
+  const int nb = bwd_blocks(N, C, sink);
+  int pstride = 0;
+  if (sink) {   // records [nb][w(C) | b(C)]
+    size_t o = sink->take((size_t)nb * 2 * C);
+    sink->add(o, nb, 2 * C, C, dw);
+    sink->add(o + C, nb, 2 * C, C, db);
+    if (sink->dry) return;
+    pstride = 2 * C;
+    dw = sink->ws + o;
+    db = dw + C;
+  }
   ProfScope ps(s, "layernorm_bwd", 0, (dRes ? 4.0 : 3.0) * N * C * (dt == DT_F32 ? 4 : 2));
-  if (dt == DT_F32) ln_bwd_t<float>(s, dY, X, mean, rstd, w, dRes, dX, dw, db, N, C);
-  else ln_bwd_t<bf16>(s, dY, X, mean, rstd, w, dRes, dX, dw, db, N, C);
+  if (dt == DT_F32) ln_bwd_t<float>(s, dY, X, mean, rstd, w, dRes, dX, dw, db, N, C, nb, pstride);
+  else ln_bwd_t<bf16>(s, dY, X, mean, rstd, w, dRes, dX, dw, db, N, C, nb, pstride);
 }
 
 }  // namespace amt

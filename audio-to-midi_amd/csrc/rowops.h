@@ -17,7 +17,11 @@ template <int C> struct RowCfg {
 // Sum per-lane partial column sums over every lane of the block that owns the same feature
 // chunk, then atomically add the C results to global memory.  All 256 threads must call it.
 template <int VEC, int LPR>
-AMT_DEV void reduce_cols_to_global(const float (&acc)[VEC], float* gdst, float* smem /* >= VEC*LPR floats */) {
+// pstride == 0: atomicAdd into gdst[0..C).  pstride > 0: plain store into this block's record,
+// gdst[blockIdx.x * pstride + 0..C) — the records are summed once per step by reduce_partials,
+// which removes the same-address atomic contention of hundreds of blocks.
+AMT_DEV void reduce_cols_to_global(const float (&acc)[VEC], float* gdst, float* smem /* >= VEC*LPR floats */,
+                                   int pstride = 0) {
   constexpr int C = VEC * LPR;
   const int tid = threadIdx.x, lane = tid & 63;
   const int sub = lane % LPR, rw = lane / LPR;
@@ -32,8 +36,21 @@ AMT_DEV void reduce_cols_to_global(const float (&acc)[VEC], float* gdst, float* 
     if (rw == 0) atomicAdd(&smem[sub * VEC + i], v);
   }
   __syncthreads();
-  if (gdst != nullptr)
-    for (int t = tid; t < C; t += 256) atomicAdd(&gdst[t], smem[t]);
+  if (gdst != nullptr) {
+    if (pstride > 0) {
+      float* rec = gdst + (size_t)blockIdx.x * pstride;
+      for (int t = tid; t < C; t += 256) rec[t] = smem[t];
+    } else {
+      for (int t = tid; t < C; t += 256) atomicAdd(&gdst[t], smem[t]);
+    }
+  }
+}
+
+
+
+static inline int rows_per_block(int C) {
+  int vec = C >= 8 ? 8 : 4;
+  return 4 * (64 / (C / vec));
 }
 
 static inline int row_grid(long N, int rows_per_block, int max_blocks = 2048) {
@@ -47,11 +64,16 @@ static inline int row_grid(long N, int rows_per_block, int max_blocks = 2048) {
 // (parameter gradients).  Contended float atomics run ~14x below the uncontended rate
 // (MI355X_MICROARCH.md, Global float atomics), so keep the number of adding blocks small and give
 // every block at least 8 row groups of streaming work.
-static inline int bwd_row_grid(long N, int rows_per_block, int max_blocks = 128) {
-  long nb = (N + (long)rows_per_block * 8 - 1) / ((long)rows_per_block * 8);
+static inline int bwd_row_grid(long N, int rows_per_block, int max_blocks = 128, int min_groups = 8) {
+  long nb = (N + (long)rows_per_block * min_groups - 1) / ((long)rows_per_block * min_groups);
   if (nb > max_blocks) nb = max_blocks;
   if (nb < 1) nb = 1;
   return (int)nb;
+}
+
+// grid of a backward row kernel: with per-block records (sink) the blocks do not contend, so use more
+template <typename Sink> static inline int bwd_blocks(long N, int C, const Sink* sink) {
+  return sink ? bwd_row_grid(N, rows_per_block(C), 256, 2) : bwd_row_grid(N, rows_per_block(C), 128, 8);
 }
 
 #define AMT_DISPATCH_C(C_, ...)                       \
