@@ -15,8 +15,6 @@
 
 namespace amt {
 
-constexpr int GBK = 32;       // K step
-constexpr int GLDK = 40;      // LDS row stride (elements): 32 + 8 pad, keeps 16-B alignment
 constexpr int GBF = 64;       // features per workgroup
 
 template <typename T>
@@ -112,9 +110,15 @@ template <typename T, int EPI, int BT>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   constexpr int TI = BT / 32;
   constexpr int FI = 2;
-  constexpr int XCH = BT * 4 / 256;   // X chunks per thread per K step
-  __shared__ __attribute__((aligned(16))) T Xs[2][BT][GLDK];
-  __shared__ __attribute__((aligned(16))) T Ws[2][GBF][GLDK];
+  // K panel per LDS stage: 64 deep for bf16 (two MFMA k-steps per barrier, 4+ loads in flight per
+  // thread), 32 for the f32 verification build (keeps static LDS under 64 KB)
+  constexpr int BK = sizeof(T) == 2 ? 64 : 32;
+  constexpr int LDK = BK + 8;
+  constexpr int CPR = BK / 8;                // 8-element chunks per tile row
+  constexpr int XCH = BT * CPR / 256;        // X chunks per thread per stage
+  constexpr int WCH = GBF * CPR / 256;       // W chunks per thread per stage
+  __shared__ __attribute__((aligned(16))) T Xs[2][BT][LDK];
+  __shared__ __attribute__((aligned(16))) T Ws[2][GBF][LDK];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -130,45 +134,53 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) acc[fi][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  Chunk8<T> xr[XCH], wr;
+  Chunk8<T> xr[XCH], wr[WCH];
   auto load_tiles = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
-      int id = tid + i * 256, row = id >> 2, c = id & 3;
+      int id = tid + i * 256, row = id / CPR, c = id % CPR;
       int n = n0 + row;
       xr[i] = (n < a.N) ? load_k_chunk(X + (size_t)n * a.ldx, k0 + 8 * c, K) : chunk_zero<T>();
     }
-    {
-      int row = tid >> 2, c = tid & 3;
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      int id = tid + i * 256, row = id / CPR, c = id % CPR;
       int m = m0 + row;
-      wr = (m < a.M) ? load_k_chunk(W + (size_t)m * a.ldw, k0 + 8 * c, K) : chunk_zero<T>();
+      wr[i] = (m < a.M) ? load_k_chunk(W + (size_t)m * a.ldw, k0 + 8 * c, K) : chunk_zero<T>();
     }
   };
   auto store_tiles = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
-      int id = tid + i * 256, row = id >> 2, c = id & 3;
+      int id = tid + i * 256, row = id / CPR, c = id % CPR;
       chunk_store(&Xs[buf][row][8 * c], xr[i]);
     }
-    chunk_store(&Ws[buf][tid >> 2][8 * (tid & 3)], wr);
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      int id = tid + i * 256, row = id / CPR, c = id % CPR;
+      chunk_store(&Ws[buf][row][8 * c], wr[i]);
+    }
   };
 
-  const int nk = (K + GBK - 1) / GBK;
+  const int nk = (K + BK - 1) / BK;
   load_tiles(0);
   store_tiles(0);
   __syncthreads();
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tiles((kt + 1) * GBK);
-    Frag<T> wfr[FI], xfr[TI];
+    if (kt + 1 < nk) load_tiles((kt + 1) * BK);
 #pragma unroll
-    for (int fi = 0; fi < FI; ++fi) wfr[fi] = frag_row(&Ws[cur][wf * 32 + fi * 16 + r][8 * g]);
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      Frag<T> wfr[FI], xfr[TI];
 #pragma unroll
-    for (int ti = 0; ti < TI; ++ti) xfr[ti] = frag_row(&Xs[cur][wt * (BT / 2) + ti * 16 + r][8 * g]);
+      for (int fi = 0; fi < FI; ++fi) wfr[fi] = frag_row(&Ws[cur][wf * 32 + fi * 16 + r][32 * kk + 8 * g]);
 #pragma unroll
-    for (int fi = 0; fi < FI; ++fi)
+      for (int ti = 0; ti < TI; ++ti) xfr[ti] = frag_row(&Xs[cur][wt * (BT / 2) + ti * 16 + r][32 * kk + 8 * g]);
 #pragma unroll
-      for (int ti = 0; ti < TI; ++ti) mma(acc[fi][ti], wfr[fi], xfr[ti]);
+      for (int fi = 0; fi < FI; ++fi)
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) mma(acc[fi][ti], wfr[fi], xfr[ti]);
+    }
     if (kt + 1 < nk) store_tiles(cur ^ 1);
     __syncthreads();
     cur ^= 1;

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -236,6 +237,13 @@ struct amt_ctx {
   std::vector<PartDesc> part_descs;
   PartDesc* part_desc_dev = nullptr;
   int n_part_desc = 0;
+  // side stream for weight-gradient launches (they only feed the gradient buffer, so they overlap
+  // with the dependent data-gradient chain); events are created at plan time
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0, ev_needed = 0;
+  size_t scratch_max = 0;       // bytes of per-scope backward scratch (two alternating regions)
+  bool use_side = false;
 
   const float* P(size_t off) const { return params + off; }
   const void* WC(size_t off) const { return static_cast<const char*>(wc) + off * esz; }
@@ -479,7 +487,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   if (dry) { c->part_descs.clear(); sink.descs = &c->part_descs; }
 
   auto G = [&](size_t off) { return grads + off; };
-  std::vector<WgradArgs> pending;
+  std::vector<WgradArgs> pending, pending_skinny;
   auto wgrad = [&](const void* Gm, int ldg, const void* Am, int lda, int n, int M, int Kp, size_t w_off, int ldw,
                    long b_off, int m_store) {
     WgradArgs w;
@@ -487,18 +495,57 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     w.G = Gm; w.ldg = ldg; w.A = Am; w.lda = lda; w.N = n; w.M = M; w.Kp = Kp;
     w.dW = G(w_off); w.ldw = ldw; w.dbias = b_off >= 0 ? G((size_t)b_off) : nullptr; w.M_store = m_store;
     const int tiles = ((M + 63) / 64) * ((Kp + 63) / 64);
-    if (tiles == 1 && n >= 16384) gemm_tn_wgrad(s, dt, w, &sink);   // skinny: per-split records
-    else pending.push_back(w);                                       // grouped launch at the end of the layer
+    if (tiles == 1 && n >= 16384) pending_skinny.push_back(w);   // per-split records (gemm.hip)
+    else pending.push_back(w);                                    // grouped launch
   };
-  // all queued weight gradients of a layer / block in one launch; must run before the layer's
-  // scratch tensors are recycled
-  auto flush_wgrads = [&]() {
-    for (size_t i = 0; i < pending.size(); i += 8) {
-      int cnt = (int)std::min<size_t>(8, pending.size() - i);
-      gemm_tn_wgrad_group(s, dt, pending.data() + i, cnt, &sink);
+  // ---- scopes.  The backward pass is a chain of scopes (decoder, each transformer layer, final
+  // LayerNorm, each CNN block, each downsample).  The data-gradient chain of a scope runs on the
+  // main stream; its weight-gradient launches are queued and issued on the side stream when the
+  // scope ends, so they overlap with the NEXT scopes' chain.  Scratch tensors alternate between two
+  // regions and the residual-gradient buffers rotate over three, and scope j waits for the side
+  // work of scope j-2 before it reuses that scope's region / buffer.
+  const bool side_on = c->use_side && c->side != nullptr;
+  hipStream_t ws = side_on ? c->side : s;
+  std::vector<hipEvent_t> side_done;
+  size_t mark = 0;
+  size_t scratch_used = 0;
+  auto next_event = [&]() -> hipEvent_t {
+    if (dry) { c->ev_needed++; return nullptr; }
+    return c->ev_pool[c->ev_used++];
+  };
+  auto begin_scope = [&]() {
+    const size_t j = side_done.size();
+    if (side_on && j >= 2 && side_done[j - 2] != nullptr) RUN((void)hipStreamWaitEvent(s, side_done[j - 2], 0));
+    A.off = mark + (j & 1) * c->scratch_max;
+  };
+  auto end_scope = [&]() {
+    const size_t j = side_done.size();
+    const size_t base = mark + (j & 1) * c->scratch_max;
+    if (A.off > base && A.off - base > scratch_used) scratch_used = A.off - base;
+    hipEvent_t done = nullptr;
+    if (!pending.empty() || !pending_skinny.empty()) {
+      if (side_on) {
+        hipEvent_t ev = next_event();
+        RUN((void)hipEventRecord(ev, s));
+        RUN((void)hipStreamWaitEvent(ws, ev, 0));
+      }
+      for (const WgradArgs& w : pending_skinny) gemm_tn_wgrad(ws, dt, w, &sink);
+      for (size_t i = 0; i < pending.size(); i += 8) {
+        int cnt = (int)std::min<size_t>(8, pending.size() - i);
+        gemm_tn_wgrad_group(ws, dt, pending.data() + i, cnt, &sink);
+      }
+      pending.clear();
+      pending_skinny.clear();
+      if (side_on) {
+        done = next_event();
+        RUN((void)hipEventRecord(done, ws));
+        if (dry) done = reinterpret_cast<hipEvent_t>(1);   // placeholder so the wait is counted as present
+      }
     }
-    pending.clear();
+    side_done.push_back(done);
   };
+  c->ev_used = 0;
+  if (dry) c->ev_needed = 0;
 
   RUN((void)hipMemsetAsync(grads, 0, L.n_params * sizeof(float), s));
   RUN((void)hipMemsetAsync(c->loss_acc, 0, 2 * sizeof(float), s));
@@ -506,9 +553,12 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   // two ping-pong gradient buffers for the residual stream / CNN activations
   const size_t act_elems = (size_t)B * (T / 5) * 4;
   const size_t res_elems = act_elems > (size_t)N * H ? act_elems : (size_t)N * H;
-  void* dbuf[2] = {A.alloc(res_elems * es), A.alloc(res_elems * es)};
+  void* dbuf[3] = {A.alloc(res_elems * es), A.alloc(res_elems * es), A.alloc(res_elems * es)};
   int di = 0;
-  const size_t mark = A.off;
+  mark = A.off;
+  A.off = mark + 2 * c->scratch_max;     // both scratch regions are part of the plan
+  if (A.off > A.peak) A.peak = A.off;
+  begin_scope();
 
   // loss + dlogits
   void* dlog = A.alloc((size_t)N * L.VP * es);
@@ -521,15 +571,15 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     RUN(gemm_nt(s, dt, EPI_STORE, g));
   }
   void* dcur = dbuf[di];
-  flush_wgrads();
   layernorm_bwd(s, dt, dhn, c->hd_x, c->hd_mean, c->hd_rstd, c->P(L.hd_lnw), nullptr, dcur, G(L.hd_lnw),
                     G(L.hd_lnb), N, H, &sink);
+  end_scope();
 
   for (int li = (int)L.layers.size() - 1; li >= 0; --li) {
     const LayerP& lp = L.layers[li];
     const LayerSave& ls = c->lsave[li];
     const bool local = (li % 2 == 0);
-    A.off = mark;
+    begin_scope();
     const void* dy = dcur;
     const void* dyd = dy;
     if (dp.thr) {
@@ -586,20 +636,21 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       GemmArgs g = gargs(dqc, L.QC, c->WC(lp.c_wqct), L.QC, N, H, L.QC, nullptr, dxn, H);
       RUN(gemm_nt(s, dt, EPI_STORE, g));
     }
-    di ^= 1;
+    di = (di + 1) % 3;
     void* dx = dbuf[di];
     layernorm_bwd(s, dt, dxn, ls.x, ls.m1, ls.r1, c->P(lp.ln1_w), dh, dx, G(lp.ln1_w), G(lp.ln1_b), N, H, &sink);
     dcur = dx;
-    flush_wgrads();
+    end_scope();
   }
   // final CNN LayerNorm
   {
-    A.off = mark;
-    di ^= 1;
+    begin_scope();
+    di = (di + 1) % 3;
     void* dx = dbuf[di];
     layernorm_bwd(s, dt, dcur, c->fn_x, c->fn_mean, c->fn_rstd, c->P(L.fn_w), nullptr, dx, G(L.fn_w), G(L.fn_b), N,
                       H, &sink);
     dcur = dx;
+    end_scope();
   }
   // CNN stages, last to first
   int Lcur = S;
@@ -611,7 +662,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     for (int j = (int)st.blocks.size() - 1; j >= 0; --j) {
       const BlockP& bp = st.blocks[j];
       const BlockSave& bs = sv.blocks[j];
-      A.off = mark;
+      begin_scope();
       const void* dy = dcur;
       void* dz = A.alloc((size_t)Nn * C * es);
       scale_bwd(s, dt, dy, bs.z, c->P(bp.gamma), dz, G(bp.gamma), Nn, C, &sink);
@@ -631,14 +682,14 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       void* dD = A.alloc((size_t)Nn * C * es);
       dwln_bwd(s, dt, dln, bs.x, c->P(bp.dw_w), c->P(bp.dw_b), bs.mean, bs.rstd, c->P(bp.ln_w), dD, G(bp.ln_w),
                    G(bp.ln_b), B, Lcur, C, &sink);
-      di ^= 1;
+      di = (di + 1) % 3;
       void* dx = dbuf[di];
       dwconv_bwd(s, dt, dD, bs.x, c->P(bp.dw_w), dy, dx, G(bp.dw_w), G(bp.dw_b), B, Lcur, C, &sink);
       dcur = dx;
-      flush_wgrads();
+      end_scope();
     }
     if (si > 0) {
-      A.off = mark;
+      begin_scope();
       const int Cin = st.Cin, Lin = Lcur * 2;
       wgrad(dcur, C, sv.ln, 2 * Cin, Nn, C, 2 * Cin, st.conv_w, 2 * Cin, (long)st.conv_b, 0);
       void* dln = A.alloc((size_t)Nn * 2 * Cin * es);
@@ -646,13 +697,13 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
         GemmArgs g = gargs(dcur, C, c->WC(st.c_wt), C, Nn, 2 * Cin, C, nullptr, dln, 2 * Cin);
         RUN(gemm_nt(s, dt, EPI_STORE, g));
       }
-      di ^= 1;
+      di = (di + 1) % 3;
       void* dx = dbuf[di];
       layernorm_bwd(s, dt, dln, sv.x, sv.mean, sv.rstd, c->P(st.ln_w), nullptr, dx, G(st.ln_w), G(st.ln_b), B * Lin,
                         Cin, &sink);
       dcur = dx;
       Lcur = Lin;
-      flush_wgrads();
+      end_scope();
     } else {
       RUN(stem_bwd(s, dt, audio, dcur, c->P(st.conv_w), c->P(st.conv_b), c->P(st.ln_w), G(st.conv_w), G(st.conv_b),
                    G(st.ln_w), G(st.ln_b), B, T));
@@ -660,7 +711,13 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   }
   // train.py:319-322: grads / grad_scale, all-finite flag
   RUN(hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, grads_valid, 1));
-  flush_wgrads();
+  // join: the main stream waits for the side work of the last two scopes (older ones were waited for
+  // when their regions were reused)
+  if (side_on) {
+    for (size_t j = side_done.size() >= 2 ? side_done.size() - 2 : 0; j < side_done.size(); ++j)
+      if (side_done[j] != nullptr) RUN((void)hipStreamWaitEvent(s, side_done[j], 0));
+  }
+  if (dry && scratch_used > c->scratch_max) c->scratch_max = scratch_used;
   c->part_total = sink.off;
   RUN(reduce_partials(s, c->part_desc_dev, c->n_part_desc, c->partials, grads));
   RUN(grads_finalize(s, grads, L.n_params, 1.f / scale, grads_valid));
@@ -677,14 +734,29 @@ int plan(amt_ctx* c, int B, int T, int train_mode, hipStream_t s) {
     c->err = "workspace for this (B, T) is not planned yet: run once outside stream capture";
     return 1;
   }
+  if (train_mode == 1 && c->use_side && c->side == nullptr)
+    HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
   Arena dryA;
   dryA.dry = true;
   Arena keep = c->arena;
   c->arena = dryA;
   run_forward(c, s, nullptr, B, T, train_mode == 1, true, 0);
-  if (train_mode == 1) run_backward(c, s, nullptr, nullptr, B, T, 1.f, true, 0, nullptr, nullptr);
+  if (train_mode == 1) {
+    // pass 1 measures the per-scope scratch, pass 2 lays out the two alternating scratch regions
+    c->scratch_max = 0;
+    const size_t fwd_end = c->arena.off;
+    run_backward(c, s, nullptr, nullptr, B, T, 1.f, true, 0, nullptr, nullptr);
+    c->arena.off = fwd_end;
+    c->arena.peak = fwd_end;
+    run_backward(c, s, nullptr, nullptr, B, T, 1.f, true, 0, nullptr, nullptr);
+  }
   size_t need = c->arena.peak + 4096;
   if (train_mode == 1) {
+    while (c->ev_pool.size() < c->ev_needed + 8) {
+      hipEvent_t e;
+      HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      c->ev_pool.push_back(e);
+    }
     if (c->part_total > c->partials_cap) {
       HIPCHK(c, hipDeviceSynchronize());
       if (c->partials) (void)hipFree(c->partials);
@@ -802,6 +874,10 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   c->dt = cfg->act_dtype == AMT_F32 ? DT_F32 : DT_BF16;
   c->esz = c->dt == DT_F32 ? 4 : 2;
   c->device = device;
+  // measured on MI355X (profiles/r01_notes.md): running the weight-gradient launches on a side
+  // stream does not help at B = 8 x 10 s (9.47 vs 9.09 ms/step): the chain kernels already occupy
+  // every CU and slow down when sharing them.  Kept as an opt-in for larger per-GPU batches.
+  c->use_side = getenv("AMT_SIDE_STREAM") != nullptr;
   const Layout& L = c->L;
   auto fail = [&](const char* what, hipError_t err) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(err);
@@ -833,6 +909,8 @@ void amt_destroy(amt_ctx* c) {
                   c->partials, c->part_desc_dev};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
 }
 
