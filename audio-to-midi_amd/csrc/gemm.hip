@@ -12,6 +12,7 @@
 #include "prof.h"
 #include <string>
 #include <cstring>
+#include <cstdlib>
 
 namespace amt {
 
@@ -272,8 +273,13 @@ AMT_DEV Chunk8<T> load_f_chunk(const T* rowp, int f, int F) {
 
 template <typename T>
 AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx, int by) {
-  __shared__ __attribute__((aligned(16))) T Gs[2][32][WLD];
-  __shared__ __attribute__((aligned(16))) T As[2][32][WLD];
+  // TOK tokens per LDS stage (4 MFMA k-steps for bf16): every thread keeps 8 sixteen-byte loads in
+  // flight per stage, so a split of a few hundred tokens costs 2-4 memory round trips instead of
+  // one per 32 tokens.  One LDS buffer + register prefetch of the next stage.
+  constexpr int TOK = sizeof(T) == 2 ? 128 : 64;
+  constexpr int NCH = TOK * 8 / 256;          // chunks per thread per operand per stage
+  __shared__ __attribute__((aligned(16))) T Gs[TOK][WLD];
+  __shared__ __attribute__((aligned(16))) T As[TOK][WLD];
   __shared__ float red[32][65];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -296,44 +302,48 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
 #pragma unroll
   for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
 
-  const int lrow = tid >> 3, lc = tid & 7;
-  Chunk8<T> gr, ar;
+  const int lrow = tid >> 3, lc = tid & 7;   // thread covers rows lrow + 32 i, chunk lc
+  Chunk8<T> gr[NCH], ar[NCH];
   auto load_tiles = [&](int nb) {
-    int n = nb + lrow;
-    bool ok = n < nend;
-    gr = ok ? load_f_chunk(G + (size_t)n * a.ldg, m0 + 8 * lc, a.M) : chunk_zero<T>();
-    ar = ok ? load_f_chunk(A + (size_t)n * a.lda, k0 + 8 * lc, a.Kp) : chunk_zero<T>();
-  };
-  auto store_tiles = [&](int buf) {
-    chunk_store(&Gs[buf][lrow][8 * lc], gr);
-    chunk_store(&As[buf][lrow][8 * lc], ar);
-    if (do_bias) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) bsum[i] += chunk_get(gr, i);
+    for (int i = 0; i < NCH; ++i) {
+      int n = nb + lrow + 32 * i;
+      bool ok = n < nend;
+      gr[i] = ok ? load_f_chunk(G + (size_t)n * a.ldg, m0 + 8 * lc, a.M) : chunk_zero<T>();
+      ar[i] = ok ? load_f_chunk(A + (size_t)n * a.lda, k0 + 8 * lc, a.Kp) : chunk_zero<T>();
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      chunk_store(&Gs[lrow + 32 * i][8 * lc], gr[i]);
+      chunk_store(&As[lrow + 32 * i][8 * lc], ar[i]);
+      if (do_bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] += chunk_get(gr[i], e);
+      }
     }
   };
 
-  const int nsteps = (nend - nbeg + 31) / 32;
-  if (nsteps > 0) {
-    load_tiles(nbeg);
-    store_tiles(0);
-  }
-  __syncthreads();
-  int cur = 0;
+  const int nsteps = (nend - nbeg + TOK - 1) / TOK;
+  if (nsteps > 0) load_tiles(nbeg);
   for (int st = 0; st < nsteps; ++st) {
-    if (st + 1 < nsteps) load_tiles(nbeg + (st + 1) * 32);
-    Frag<T> gf[2], af[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) gf[i] = frag_col16(&Gs[cur][8 * g][wm * 32 + i * 16], WLD, r);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) af[j] = frag_col16(&As[cur][8 * g][wk * 32 + j * 16], WLD, r);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) mma(acc[i][j], gf[i], af[j]);
-    if (st + 1 < nsteps) store_tiles(cur ^ 1);
+    __syncthreads();                 // previous stage fully consumed
+    store_tiles();
     __syncthreads();
-    cur ^= 1;
+    if (st + 1 < nsteps) load_tiles(nbeg + (st + 1) * TOK);
+#pragma unroll
+    for (int kk = 0; kk < TOK / 32; ++kk) {
+      Frag<T> gf[2], af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) gf[i] = frag_col16(&Gs[32 * kk + 8 * g][wm * 32 + i * 16], WLD, r);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) af[j] = frag_col16(&As[32 * kk + 8 * g][wk * 32 + j * 16], WLD, r);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma(acc[i][j], gf[i], af[j]);
+    }
   }
 
   // acc[i][j][e] = dW[m0 + wm*32 + i*16 + 4g + e][k0 + wk*32 + j*16 + r]
@@ -353,6 +363,7 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
     }
 
   if (do_bias) {
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 8; ++i) red[lrow][8 * lc + i] = bsum[i];
     __syncthreads();
@@ -396,7 +407,7 @@ void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a_in, PartialSink* 
     // writing one record; reduce_partials sums them (no same-address atomics)
     int rps = 256;
     int splits = (a.N + rps - 1) / rps;
-    if (splits > 1024) { splits = 1024; rps = ((a.N + splits - 1) / splits + 31) / 32 * 32; splits = (a.N + rps - 1) / rps; }
+    if (splits > 1024) { splits = 1024; rps = ((a.N + splits - 1) / splits + 127) / 128 * 128; splits = (a.N + rps - 1) / rps; }
     const size_t rec = (size_t)Mst * a.Kp + (a.dbias ? Mst : 0);
     size_t o = sink->take((size_t)splits * rec);
     sink->add(o, splits, (uint32_t)rec, (uint32_t)(Mst * a.Kp), a.dW);
@@ -420,7 +431,7 @@ void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a_in, PartialSink* 
   if (splits > max_splits) splits = max_splits;
   if (splits > 48) splits = 48;
   if (splits < 1) splits = 1;
-  int rps = ((a.N + splits - 1) / splits + 31) / 32 * 32;
+  int rps = ((a.N + splits - 1) / splits + 127) / 128 * 128;
   splits = (a.N + rps - 1) / rps;
   dim3 grid(tiles, splits);
   const double es = dt == DT_F32 ? 4 : 2;
@@ -450,12 +461,15 @@ void gemm_tn_wgrad_group(hipStream_t s, DType dt, const WgradArgs* probs, int n,
   const double es = dt == DT_F32 ? 4 : 2;
   for (int i = 0; i < n; ++i) {
     const WgradArgs& a = probs[i];
-    int splits = (1536 + total_tiles - 1) / total_tiles;
+    // few token splits: every split adds M*Kp*4 bytes of fp32 atomics and the chip-wide atomic rate
+    // (~1.3 TB/s) was the bound at 1536 workgroups (38 us per layer group vs 24 us at ~224)
+    static const int target_wgs = getenv("AMT_WGRAD_TARGET_WGS") ? atoi(getenv("AMT_WGRAD_TARGET_WGS")) : 224;
+    int splits = (target_wgs + total_tiles - 1) / total_tiles;
     int max_splits = (a.N + 127) / 128;
     if (splits > max_splits) splits = max_splits;
     if (splits > 48) splits = 48;
     if (splits < 1) splits = 1;
-    int rps = ((a.N + splits - 1) / splits + 31) / 32 * 32;
+    int rps = ((a.N + splits - 1) / splits + 127) / 128 * 128;
     splits = (a.N + rps - 1) / rps;
     g.rps[i] = rps;
     g.prefix[i + 1] = g.prefix[i] + g.tiles[i] * splits;
