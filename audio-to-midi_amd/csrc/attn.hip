@@ -193,15 +193,14 @@ __global__ __launch_bounds__(256) void attn_global_fwd_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------ global backward: dQ (and delta)
 template <typename T>
-__global__ __launch_bounds__(256) void attn_global_bwd_dq_kernel(AttnBwdArgs ba) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, unsigned char* smem_raw) {
   const AttnArgs& a = ba.f;
   T* Ks = reinterpret_cast<T*>(smem_raw);
   T* Vs = Ks + 64 * ALD;
   T* Ps = Vs + 64 * ALD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z, S = a.S;
-  const int qrow = blockIdx.x * 64 + wave * 16 + r;
+  const int qrow = tile * 64 + wave * 16 + r;
   const T* QC = reinterpret_cast<const T*>(a.QC);
   const T* KV = reinterpret_cast<const T*>(a.KV);
   const T* O = reinterpret_cast<const T*>(a.O);
@@ -299,8 +298,7 @@ __global__ __launch_bounds__(256) void attn_global_bwd_dq_kernel(AttnBwdArgs ba)
 
 // ------------------------------------------------------------------ global backward: dK, dV
 template <typename T>
-__global__ __launch_bounds__(256) void attn_global_bwd_dkv_kernel(AttnBwdArgs ba) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, unsigned char* smem_raw) {
   const AttnArgs& a = ba.f;
   T* Qs = reinterpret_cast<T*>(smem_raw);
   T* dOs = Qs + 64 * ALD;
@@ -310,10 +308,11 @@ __global__ __launch_bounds__(256) void attn_global_bwd_dkv_kernel(AttnBwdArgs ba
   float* delta_s = lse_s + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z, S = a.S;
-  const int key = blockIdx.x * 64 + wave * 16 + r;
+  const int key = tile * 64 + wave * 16 + r;
   const T* QC = reinterpret_cast<const T*>(a.QC);
   const T* KV = reinterpret_cast<const T*>(a.KV);
   const T* dO = reinterpret_cast<const T*>(ba.dO);
+  const T* O = reinterpret_cast<const T*>(a.O);
   T* PTw = PT + wave * 16 * ALD;
   T* dSTw = dST + wave * 16 * ALD;
 
@@ -353,13 +352,27 @@ __global__ __launch_bounds__(256) void attn_global_bwd_dkv_kernel(AttnBwdArgs ba
         for (int i = 0; i < 8; ++i) x[i] = to_f(from_f<T>(x[i])) * 0.125f;
       }
       store8f(Qs + row * ALD + 8 * c, x);
-      stage_row_chunk(dOs + row * ALD + 8 * c, dO + (size_t)(b * S + q) * ba.lddo + h * 64 + 8 * c, q < S, a.cos,
-                      a.sin, 0, 0, false, 1.f);
+      // dO chunk to LDS; delta[q] = sum_d dO[q][d] O[q][d] is formed here (8 lanes share a row), so
+      // this role does not depend on the dQ role and both run in one launch
+      float dch[8], och[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { dch[i] = 0.f; och[i] = 0.f; }
+      if (q < S) {
+        load8f(dO + (size_t)(b * S + q) * ba.lddo + h * 64 + 8 * c, dch);
+        load8f(O + (size_t)(b * S + q) * a.ldo + h * 64 + 8 * c, och);
+      }
+      store8f(dOs + row * ALD + 8 * c, dch);
+      float part = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) part += dch[i] * och[i];
+      part += __shfl_xor(part, 1, 64);
+      part += __shfl_xor(part, 2, 64);
+      part += __shfl_xor(part, 4, 64);
+      if (c == 0) delta_s[row] = part;
     }
     if (tid < 64) {
       int q = qt * 64 + tid;
       lse_s[tid] = (q < S) ? a.LSE[(size_t)(b * a.H + h) * S + q] : 0.f;
-      delta_s[tid] = (q < S) ? ba.delta[(size_t)(b * a.H + h) * S + q] : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -414,6 +427,14 @@ __global__ __launch_bounds__(256) void attn_global_bwd_dkv_kernel(AttnBwdArgs ba
   }
 }
 
+// one launch, two independent roles: blocks [0, ntile) compute dQ, blocks [ntile, 2 ntile) dK/dV
+template <typename T>
+__global__ __launch_bounds__(256) void attn_global_bwd_kernel(AttnBwdArgs ba, int ntile) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if ((int)blockIdx.x < ntile) attn_global_bwd_dq_body<T>(ba, blockIdx.x, smem_raw);
+  else attn_global_bwd_dkv_body<T>(ba, blockIdx.x - ntile, smem_raw);
+}
+
 template <typename K> static void set_max_lds(K kernel, size_t bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)bytes);
@@ -435,22 +456,18 @@ void attn_global_fwd(hipStream_t s, DType dt, const AttnArgs& a) {
 }
 
 void attn_global_bwd(hipStream_t s, DType dt, const AttnBwdArgs& a) {
-  dim3 grid((a.f.S + 63) / 64, a.f.H, a.f.B);
+  const int ntile = (a.f.S + 63) / 64;
+  dim3 grid(2 * ntile, a.f.H, a.f.B);
   ProfScope ps(s, "attn_global_bwd", 8.0 * a.f.B * a.f.H * (double)a.f.S * a.f.S * 64,
                8.0 * a.f.B * a.f.S * a.f.H * 64 * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) {
-    size_t lds1 = (size_t)(64 * 2 + 64) * ALD * sizeof(float);
-    size_t lds2 = (size_t)(64 * 2 + 128) * ALD * sizeof(float) + 128 * sizeof(float);
-    static bool once = (set_max_lds(attn_global_bwd_dq_kernel<float>, 96 * 1024),
-                        set_max_lds(attn_global_bwd_dkv_kernel<float>, 96 * 1024), true);
+    size_t lds = (size_t)(64 * 2 + 128) * ALD * sizeof(float) + 128 * sizeof(float);
+    static bool once = (set_max_lds(attn_global_bwd_kernel<float>, 96 * 1024), true);
     (void)once;
-    hipLaunchKernelGGL((attn_global_bwd_dq_kernel<float>), grid, dim3(256), lds1, s, a);
-    hipLaunchKernelGGL((attn_global_bwd_dkv_kernel<float>), grid, dim3(256), lds2, s, a);
+    hipLaunchKernelGGL((attn_global_bwd_kernel<float>), grid, dim3(256), lds, s, a, ntile);
   } else {
-    size_t lds1 = (size_t)(64 * 2 + 64) * ALD * sizeof(bf16);
-    size_t lds2 = (size_t)(64 * 2 + 128) * ALD * sizeof(bf16) + 128 * sizeof(float);
-    hipLaunchKernelGGL((attn_global_bwd_dq_kernel<bf16>), grid, dim3(256), lds1, s, a);
-    hipLaunchKernelGGL((attn_global_bwd_dkv_kernel<bf16>), grid, dim3(256), lds2, s, a);
+    size_t lds = (size_t)(64 * 2 + 128) * ALD * sizeof(bf16) + 128 * sizeof(float);
+    hipLaunchKernelGGL((attn_global_bwd_kernel<bf16>), grid, dim3(256), lds, s, a, ntile);
   }
 }
 
