@@ -171,17 +171,23 @@ void stem_bwd(hipStream_t s, DType dt, const void* audio, const void* dY, const 
 template <typename T, int VEC>
 AMT_DEV void dwconv_row(const T* __restrict__ X, long rowbase /* b*L */, int l, int L, int C, int sub,
                         const float (&wk)[7][VEC], const float (&bv)[VEC], float (&out)[VEC]) {
+  // all seven taps are loaded unconditionally from a clamped row and masked afterwards: a branch
+  // per tap would serialise seven L2 round trips (measured ~4 us per row visit)
+  float x[7][VEC];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    int ll = l + k - 3;
+    int lc = ll < 0 ? 0 : (ll >= L ? L - 1 : ll);
+    loadvf<VEC>(X + (rowbase + lc) * C + sub * VEC, x[k]);
+  }
 #pragma unroll
   for (int i = 0; i < VEC; ++i) out[i] = bv[i];
 #pragma unroll
   for (int k = 0; k < 7; ++k) {
     int ll = l + k - 3;
-    if (ll >= 0 && ll < L) {
-      float x[VEC];
-      loadvf<VEC>(X + (rowbase + ll) * C + sub * VEC, x);
+    float m = (ll >= 0 && ll < L) ? 1.f : 0.f;
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) out[i] += wk[k][i] * x[i];
-    }
+    for (int i = 0; i < VEC; ++i) out[i] += wk[k][i] * (x[k][i] * m);
   }
 }
 
@@ -348,6 +354,177 @@ __global__ __launch_bounds__(256) void scale_bwd_kernel(const T* __restrict__ dY
     storevf<VEC>(dZ + row * C + sub * VEC, o);
   }
   reduce_cols_to_global<VEC, LPR>(ag, dgamma, smem, pstride);
+}
+
+
+// ------------------------------------------------------------------ fused tail of the Block backward
+// rows kept in LDS per tile (TL interior rows + 3 halo rows each side)
+template <int C> struct DwTile {
+  static constexpr int ROWS = C <= 8 ? 256 : (C <= 32 ? 128 : (C <= 64 ? 64 : 32));
+  static constexpr int TL = ROWS - 6;
+};
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void dwblock_bwd_kernel(
+    const T* __restrict__ dLN, const T* __restrict__ X, const T* __restrict__ dY, const T* __restrict__ Z,
+    const float* __restrict__ wdw, const float* __restrict__ bdw, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ lnw, T* __restrict__ dX, float* dlnw, float* dlnb,
+    float* dwdw, float* dbdw, float* dgamma, int B, int L, int tiles_per_clip, int total_tiles, int pstride) {
+  using R = RowCfg<C>;
+  constexpr int VEC = R::VEC, LPR = R::LPR, RPB = R::RPB, RPW = R::RPW;
+  constexpr int ROWS = DwTile<C>::ROWS, TL = DwTile<C>::TL;
+  __shared__ __attribute__((aligned(16))) T dDs[ROWS][C];
+  __shared__ float smem[11 * C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, rw = lane / LPR;
+  float wk[7][VEC], bv[VEC], wv[VEC];
+  float aw[7][VEC], ab[VEC], alw[VEC], alb[VEC], ag[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    bv[i] = bdw[sub * VEC + i]; wv[i] = lnw[sub * VEC + i];
+    ab[i] = 0.f; alw[i] = 0.f; alb[i] = 0.f; ag[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { wk[k][i] = wdw[k * C + sub * VEC + i]; aw[k][i] = 0.f; }
+  }
+  for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    const int b = t / tiles_per_clip, l0 = (t % tiles_per_clip) * TL;
+    const long rb = (long)b * L;
+    __syncthreads();   // previous tile's phase 2 done with dDs
+    // ---- phase 1: dD for rows l0-3 .. l0+TL+2 into LDS
+    for (int p = wave * RPW + rw; p < ROWS; p += RPB) {
+      const int l = l0 - 3 + p;
+      float o[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o[i] = 0.f;
+      if (l >= 0 && l < L) {
+        float d[VEC], dl[VEC];
+        dwconv_row<T, VEC>(X, rb, l, L, C, sub, wk, bv, d);
+        loadvf<VEC>(dLN + (rb + l) * C + sub * VEC, dl);
+        const float mu = mean[rb + l], rs = rstd[rb + l];
+        const bool interior = (p >= 3) && (p < TL + 3);
+        float s1 = 0.f, s2 = 0.f, gy[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          d[i] = (d[i] - mu) * rs;
+          gy[i] = dl[i] * wv[i];
+          s1 += gy[i];
+          s2 += gy[i] * d[i];
+          if (interior) { alw[i] += dl[i] * d[i]; alb[i] += dl[i]; }
+        }
+        s1 = group_sum<LPR>(s1) * (1.f / C);
+        s2 = group_sum<LPR>(s2) * (1.f / C);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] = rs * (gy[i] - s1 - d[i] * s2);
+      }
+      storevf<VEC>(&dDs[p][sub * VEC], o);
+    }
+    __syncthreads();
+    // ---- phase 2: dX = dY + conv^T(dD), depthwise weight / bias / gamma gradients
+    for (int i0 = wave * RPW + rw; i0 < TL; i0 += RPB) {
+      const int l = l0 + i0;
+      if (l < L) {
+        float o[VEC], dd[VEC], dy[VEC];
+        loadvf<VEC>(dY + (rb + l) * C + sub * VEC, dy);
+        loadvf<VEC>(&dDs[i0 + 3][sub * VEC], dd);   // value as stored (rounded to T), like the unfused path
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { o[i] = dy[i]; ab[i] += dd[i]; }
+        if (Z != nullptr) {
+          float z[VEC];
+          loadvf<VEC>(Z + (rb + l) * C + sub * VEC, z);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) ag[i] += dy[i] * z[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+          float tq[VEC];
+          loadvf<VEC>(&dDs[i0 + 6 - k][sub * VEC], tq);   // dD[l - k + 3] (zero outside the clip)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o[i] += wk[k][i] * tq[i];
+          const int lx = l + k - 3;
+          const int lxc = lx < 0 ? 0 : (lx >= L ? L - 1 : lx);
+          const float mx = (lx >= 0 && lx < L) ? 1.f : 0.f;
+          float x[VEC];
+          loadvf<VEC>(X + (rb + lxc) * C + sub * VEC, x);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) aw[k][i] += dd[i] * (x[i] * mx);
+        }
+        storevf<VEC>(dX + (rb + l) * C + sub * VEC, o);
+      }
+    }
+  }
+  // all eleven column sums through LDS with three barriers in total
+  __syncthreads();
+  for (int t = threadIdx.x; t < 11 * C; t += 256) smem[t] = 0.f;
+  __syncthreads();
+  auto fold = [&](const float (&acc)[VEC], int slot) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float v = acc[i];
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      if (rw == 0) atomicAdd(&smem[slot * C + sub * VEC + i], v);
+    }
+  };
+  fold(alw, 0);
+  fold(alb, 1);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) fold(aw[k], 2 + k);
+  fold(ab, 9);
+  fold(ag, 10);
+  __syncthreads();
+  if (pstride > 0) {   // record layout == smem layout: [lnw | lnb | taps 7C | bias | gamma]
+    float* rec = dlnw + (size_t)blockIdx.x * pstride;
+    const int n = dgamma != nullptr ? 11 * C : 10 * C;
+    for (int t = threadIdx.x; t < n; t += 256) rec[t] = smem[t];
+  } else {
+    for (int t = threadIdx.x; t < 11 * C; t += 256) {
+      const int slot = t / C, ch = t % C;
+      float* dst = slot == 0 ? dlnw : slot == 1 ? dlnb : slot < 9 ? dwdw + (slot - 2) * C : slot == 9 ? dbdw : dgamma;
+      if (dst != nullptr) atomicAdd(&dst[ch], smem[t]);
+    }
+  }
+}
+
+template <typename T>
+static void dwblock_bwd_t(hipStream_t s, const void* dLN, const void* X, const void* dY, const void* Z,
+                          const float* wdw, const float* bdw, const float* mean, const float* rstd, const float* lnw,
+                          void* dX, float* dlnw, float* dlnb, float* dwdw, float* dbdw, float* dgamma, int B, int L, int C,
+                          int nb, int tiles_per_clip, int total, int pstride) {
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwblock_bwd_kernel<T, CC>), dim3(nb), dim3(256), 0, s, (const T*)dLN,
+                                       (const T*)X, (const T*)dY, (const T*)Z, wdw, bdw, mean, rstd, lnw, (T*)dX, dlnw,
+                                       dlnb, dwdw, dbdw, dgamma, B, L, tiles_per_clip, total, pstride));
+}
+
+static int dw_tile_len(int C) { return (C <= 8 ? 256 : (C <= 32 ? 128 : (C <= 64 ? 64 : 32))) - 6; }
+
+void dwblock_bwd(hipStream_t s, DType dt, const void* dLN, const void* X, const void* dY, const void* Z,
+                 const float* wdw, const float* bdw, const float* mean, const float* rstd, const float* lnw, void* dX,
+                 float* dlnw, float* dlnb, float* dwdw, float* dbdw, float* dgamma, int B, int L, int C,
+                 PartialSink* sink) {
+  const int TL = dw_tile_len(C);
+  const int tiles_per_clip = (L + TL - 1) / TL, total = B * tiles_per_clip;
+  const int nb = total < 256 ? total : 256;
+  int pstride = 0;
+  if (sink) {   // records [nb][lnw C | lnb C | taps 7C | bias C | gamma C]
+    const int rec = 11 * C;
+    size_t o = sink->take((size_t)nb * rec);
+    sink->add(o, nb, rec, C, dlnw);
+    sink->add(o + C, nb, rec, C, dlnb);
+    sink->add(o + 2 * C, nb, rec, 7 * C, dwdw);
+    sink->add(o + 9 * C, nb, rec, C, dbdw);
+    if (dgamma) sink->add(o + 10 * C, nb, rec, C, dgamma);
+    if (sink->dry) return;
+    pstride = rec;
+    dlnw = sink->ws + o; dlnb = dlnw + C; dwdw = dlnw + 2 * C; dbdw = dlnw + 9 * C;
+    if (dgamma) dgamma = dlnw + 10 * C;
+  }
+  ProfScope ps(s, "dwblock_bwd", 42.0 * B * L * C, 5.0 * B * L * C * (dt == DT_F32 ? 4 : 2));
+  if (dt == DT_F32)
+    dwblock_bwd_t<float>(s, dLN, X, dY, Z, wdw, bdw, mean, rstd, lnw, dX, dlnw, dlnb, dwdw, dbdw, dgamma, B, L, C, nb,
+                         tiles_per_clip, total, pstride);
+  else
+    dwblock_bwd_t<bf16>(s, dLN, X, dY, Z, wdw, bdw, mean, rstd, lnw, dX, dlnw, dlnb, dwdw, dbdw, dgamma, B, L, C, nb,
+                        tiles_per_clip, total, pstride);
 }
 
 template <typename T>

@@ -356,8 +356,10 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
       for (int e = 0; e < 4; ++e) {
         int m = m0 + wm * 32 + i * 16 + 4 * g + e;
         if (m < Mst && k < a.Kp) {
-          if (a.part) a.part[(size_t)by * a.part_stride + (size_t)m * a.Kp + k] = acc[i][j][e];
-          else atomicAdd(&a.dW[(size_t)m * a.ldw + k], acc[i][j][e]);
+          float v = acc[i][j][e];
+          if (a.row_scale) v *= a.row_scale[m];
+          if (a.part) a.part[(size_t)by * a.part_stride + (size_t)m * a.Kp + k] = v;
+          else atomicAdd(&a.dW[(size_t)m * a.ldw + k], v);
         }
       }
     }
@@ -373,6 +375,7 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
       for (int q = 0; q < 32; ++q) s += red[q][tid];
       int m = m0 + tid;
       if (m < Mst) {
+        if (a.row_scale) s *= a.row_scale[m];
         if (a.part) a.part[(size_t)by * a.part_stride + (size_t)Mst * a.Kp + m] = s;
         else atomicAdd(&a.dbias[m], s);
       }

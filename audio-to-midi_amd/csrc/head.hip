@@ -184,7 +184,11 @@ __global__ __launch_bounds__(256) void convert_batch_kernel(const float* __restr
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
       int r = r0 + i, c = c0 + tx;
-      if (r < d.rows && c < d.cols) dp[(size_t)r * d.cols + c] = from_f<T>(tile[tx][i]);
+      if (r < d.rows && c < d.cols) {
+        float v = tile[tx][i];
+        if (d.scale_off >= 0) v *= src[d.scale_off + c];
+        dp[(size_t)r * d.cols + c] = from_f<T>(v);
+      }
     }
   }
 }

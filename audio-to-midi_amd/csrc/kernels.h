@@ -49,6 +49,7 @@ struct WgradArgs {
   float* dbias;             // [M] fp32 or nullptr
   int M_store;              // rows of dW / dbias actually written (0 = M); G may be zero-padded past it
   float* part; int part_stride;   // set by the launcher: per-split records instead of atomics
+  const float* row_scale;         // optional [M]: dW[m][:] and dbias[m] are scaled by row_scale[m] (layer scale)
 };
 struct PartialSink;
 void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a, PartialSink* sink = nullptr);
@@ -99,6 +100,13 @@ void dwln_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const floa
 // dX = dRes + conv^T(dD) ; dwdw[k][c] += sum dD[l][c] X[l+k-3][c] ; dbdw[c] += sum dD
 void dwconv_bwd(hipStream_t s, DType dt, const void* dD, const void* X, const float* wdw, const void* dRes,
                 void* dX, float* dwdw, float* dbdw, int B, int L, int C, PartialSink* sink = nullptr);
+// Fused tail of the Block backward (replaces dwln_bwd + dwconv_bwd [+ scale_bwd's dgamma]):
+//   dD = LN'(dLN) w.r.t. the depthwise-conv output (recomputed from X), kept in LDS with a 3-row halo;
+//   dX = dY + conv^T(dD); dlnw, dlnb, dwdw[7][C], dbdw, and dgamma[c] += sum dY * Z (if Z != null).
+void dwblock_bwd(hipStream_t s, DType dt, const void* dLN, const void* X, const void* dY, const void* Z,
+                 const float* wdw, const float* bdw, const float* mean, const float* rstd, const float* lnw,
+                 void* dX, float* dlnw, float* dlnb, float* dwdw, float* dbdw, float* dgamma, int B, int L, int C,
+                 PartialSink* sink = nullptr);
 // dZ = gamma * dY ; dgamma[c] += sum dY * Z
 void scale_bwd(hipStream_t s, DType dt, const void* dY, const void* Z, const float* gamma, void* dZ,
                float* dgamma, int N, int C, PartialSink* sink = nullptr);
@@ -151,7 +159,8 @@ void adamw_compute(hipStream_t s, const float* params, const float* grads, float
 void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, const float* norm2, float clip);
 
 // batched fp32 -> T weight conversion (plain copy or transpose), one launch for the whole model
-struct ConvDesc { uint64_t src_off; uint64_t dst_off; int rows, cols; int src_rows; int transpose; };
+struct ConvDesc { uint64_t src_off; uint64_t dst_off; int rows, cols; int src_rows; int transpose;
+                  long long scale_off; /* >= 0: dst[r][c] *= params[scale_off + c] */ };
 void convert_batch(hipStream_t s, DType dt, const float* src, void* dst, const ConvDesc* descs_dev,
                    const int* tile_prefix_dev, int n_desc, int total_tiles);
 

@@ -34,6 +34,7 @@ struct Seg {
 struct BlockP {  // offsets into the flat fp32 vector
   size_t dw_w, dw_b, ln_w, ln_b, pw1_w, pw1_b, pw2_w, pw2_b, gamma;
   size_t c_pw1, c_pw1t, c_pw2, c_pw2t;  // compute-copy offsets (elements of T)
+  size_t c_pw2tg;                       // pw2^T with its columns scaled by gamma (layer scale folded)
 };
 struct StageP {
   int C, Cin, depth;
@@ -93,8 +94,8 @@ Layout build_layout(const amt_config& c) {
   auto cpair = [&](size_t src, int rows, int cols, size_t& cw, size_t& cwt) {
     cw = cbuf((size_t)rows * cols);
     cwt = cbuf((size_t)rows * cols);
-    L.conv.push_back(ConvDesc{src, cw, rows, cols, rows, 0});
-    L.conv.push_back(ConvDesc{src, cwt, cols, rows, rows, 1});
+    L.conv.push_back(ConvDesc{src, cw, rows, cols, rows, 0, -1});
+    L.conv.push_back(ConvDesc{src, cwt, cols, rows, rows, 1, -1});
   };
   int depth_base = 0;
   for (int s = 0; s < c.n_stages; ++s) {
@@ -133,6 +134,8 @@ Layout build_layout(const amt_config& c) {
       b.gamma = seg(q + "gamma", C, 1, d);
       cpair(b.pw1_w, 2 * C, C, b.c_pw1, b.c_pw1t);
       cpair(b.pw2_w, C, 2 * C, b.c_pw2, b.c_pw2t);
+      b.c_pw2tg = cbuf((size_t)2 * C * C);
+      L.conv.push_back(ConvDesc{b.pw2_w, b.c_pw2tg, 2 * C, C, C, 1, (long long)b.gamma});
       st.blocks.push_back(b);
     }
     depth_base += st.depth;
@@ -175,8 +178,8 @@ Layout build_layout(const amt_config& c) {
   // head: padded to VP rows so that every GEMM has M % 4 == 0 and K % 8 == 0
   L.c_hw = cbuf((size_t)L.VP * H);
   L.c_hwt = cbuf((size_t)L.VP * H);
-  L.conv.push_back(ConvDesc{L.hd_w, L.c_hw, L.VP, H, c.n_events, 0});
-  L.conv.push_back(ConvDesc{L.hd_w, L.c_hwt, H, L.VP, c.n_events, 1});
+  L.conv.push_back(ConvDesc{L.hd_w, L.c_hw, L.VP, H, c.n_events, 0, -1});
+  L.conv.push_back(ConvDesc{L.hd_w, L.c_hwt, H, L.VP, c.n_events, 1, -1});
   L.n_params = off;
   L.n_compute = coff;
   return L;
@@ -489,9 +492,10 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   auto G = [&](size_t off) { return grads + off; };
   std::vector<WgradArgs> pending, pending_skinny;
   auto wgrad = [&](const void* Gm, int ldg, const void* Am, int lda, int n, int M, int Kp, size_t w_off, int ldw,
-                   long b_off, int m_store) {
+                   long b_off, int m_store, const float* row_scale = nullptr) {
     WgradArgs w;
     memset(&w, 0, sizeof(w));
+    w.row_scale = row_scale;
     w.G = Gm; w.ldg = ldg; w.A = Am; w.lda = lda; w.N = n; w.M = M; w.Kp = Kp;
     w.dW = G(w_off); w.ldw = ldw; w.dbias = b_off >= 0 ? G((size_t)b_off) : nullptr; w.M_store = m_store;
     const int tiles = ((M + 63) / 64) * ((Kp + 63) / 64);
@@ -664,12 +668,13 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       const BlockSave& bs = sv.blocks[j];
       begin_scope();
       const void* dy = dcur;
-      void* dz = A.alloc((size_t)Nn * C * es);
-      scale_bwd(s, dt, dy, bs.z, c->P(bp.gamma), dz, G(bp.gamma), Nn, C, &sink);
-      wgrad(dz, C, bs.h, 2 * C, Nn, C, 2 * C, bp.pw2_w, 2 * C, (long)bp.pw2_b, 0);
+      // layer scale folded away: dz = gamma * dy is never materialised.  The data-gradient GEMM uses a
+      // gamma-scaled copy of pw2^T, the pw2 weight/bias gradients are row-scaled in their epilogue
+      // and dgamma = sum dy * z is formed in the fused tail kernel.
+      wgrad(dy, C, bs.h, 2 * C, Nn, C, 2 * C, bp.pw2_w, 2 * C, (long)bp.pw2_b, 0, c->P(bp.gamma));
       void* du = A.alloc((size_t)Nn * 2 * C * es);
       {
-        GemmArgs g = gargs(dz, C, c->WC(bp.c_pw2t), C, Nn, 2 * C, C, nullptr, du, 2 * C);
+        GemmArgs g = gargs(dy, C, c->WC(bp.c_pw2tg), C, Nn, 2 * C, C, nullptr, du, 2 * C);
         g.U = bs.u; g.ldu = 2 * C;
         RUN(gemm_nt(s, dt, EPI_GELU_BWD, g));
       }
@@ -679,12 +684,10 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
         GemmArgs g = gargs(du, 2 * C, c->WC(bp.c_pw1t), 2 * C, Nn, C, 2 * C, nullptr, dln, C);
         RUN(gemm_nt(s, dt, EPI_STORE, g));
       }
-      void* dD = A.alloc((size_t)Nn * C * es);
-      dwln_bwd(s, dt, dln, bs.x, c->P(bp.dw_w), c->P(bp.dw_b), bs.mean, bs.rstd, c->P(bp.ln_w), dD, G(bp.ln_w),
-                   G(bp.ln_b), B, Lcur, C, &sink);
       di = (di + 1) % 3;
       void* dx = dbuf[di];
-      dwconv_bwd(s, dt, dD, bs.x, c->P(bp.dw_w), dy, dx, G(bp.dw_w), G(bp.dw_b), B, Lcur, C, &sink);
+      dwblock_bwd(s, dt, dln, bs.x, dy, bs.z, c->P(bp.dw_w), c->P(bp.dw_b), bs.mean, bs.rstd, c->P(bp.ln_w), dx,
+                  G(bp.ln_w), G(bp.ln_b), G(bp.dw_w), G(bp.dw_b), G(bp.gamma), B, Lcur, C, &sink);
       dcur = dx;
       end_scope();
     }

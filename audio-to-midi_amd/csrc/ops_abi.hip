@@ -86,6 +86,14 @@ int32_t amt_op_dwconv_bwd(int32_t dtype, const void* dD, const void* X, const fl
   dwconv_bwd(st(stream), dtof(dtype), dD, X, wdw, dRes, dX, dwdw, dbdw, B, L, C);
   return done();
 }
+int32_t amt_op_dwblock_bwd(int32_t dtype, const void* dLN, const void* X, const void* dY, const void* Z,
+                           const float* wdw, const float* bdw, const float* mean, const float* rstd, const float* lnw,
+                           void* dX, float* dlnw, float* dlnb, float* dwdw, float* dbdw, float* dgamma, int32_t B,
+                           int32_t L, int32_t C, void* stream) {
+  dwblock_bwd(st(stream), dtof(dtype), dLN, X, dY, Z, wdw, bdw, mean, rstd, lnw, dX, dlnw, dlnb, dwdw, dbdw, dgamma, B, L,
+              C);
+  return done();
+}
 int32_t amt_op_scale_bwd(int32_t dtype, const void* dY, const void* Z, const float* gamma, void* dZ, float* dgamma,
                          int32_t N, int32_t C, void* stream) {
   scale_bwd(st(stream), dtof(dtype), dY, Z, gamma, dZ, dgamma, N, C);

@@ -106,6 +106,7 @@ SIGNATURES = {
     "amt_op_dwln_fwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "amt_op_dwln_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "amt_op_dwconv_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "amt_op_dwblock_bwd": (_i32, [_i32] + [_vp] * 15 + [_i32, _i32, _i32, _vp]),
     "amt_op_scale_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "amt_op_attn_fwd": (_i32, [_i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _u64,
                                _u32, _f32, _vp]),

@@ -43,6 +43,11 @@ int32_t amt_op_dwln_bwd(int32_t dtype, const void* dY, const void* X, const floa
                         int32_t B, int32_t L, int32_t C, void* stream);
 int32_t amt_op_dwconv_bwd(int32_t dtype, const void* dD, const void* X, const float* wdw, const void* dRes, void* dX,
                           float* dwdw, float* dbdw, int32_t B, int32_t L, int32_t C, void* stream);
+/* fused tail of the Block backward: dX = dY + conv^T(LN'(dLN)); dlnw, dlnb, dwdw[7][C], dbdw, dgamma += ... */
+int32_t amt_op_dwblock_bwd(int32_t dtype, const void* dLN, const void* X, const void* dY, const void* Z,
+                           const float* wdw, const float* bdw, const float* mean, const float* rstd, const float* lnw,
+                           void* dX, float* dlnw, float* dlnb, float* dwdw, float* dbdw, float* dgamma, int32_t B,
+                           int32_t L, int32_t C, void* stream);
 int32_t amt_op_scale_bwd(int32_t dtype, const void* dY, const void* Z, const float* gamma, void* dZ, float* dgamma,
                          int32_t N, int32_t C, void* stream);
 /* attention core on raw projections; local != 0 selects the windowed kernel */

@@ -266,6 +266,17 @@ def test_block_conv_pieces(dtype, C, L):
     check(host(dX), dR + xt2.grad.numpy(), dtype, scale=4.0, what="dwconv dX")
     check(host(dwd), w2.grad.numpy()[:, 0, :].T, "float32", scale=sc, what="dwconv dw")
     check(host(dbd), b2.grad.numpy(), "float32", scale=sc, what="dwconv db")
+    # fused tail (dwln_bwd + dwconv_bwd + dgamma in one kernel, dD kept in LDS) against the same references
+    Zt = rounded(rng.standard_normal((B, L, C)), dtype)
+    dX2 = torch.zeros_like(Xd); outs = [torch.zeros(n, device="cuda") for n in (C, C, 7 * C, C, C)]
+    call("amt_op_dwblock_bwd", DT[dtype], P(dev(dY, dtype)), P(Xd), P(dev(dR, dtype)), P(dev(Zt, dtype)), P(wdev),
+         P(f32(bdw)), P(mean), P(rstd), P(f32(lw)), P(dX2), *[P(o) for o in outs], B, L, C, stream())
+    check(host(dX2), dR + xt2.grad.numpy(), dtype, scale=4.0, what="fused dX")
+    check(host(outs[0]), tw[2].grad.numpy(), "float32", scale=sc, what="fused dlnw")
+    check(host(outs[1]), tw[3].grad.numpy(), "float32", scale=sc, what="fused dlnb")
+    check(host(outs[2]).reshape(7, C), w2.grad.numpy()[:, 0, :].T, "float32", scale=sc, what="fused dw")
+    check(host(outs[3]), b2.grad.numpy(), "float32", scale=sc, what="fused db")
+    check(host(outs[4]), (dR * Zt).sum((0, 1)), "float32", scale=sc, what="fused dgamma")
     # layer scale
     Z = rounded(rng.standard_normal((B * L, C)), dtype); g = rng.standard_normal(C).astype(np.float32)
     dZ = torch.zeros((B * L, C), device="cuda", dtype=Xd.dtype); dg = torch.zeros(C, device="cuda")
