@@ -72,6 +72,44 @@ AMT_DEV void stage_row_chunk(T* dst, const T* src, bool valid, const float* cs, 
   store8f(dst, x);
 }
 
+
+// K/V tile staging split in two so that the global loads of tile t+1 are in flight while tile t is
+// being multiplied: kv_load issues this thread's four 16-byte loads (rows past the clip are read
+// from a clamped row), kv_store applies RoPE to K, zeroes invalid rows and writes LDS.
+template <typename T>
+AMT_DEV void kv_load(Chunk8<T> (&kc)[2], Chunk8<T> (&vc)[2], const T* KV, int ldkv, int b, int h, int S, int kt,
+                     int tid) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    int id = tid + 256 * it, row = id >> 3, c = id & 7;
+    int key = kt * 64 + row;
+    int keyc = key < S ? key : S - 1;
+    const T* kp = KV + (size_t)(b * S + keyc) * ldkv + h * 64 + 8 * c;
+    kc[it] = chunk_load(kp);
+    vc[it] = chunk_load(kp + 256);
+  }
+}
+template <typename T>
+AMT_DEV void kv_store(T* Ks, T* Vs, const Chunk8<T> (&kc)[2], const Chunk8<T> (&vc)[2], int S, int kt, int tid,
+                      const float* cs, const float* sn) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    int id = tid + 256 * it, row = id >> 3, c = id & 7;
+    int key = kt * 64 + row;
+    float kx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kx[i] = chunk_get(kc[it], i);
+    if (key < S) {
+      rope8(kx, cs, sn, key, 4 * c, 1.f);
+      store8f(Ks + row * ALD + 8 * c, kx);
+      chunk_store(Vs + row * ALD + 8 * c, vc[it]);
+    } else {
+      chunk_store(Ks + row * ALD + 8 * c, chunk_zero<T>());
+      chunk_store(Vs + row * ALD + 8 * c, chunk_zero<T>());
+    }
+  }
+}
+
 AMT_DEV uint32_t gdrop_idx(int b, int H, int h, int S, int q, int key) {
   return (uint32_t)(((b * H + h) * S + q)) * (uint32_t)S + (uint32_t)key;
 }
@@ -112,17 +150,13 @@ __global__ __launch_bounds__(256) void attn_global_fwd_kernel(AttnArgs a) {
   for (int i = 0; i < 4; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (S + 63) / 64;
+  Chunk8<T> kc[2], vc[2];
+  kv_load<T>(kc, vc, KV, a.ldkv, b, h, S, 0, tid);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      int id = tid + 256 * it, row = id >> 3, c = id & 7;
-      int key = kt * 64 + row;
-      const T* kp = KV + (size_t)(b * S + key) * a.ldkv + h * 64 + 8 * c;
-      stage_row_chunk(Ks + row * ALD + 8 * c, kp, key < S, a.cos, a.sin, key, 4 * c, true, 1.f);
-      stage_row_chunk(Vs + row * ALD + 8 * c, kp + 256, key < S, a.cos, a.sin, key, 4 * c, false, 1.f);
-    }
+    kv_store<T>(Ks, Vs, kc, vc, S, kt, tid, a.cos, a.sin);
     __syncthreads();
+    if (kt + 1 < nkt) kv_load<T>(kc, vc, KV, a.ldkv, b, h, S, kt + 1, tid);
 
     f32x4 sacc[4];
 #pragma unroll
@@ -241,17 +275,13 @@ AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, unsigned c
   for (int i = 0; i < 4; ++i) dqacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (S + 63) / 64;
+  Chunk8<T> kc[2], vc[2];
+  kv_load<T>(kc, vc, KV, a.ldkv, b, h, S, 0, tid);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      int id = tid + 256 * it, row = id >> 3, c = id & 7;
-      int key = kt * 64 + row;
-      const T* kp = KV + (size_t)(b * S + key) * a.ldkv + h * 64 + 8 * c;
-      stage_row_chunk(Ks + row * ALD + 8 * c, kp, key < S, a.cos, a.sin, key, 4 * c, true, 1.f);
-      stage_row_chunk(Vs + row * ALD + 8 * c, kp + 256, key < S, a.cos, a.sin, key, 4 * c, false, 1.f);
-    }
+    kv_store<T>(Ks, Vs, kc, vc, S, kt, tid, a.cos, a.sin);
     __syncthreads();
+    if (kt + 1 < nkt) kv_load<T>(kc, vc, KV, a.ldkv, b, h, S, kt + 1, tid);
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f}, dpacc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -338,37 +368,41 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, unsigned 
   const int nqt = (S + 63) / 64;
   for (int qt = 0; qt < nqt; ++qt) {
     __syncthreads();
+    {
+      float qx[2][8], dch[2][8], och[2][8];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      int id = tid + 256 * it, row = id >> 3, c = id & 7;
-      int q = qt * 64 + row;
-      float x[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] = 0.f;
-      if (q < S) {
-        load8f(QC + (size_t)(b * S + q) * a.ldqc + h * 64 + 8 * c, x);
-        rope8(x, a.cos, a.sin, q, 4 * c, 1.f);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = to_f(from_f<T>(x[i])) * 0.125f;
+      for (int it = 0; it < 2; ++it) {
+        int id = tid + 256 * it, row = id >> 3, c = id & 7;
+        int q = qt * 64 + row;
+        int qc = q < S ? q : S - 1;
+        load8f(QC + (size_t)(b * S + qc) * a.ldqc + h * 64 + 8 * c, qx[it]);
+        load8f(dO + (size_t)(b * S + qc) * ba.lddo + h * 64 + 8 * c, dch[it]);
+        load8f(O + (size_t)(b * S + qc) * a.ldo + h * 64 + 8 * c, och[it]);
       }
-      store8f(Qs + row * ALD + 8 * c, x);
-      // dO chunk to LDS; delta[q] = sum_d dO[q][d] O[q][d] is formed here (8 lanes share a row), so
-      // this role does not depend on the dQ role and both run in one launch
-      float dch[8], och[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { dch[i] = 0.f; och[i] = 0.f; }
-      if (q < S) {
-        load8f(dO + (size_t)(b * S + q) * ba.lddo + h * 64 + 8 * c, dch);
-        load8f(O + (size_t)(b * S + q) * a.ldo + h * 64 + 8 * c, och);
+      for (int it = 0; it < 2; ++it) {
+        int id = tid + 256 * it, row = id >> 3, c = id & 7;
+        int q = qt * 64 + row;
+        if (q < S) {
+          rope8(qx[it], a.cos, a.sin, q, 4 * c, 1.f);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) qx[it][i] = to_f(from_f<T>(qx[it][i])) * 0.125f;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { qx[it][i] = 0.f; dch[it][i] = 0.f; och[it][i] = 0.f; }
+        }
+        store8f(Qs + row * ALD + 8 * c, qx[it]);
+        store8f(dOs + row * ALD + 8 * c, dch[it]);
+        // delta[q] = sum_d dO[q][d] O[q][d] (8 lanes share a row), so this role does not depend on
+        // the dQ role and both run in one launch
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) part += dch[it][i] * och[it][i];
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        if (c == 0) delta_s[row] = part;
       }
-      store8f(dOs + row * ALD + 8 * c, dch);
-      float part = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) part += dch[i] * och[i];
-      part += __shfl_xor(part, 1, 64);
-      part += __shfl_xor(part, 2, 64);
-      part += __shfl_xor(part, 4, 64);
-      if (c == 0) delta_s[row] = part;
     }
     if (tid < 64) {
       int q = qt * 64 + tid;
