@@ -8,6 +8,7 @@
 #include "rowops.h"
 #include "kernels.h"
 #include "prof.h"
+#include <algorithm>
 
 namespace amt {
 
@@ -525,6 +526,176 @@ void dwblock_bwd(hipStream_t s, DType dt, const void* dLN, const void* X, const 
   else
     dwblock_bwd_t<bf16>(s, dLN, X, dY, Z, wdw, bdw, mean, rstd, lnw, dX, dlnw, dlnb, dwdw, dbdw, dgamma, B, L, C, nb,
                         tiles_per_clip, total, pstride);
+}
+
+
+// ------------------------------------------------------------------ whole Block per position, C <= 8
+// Stages 0 and 1 (C = 4, 8; 256 000 / 128 000 positions) have 4..16-wide 1x1 convs: an MFMA GEMM tile
+// is almost all padding there (measured 20-25 us per launch).  One thread owns one position:
+// depthwise conv + LayerNorm + pw1 + GELU + pw2 + layer scale + residual in registers, weights
+// broadcast from LDS.  Every tensor the backward pass needs is written exactly as the unfused
+// path writes it (LN output, u, h = gelu(u), z, y, mean, rstd), with the same roundings.
+template <typename T, int C>
+__global__ __launch_bounds__(256) void block_small_fwd_kernel(
+    const T* __restrict__ X, const float* __restrict__ wdw, const float* __restrict__ bdw,
+    const float* __restrict__ lnw, const float* __restrict__ lnb, const T* __restrict__ w1, const float* __restrict__ b1,
+    const T* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ gamma, T* __restrict__ LN,
+    float* __restrict__ mean, float* __restrict__ rstd, T* __restrict__ U, T* __restrict__ Hh, T* __restrict__ Z,
+    T* __restrict__ Y, int B, int L) {
+  constexpr int H2 = 2 * C;
+  __shared__ float sw1[H2 * C], sw2[C * H2], sb1[H2], sb2[C], sg[C], sdw[7 * C], sbd[C], slw[C], slb[C];
+  for (int t = threadIdx.x; t < H2 * C; t += 256) { sw1[t] = to_f(w1[t]); sw2[t] = to_f(w2[t]); }
+  for (int t = threadIdx.x; t < H2; t += 256) sb1[t] = b1[t];
+  for (int t = threadIdx.x; t < 7 * C; t += 256) sdw[t] = wdw[t];
+  if (threadIdx.x < C) {
+    sb2[threadIdx.x] = b2[threadIdx.x]; sg[threadIdx.x] = gamma[threadIdx.x]; sbd[threadIdx.x] = bdw[threadIdx.x];
+    slw[threadIdx.x] = lnw[threadIdx.x]; slb[threadIdx.x] = lnb[threadIdx.x];
+  }
+  __syncthreads();
+  const long N = (long)B * L;
+  for (long row = (long)blockIdx.x * 256 + threadIdx.x; row < N; row += (long)gridDim.x * 256) {
+    const int b = (int)(row / L), l = (int)(row % L);
+    const long rb = (long)b * L;
+    float x[7][C];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      int ll = l + k - 3;
+      int lc = ll < 0 ? 0 : (ll >= L ? L - 1 : ll);
+      loadvf<C>(X + (rb + lc) * C, x[k]);
+    }
+    float d[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) d[c] = sbd[c];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      int ll = l + k - 3;
+      float m = (ll >= 0 && ll < L) ? 1.f : 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) d[c] += sdw[k * C + c] * (x[k][c] * m);
+    }
+    float mu = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) mu += d[c];
+    mu *= (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { d[c] -= mu; q += d[c] * d[c]; }
+    const float rs = 1.f / sqrtf(q * (1.f / C) + kLnEps);
+    float ln[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) ln[c] = to_f(from_f<T>(d[c] * rs * slw[c] + slb[c]));
+    float u[H2], h[H2];
+#pragma unroll
+    for (int j = 0; j < H2; ++j) {
+      float a = sb1[j];
+#pragma unroll
+      for (int c = 0; c < C; ++c) a += sw1[j * C + c] * ln[c];
+      u[j] = to_f(from_f<T>(a));
+      h[j] = to_f(from_f<T>(gelu_tanh(u[j])));
+    }
+    float z[C], y[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float a = sb2[c];
+#pragma unroll
+      for (int j = 0; j < H2; ++j) a += sw2[c * H2 + j] * h[j];
+      z[c] = to_f(from_f<T>(a));
+      y[c] = x[3][c] + sg[c] * z[c];
+    }
+    storevf<C>(LN + row * C, ln);
+    storevf<C>(Z + row * C, z);
+    storevf<C>(Y + row * C, y);
+    mean[row] = mu;
+    rstd[row] = rs;
+    if constexpr (H2 == 8) {
+      storevf<8>(U + row * H2, u);
+      storevf<8>(Hh + row * H2, h);
+    } else {
+      float t0[8], t1[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { t0[i] = u[i]; t1[i] = u[8 + i]; }
+      storevf<8>(U + row * H2, t0); storevf<8>(U + row * H2 + 8, t1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { t0[i] = h[i]; t1[i] = h[8 + i]; }
+      storevf<8>(Hh + row * H2, t0); storevf<8>(Hh + row * H2 + 8, t1);
+    }
+  }
+}
+
+// data-gradient chain of the two 1x1 convs per position (replaces the GELU' GEMM + the store GEMM):
+//   du = (w2tg . dy) * gelu'(u)   (w2tg = pw2^T with gamma folded in),   dln = w1t . du
+template <typename T, int C>
+__global__ __launch_bounds__(256) void block_small_bwd_kernel(const T* __restrict__ dY, const T* __restrict__ U,
+                                                              const T* __restrict__ w2tg, const T* __restrict__ w1t,
+                                                              T* __restrict__ dU, T* __restrict__ dLN, long N) {
+  constexpr int H2 = 2 * C;
+  __shared__ float s2[H2 * C], s1[C * H2];
+  for (int t = threadIdx.x; t < H2 * C; t += 256) { s2[t] = to_f(w2tg[t]); s1[t] = to_f(w1t[t]); }
+  __syncthreads();
+  for (long row = (long)blockIdx.x * 256 + threadIdx.x; row < N; row += (long)gridDim.x * 256) {
+    float dy[C], u[H2], du[H2];
+    loadvf<C>(dY + row * C, dy);
+    if constexpr (H2 == 8) {
+      loadvf<8>(U + row * H2, u);
+    } else {
+      float t0[8], t1[8];
+      loadvf<8>(U + row * H2, t0); loadvf<8>(U + row * H2 + 8, t1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { u[i] = t0[i]; u[8 + i] = t1[i]; }
+    }
+#pragma unroll
+    for (int j = 0; j < H2; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) a += s2[j * C + c] * dy[c];
+      du[j] = to_f(from_f<T>(a * gelu_tanh_grad(u[j])));
+    }
+    float dl[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < H2; ++j) a += s1[c * H2 + j] * du[j];
+      dl[c] = a;
+    }
+    storevf<C>(dLN + row * C, dl);
+    if constexpr (H2 == 8) {
+      storevf<8>(dU + row * H2, du);
+    } else {
+      float t0[8], t1[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { t0[i] = du[i]; t1[i] = du[8 + i]; }
+      storevf<8>(dU + row * H2, t0); storevf<8>(dU + row * H2 + 8, t1);
+    }
+  }
+}
+
+void block_small_fwd(hipStream_t s, DType dt, const void* X, const float* wdw, const float* bdw, const float* lnw,
+                     const float* lnb, const void* w1, const float* b1, const void* w2, const float* b2,
+                     const float* gamma, void* LN, float* mean, float* rstd, void* U, void* Hh, void* Z, void* Y, int B,
+                     int L, int C) {
+  const long N = (long)B * L;
+  const int grid = (int)std::min<long>((N + 255) / 256, 2048);
+  ProfScope ps(s, "block_small_fwd", 2.0 * N * (7 * C + 4 * C * C), 8.0 * N * C * (dt == DT_F32 ? 4 : 2));
+#define AMT_LAUNCH_SF(TT, CC_)                                                                                         \
+  hipLaunchKernelGGL((block_small_fwd_kernel<TT, CC_>), dim3(grid), dim3(256), 0, s, (const TT*)X, wdw, bdw, lnw, lnb,  \
+                     (const TT*)w1, b1, (const TT*)w2, b2, gamma, (TT*)LN, mean, rstd, (TT*)U, (TT*)Hh, (TT*)Z, (TT*)Y, \
+                     B, L)
+  if (dt == DT_F32) { if (C == 4) AMT_LAUNCH_SF(float, 4); else AMT_LAUNCH_SF(float, 8); }
+  else { if (C == 4) AMT_LAUNCH_SF(bf16, 4); else AMT_LAUNCH_SF(bf16, 8); }
+#undef AMT_LAUNCH_SF
+}
+
+void block_small_bwd(hipStream_t s, DType dt, const void* dY, const void* U, const void* w2tg, const void* w1t, void* dU,
+                     void* dLN, long N, int C) {
+  const int grid = (int)std::min<long>((N + 255) / 256, 2048);
+  ProfScope ps(s, "block_small_bwd", 8.0 * N * C * C, 6.0 * N * C * (dt == DT_F32 ? 4 : 2));
+#define AMT_LAUNCH_SB(TT, CC_)                                                                                       \
+  hipLaunchKernelGGL((block_small_bwd_kernel<TT, CC_>), dim3(grid), dim3(256), 0, s, (const TT*)dY, (const TT*)U,     \
+                     (const TT*)w2tg, (const TT*)w1t, (TT*)dU, (TT*)dLN, N)
+  if (dt == DT_F32) { if (C == 4) AMT_LAUNCH_SB(float, 4); else AMT_LAUNCH_SB(float, 8); }
+  else { if (C == 4) AMT_LAUNCH_SB(bf16, 4); else AMT_LAUNCH_SB(bf16, 8); }
+#undef AMT_LAUNCH_SB
 }
 
 template <typename T>

@@ -100,6 +100,15 @@ void dwln_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const floa
 // dX = dRes + conv^T(dD) ; dwdw[k][c] += sum dD[l][c] X[l+k-3][c] ; dbdw[c] += sum dD
 void dwconv_bwd(hipStream_t s, DType dt, const void* dD, const void* X, const float* wdw, const void* dRes,
                 void* dX, float* dwdw, float* dbdw, int B, int L, int C, PartialSink* sink = nullptr);
+// Whole Block forward per position for C in {4, 8} (dwconv + LN + pw1 + GELU + pw2 + gamma + residual);
+// w1 [2C][C], w2 [C][2C] are the T compute copies.  Writes LN, mean, rstd, U, H = gelu(U), Z, Y.
+void block_small_fwd(hipStream_t s, DType dt, const void* X, const float* wdw, const float* bdw, const float* lnw,
+                     const float* lnb, const void* w1, const float* b1, const void* w2, const float* b2,
+                     const float* gamma, void* LN, float* mean, float* rstd, void* U, void* Hh, void* Z, void* Y, int B,
+                     int L, int C);
+// dU = (w2tg . dY) * gelu'(U), dLN = w1t . dU per position (C in {4, 8}); w2tg [2C][C], w1t [C][2C] (T)
+void block_small_bwd(hipStream_t s, DType dt, const void* dY, const void* U, const void* w2tg, const void* w1t, void* dU,
+                     void* dLN, long N, int C);
 // Fused tail of the Block backward (replaces dwln_bwd + dwconv_bwd [+ scale_bwd's dgamma]):
 //   dD = LN'(dLN) w.r.t. the depthwise-conv output (recomputed from X), kept in LDS with a 3-row halo;
 //   dX = dY + conv^T(dD); dlnw, dlnb, dwdw[7][C], dbdw, and dgamma[c] += sum dY * Z (if Z != null).

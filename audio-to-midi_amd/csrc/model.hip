@@ -384,6 +384,14 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
       bs.u = A.alloc((size_t)N * 2 * C * es);
       bs.h = A.alloc((size_t)N * 2 * C * es);
       bs.z = A.alloc((size_t)N * C * es);
+      if (C <= 8) {   // per-position kernel: the 1x1 convs are too narrow for an MFMA tile
+        void* y = out_buf((size_t)N * C);
+        RUN(block_small_fwd(s, dt, cur, c->P(bp.dw_w), c->P(bp.dw_b), c->P(bp.ln_w), c->P(bp.ln_b), c->WC(bp.c_pw1),
+                            c->P(bp.pw1_b), c->WC(bp.c_pw2), c->P(bp.pw2_b), c->P(bp.gamma), bs.ln, bs.mean, bs.rstd,
+                            bs.u, bs.h, bs.z, y, B, Lcur, C));
+        cur = y;
+        continue;
+      }
       RUN(dwln_fwd(s, dt, cur, c->P(bp.dw_w), c->P(bp.dw_b), c->P(bp.ln_w), c->P(bp.ln_b), bs.ln, bs.mean, bs.rstd, B,
                    Lcur, C));
       GemmArgs g1 = gargs(bs.ln, C, c->WC(bp.c_pw1), C, N, 2 * C, C, c->P(bp.pw1_b), bs.u, 2 * C);
@@ -673,17 +681,17 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       // and dgamma = sum dy * z is formed in the fused tail kernel.
       wgrad(dy, C, bs.h, 2 * C, Nn, C, 2 * C, bp.pw2_w, 2 * C, (long)bp.pw2_b, 0, c->P(bp.gamma));
       void* du = A.alloc((size_t)Nn * 2 * C * es);
-      {
+      void* dln = A.alloc((size_t)Nn * C * es);
+      if (C <= 8) {
+        RUN(block_small_bwd(s, dt, dy, bs.u, c->WC(bp.c_pw2tg), c->WC(bp.c_pw1t), du, dln, (long)Nn, C));
+      } else {
         GemmArgs g = gargs(dy, C, c->WC(bp.c_pw2tg), C, Nn, 2 * C, C, nullptr, du, 2 * C);
         g.U = bs.u; g.ldu = 2 * C;
         RUN(gemm_nt(s, dt, EPI_GELU_BWD, g));
+        GemmArgs g2 = gargs(du, 2 * C, c->WC(bp.c_pw1t), 2 * C, Nn, C, 2 * C, nullptr, dln, C);
+        RUN(gemm_nt(s, dt, EPI_STORE, g2));
       }
       wgrad(du, 2 * C, bs.ln, C, Nn, 2 * C, C, bp.pw1_w, C, (long)bp.pw1_b, 0);
-      void* dln = A.alloc((size_t)Nn * C * es);
-      {
-        GemmArgs g = gargs(du, 2 * C, c->WC(bp.c_pw1t), 2 * C, Nn, C, 2 * C, nullptr, dln, C);
-        RUN(gemm_nt(s, dt, EPI_STORE, g));
-      }
       di = (di + 1) % 3;
       void* dx = dbuf[di];
       dwblock_bwd(s, dt, dln, bs.x, dy, bs.z, c->P(bp.dw_w), c->P(bp.dw_b), bs.mean, bs.rstd, c->P(bp.ln_w), dx,
