@@ -107,19 +107,21 @@ AMT_DEV void epi_glu(const GemmArgs& a, int n, int m, float (&u1)[4], float (&u2
 // ------------------------------------------------------------------ gemm_nt kernel
 // workgroup: 256 threads = 4 waves arranged 2 (token halves) x 2 (feature halves);
 // tile BT tokens x 64 features; per wave (BT/2) x 32 = TI x 2 MFMA 16x16 sub-tiles.
-template <typename T, int EPI, int BT>
+template <typename T, int EPI, int BT, int BK>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   constexpr int TI = BT / 32;
   constexpr int FI = 2;
-  // K panel per LDS stage: 64 deep for bf16 (two MFMA k-steps per barrier, 4+ loads in flight per
-  // thread), 32 for the f32 verification build (keeps static LDS under 64 KB)
-  constexpr int BK = sizeof(T) == 2 ? 64 : 32;
+  // BK = K panel per LDS stage, chosen by the launcher as the smallest of {64, 128, 256} (bf16) that
+  // covers K: every load of a panel is issued up front (up to 16 sixteen-byte loads in flight per
+  // thread), so K <= 256 costs ONE memory round trip instead of one per 64 columns.  One LDS
+  // buffer; for K > BK the next panel is prefetched into registers while this one is multiplied.
   constexpr int LDK = BK + 8;
   constexpr int CPR = BK / 8;                // 8-element chunks per tile row
   constexpr int XCH = BT * CPR / 256;        // X chunks per thread per stage
   constexpr int WCH = GBF * CPR / 256;       // W chunks per thread per stage
-  __shared__ __attribute__((aligned(16))) T Xs[2][BT][LDK];
-  __shared__ __attribute__((aligned(16))) T Ws[2][GBF][LDK];
+  extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+  T (*Xs)[LDK] = reinterpret_cast<T (*)[LDK]>(gemm_smem);
+  T (*Ws)[LDK] = reinterpret_cast<T (*)[LDK]>(gemm_smem + sizeof(T) * BT * LDK);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -150,41 +152,38 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
       wr[i] = (m < a.M) ? load_k_chunk(W + (size_t)m * a.ldw, k0 + 8 * c, K) : chunk_zero<T>();
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&]() {
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
       int id = tid + i * 256, row = id / CPR, c = id % CPR;
-      chunk_store(&Xs[buf][row][8 * c], xr[i]);
+      chunk_store(&Xs[row][8 * c], xr[i]);
     }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
       int id = tid + i * 256, row = id / CPR, c = id % CPR;
-      chunk_store(&Ws[buf][row][8 * c], wr[i]);
+      chunk_store(&Ws[row][8 * c], wr[i]);
     }
   };
 
   const int nk = (K + BK - 1) / BK;
   load_tiles(0);
-  store_tiles(0);
-  __syncthreads();
-  int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
+    if (kt > 0) __syncthreads();   // previous panel fully consumed
+    store_tiles();
+    __syncthreads();
     if (kt + 1 < nk) load_tiles((kt + 1) * BK);
-#pragma unroll
-    for (int kk = 0; kk < BK / 32; ++kk) {
+    const int kk_end = min(BK, K - kt * BK);
+    for (int kk = 0; kk < kk_end; kk += 32) {
       Frag<T> wfr[FI], xfr[TI];
 #pragma unroll
-      for (int fi = 0; fi < FI; ++fi) wfr[fi] = frag_row(&Ws[cur][wf * 32 + fi * 16 + r][32 * kk + 8 * g]);
+      for (int fi = 0; fi < FI; ++fi) wfr[fi] = frag_row(&Ws[wf * 32 + fi * 16 + r][kk + 8 * g]);
 #pragma unroll
-      for (int ti = 0; ti < TI; ++ti) xfr[ti] = frag_row(&Xs[cur][wt * (BT / 2) + ti * 16 + r][32 * kk + 8 * g]);
+      for (int ti = 0; ti < TI; ++ti) xfr[ti] = frag_row(&Xs[wt * (BT / 2) + ti * 16 + r][kk + 8 * g]);
 #pragma unroll
       for (int fi = 0; fi < FI; ++fi)
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti) mma(acc[fi][ti], wfr[fi], xfr[ti]);
     }
-    if (kt + 1 < nk) store_tiles(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
   }
 
   // epilogue: acc[fi][ti][i] = Y[n0 + wt*BT/2 + ti*16 + r][m0 + wf*32 + fi*16 + 4g + i]
@@ -215,25 +214,39 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   }
 }
 
+template <typename T, int EPI, int BT, int BK>
+static void launch_nt_cfg(hipStream_t s, const GemmArgs& a, const char* name, double fl, double by) {
+  constexpr size_t lds = sizeof(T) * (size_t)(BT + GBF) * (BK + 8);
+  static bool once = (lds > 64 * 1024
+                          ? (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, EPI, BT, BK>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                          : (void)0,
+                      true);
+  (void)once;
+  ProfScope ps(s, name, fl, by);
+  dim3 grid((a.N + BT - 1) / BT, (a.M + GBF - 1) / GBF);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, BT, BK>), grid, dim3(256), lds, s, a);
+}
+
 template <typename T, int EPI>
 static void launch_nt(hipStream_t s, const GemmArgs& a) {
   static const char* const epi_names[EPI_COUNT] = {"store", "store_f32", "resid", "gelu", "scale_resid", "glu",
                                                    "glu_bwd", "gelu_bwd"};
-  const size_t es = sizeof(T);
+  constexpr size_t es = sizeof(T);
+  constexpr int B0 = es == 2 ? 64 : 32;     // panel sizes: {64,128,256} for bf16, {32,64,128} for f32
   const double fl = 2.0 * a.N * (double)a.M * a.K;
   const double by = ((double)a.N * a.K + (double)a.M * a.K + (double)a.N * a.M) * es;
   // 128-token tiles when that still yields >= 2 workgroups per CU, else 64-token tiles
   long tiles128 = (long)((a.N + 127) / 128) * ((a.M + GBF - 1) / GBF);
+  static const std::string nm128 = std::string("gemm_nt<") + (es == 4 ? "f32," : "bf16,") + epi_names[EPI] + ",128>";
+  static const std::string nm64 = std::string("gemm_nt<") + (es == 4 ? "f32," : "bf16,") + epi_names[EPI] + ",64>";
   if (tiles128 >= 512) {
-    static const std::string nm = std::string("gemm_nt<") + (es == 4 ? "f32," : "bf16,") + epi_names[EPI] + ",128>";
-    ProfScope ps(s, nm.c_str(), fl, by);
-    dim3 grid((a.N + 127) / 128, (a.M + GBF - 1) / GBF);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, 128>), grid, dim3(256), 0, s, a);
+    if (a.K <= B0) launch_nt_cfg<T, EPI, 128, B0>(s, a, nm128.c_str(), fl, by);
+    else launch_nt_cfg<T, EPI, 128, 2 * B0>(s, a, nm128.c_str(), fl, by);
   } else {
-    static const std::string nm = std::string("gemm_nt<") + (es == 4 ? "f32," : "bf16,") + epi_names[EPI] + ",64>";
-    ProfScope ps(s, nm.c_str(), fl, by);
-    dim3 grid((a.N + 63) / 64, (a.M + GBF - 1) / GBF);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, 64>), grid, dim3(256), 0, s, a);
+    if (a.K <= B0) launch_nt_cfg<T, EPI, 64, B0>(s, a, nm64.c_str(), fl, by);
+    else if (a.K <= 2 * B0) launch_nt_cfg<T, EPI, 64, 2 * B0>(s, a, nm64.c_str(), fl, by);
+    else launch_nt_cfg<T, EPI, 64, 4 * B0>(s, a, nm64.c_str(), fl, by);
   }
 }
 
