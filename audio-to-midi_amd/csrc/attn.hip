@@ -175,8 +175,7 @@ __global__ __launch_bounds__(256) void attn_global_fwd_kernel(AttnArgs a) {
         if (key >= S) sacc[st][e] = -1e30f;
         mx = fmaxf(mx, sacc[st][e]);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = max_xor32(max_xor16(mx));
     float m_new = fmaxf(m_run, mx);
     float alpha = __expf(m_run - m_new);
     float psum = 0.f;
@@ -196,8 +195,7 @@ __global__ __launch_bounds__(256) void attn_global_fwd_kernel(AttnArgs a) {
       }
       store4f(Pw + r * ALD + 16 * st + 4 * g, pv);
     }
-    psum += __shfl_xor(psum, 16, 64);
-    psum += __shfl_xor(psum, 32, 64);
+    psum = sum_xor32(sum_xor16(psum));
     l_run = l_run * alpha + psum;
     m_run = m_new;
 #pragma unroll
@@ -262,8 +260,7 @@ AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, unsigned c
     qf[ks] = make_frag<T>(x);
     dof[ks] = make_frag<T>(d);
   }
-  dl += __shfl_xor(dl, 16, 64);
-  dl += __shfl_xor(dl, 32, 64);
+  dl = sum_xor32(sum_xor16(dl));
   float lse = 0.f;
   if (qrow < S) {
     lse = a.LSE[(size_t)(b * a.H + h) * S + qrow];
@@ -398,9 +395,7 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, unsigned 
         float part = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) part += dch[it][i] * och[it][i];
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
-        part += __shfl_xor(part, 4, 64);
+        part = group_sum<8>(part);
         if (c == 0) delta_s[row] = part;
       }
     }
@@ -588,13 +583,11 @@ __global__ __launch_bounds__(64) void attn_local_fwd_kernel(AttnArgs a, int padL
       for (int kk = 0; kk < 4; ++kk) sc[kk] += qv * kw[4 * kg + kk][d];
     }
     float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    mx = group_max<4>(mx);
     float sum = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) { sc[kk] = __expf(sc[kk] - mx); sum += sc[kk]; }
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
+    sum = group_sum<4>(sum);
     float inv = 1.f / sum;
     const int win = s - 1 + w, iw = w ? i : 8 + i;
 #pragma unroll
@@ -690,11 +683,11 @@ __global__ __launch_bounds__(64) void attn_local_bwd_kernel(AttnBwdArgs ba, int 
     float mx = sc[0];
 #pragma unroll
     for (int kk = 1; kk < 8; ++kk) mx = fmaxf(mx, sc[kk]);
-    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = group_max<2>(mx);
     float sum = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) { sc[kk] = __expf(sc[kk] - mx); sum += sc[kk]; }
-    sum += __shfl_xor(sum, 1, 64);
+    sum = group_sum<2>(sum);
     float inv = 1.f / sum;
     const int win = s - 1 + w;
     float dl = 0.f, pdv[8];
@@ -712,7 +705,7 @@ __global__ __launch_bounds__(64) void attn_local_bwd_kernel(AttnBwdArgs ba, int 
       pdv[kk] = pd;
       dl += p * dpm;
     }
-    dl += __shfl_xor(dl, 1, 64);
+    dl = group_sum<2>(dl);
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       Pd[w][i][8 * hf + kk] = pdv[kk];
@@ -738,7 +731,7 @@ __global__ __launch_bounds__(64) void attn_local_bwd_kernel(AttnBwdArgs ba, int 
       }
       // transpose of the rotation: partner feature sits in the neighbouring lane
       auto unrope = [&](float v, int pos) {
-        float o = __shfl_xor(v, 1, 64);
+        float o = dpp_mov<DPP_XOR1>(v);
         float c = a.cos[pos * 32 + (d >> 1)], sn = a.sin[pos * 32 + (d >> 1)];
         return (d & 1) ? (-o * sn + v * c) : (v * c + o * sn);
       };

@@ -391,66 +391,72 @@ __global__ __launch_bounds__(256) void dwblock_bwd_kernel(
     const int b = t / tiles_per_clip, l0 = (t % tiles_per_clip) * TL;
     const long rb = (long)b * L;
     __syncthreads();   // previous tile's phase 2 done with dDs
-    // ---- phase 1: dD for rows l0-3 .. l0+TL+2 into LDS
-    for (int p = wave * RPW + rw; p < ROWS; p += RPB) {
+    // ---- phase 1: dD for rows l0-3 .. l0+TL+2 into LDS.  Loads are unconditional (clamped rows,
+    // masked results) and the pass loop is fully unrolled so that the loads of all passes overlap.
+#pragma unroll
+    for (int pp = 0; pp < ROWS / RPB; ++pp) {
+      const int p = pp * RPB + wave * RPW + rw;
       const int l = l0 - 3 + p;
-      float o[VEC];
+      const bool valid = (l >= 0) && (l < L);
+      const int lcl = l < 0 ? 0 : (l >= L ? L - 1 : l);
+      float d[VEC], dl[VEC], o[VEC];
+      dwconv_row<T, VEC>(X, rb, lcl, L, C, sub, wk, bv, d);
+      loadvf<VEC>(dLN + (rb + lcl) * C + sub * VEC, dl);
+      const float mu = mean[rb + lcl], rs = rstd[rb + lcl];
+      const float fin = (valid && p >= 3 && p < TL + 3) ? 1.f : 0.f;
+      float s1 = 0.f, s2 = 0.f, gy[VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) o[i] = 0.f;
-      if (l >= 0 && l < L) {
-        float d[VEC], dl[VEC];
-        dwconv_row<T, VEC>(X, rb, l, L, C, sub, wk, bv, d);
-        loadvf<VEC>(dLN + (rb + l) * C + sub * VEC, dl);
-        const float mu = mean[rb + l], rs = rstd[rb + l];
-        const bool interior = (p >= 3) && (p < TL + 3);
-        float s1 = 0.f, s2 = 0.f, gy[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-          d[i] = (d[i] - mu) * rs;
-          gy[i] = dl[i] * wv[i];
-          s1 += gy[i];
-          s2 += gy[i] * d[i];
-          if (interior) { alw[i] += dl[i] * d[i]; alb[i] += dl[i]; }
-        }
-        s1 = group_sum<LPR>(s1) * (1.f / C);
-        s2 = group_sum<LPR>(s2) * (1.f / C);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) o[i] = rs * (gy[i] - s1 - d[i] * s2);
+      for (int i = 0; i < VEC; ++i) {
+        d[i] = (d[i] - mu) * rs;
+        gy[i] = dl[i] * wv[i];
+        s1 += gy[i];
+        s2 += gy[i] * d[i];
+        alw[i] += fin * dl[i] * d[i];
+        alb[i] += fin * dl[i];
       }
+      s1 = group_sum<LPR>(s1) * (1.f / C);
+      s2 = group_sum<LPR>(s2) * (1.f / C);
+      const float fv = valid ? 1.f : 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o[i] = fv * rs * (gy[i] - s1 - d[i] * s2);
       storevf<VEC>(&dDs[p][sub * VEC], o);
     }
     __syncthreads();
     // ---- phase 2: dX = dY + conv^T(dD), depthwise weight / bias / gamma gradients
-    for (int i0 = wave * RPW + rw; i0 < TL; i0 += RPB) {
+#pragma unroll
+    for (int pp = 0; pp < (TL + RPB - 1) / RPB; ++pp) {
+      const int i0 = pp * RPB + wave * RPW + rw;
       const int l = l0 + i0;
-      if (l < L) {
-        float o[VEC], dd[VEC], dy[VEC];
-        loadvf<VEC>(dY + (rb + l) * C + sub * VEC, dy);
-        loadvf<VEC>(&dDs[i0 + 3][sub * VEC], dd);   // value as stored (rounded to T), like the unfused path
+      const bool valid = (i0 < TL) && (l < L);
+      const int i0c = i0 < TL ? i0 : TL - 1;
+      const int lcl = l < L ? l : L - 1;
+      const float fv = valid ? 1.f : 0.f;
+      float o[VEC], dd[VEC], dy[VEC];
+      loadvf<VEC>(dY + (rb + lcl) * C + sub * VEC, dy);
+      loadvf<VEC>(&dDs[i0c + 3][sub * VEC], dd);   // value as stored (rounded to T), like the unfused path
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) { o[i] = dy[i]; ab[i] += dd[i]; }
-        if (Z != nullptr) {
-          float z[VEC];
-          loadvf<VEC>(Z + (rb + l) * C + sub * VEC, z);
+      for (int i = 0; i < VEC; ++i) { o[i] = dy[i]; dd[i] *= fv; ab[i] += dd[i]; }
+      if (Z != nullptr) {
+        float z[VEC];
+        loadvf<VEC>(Z + (rb + lcl) * C + sub * VEC, z);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) ag[i] += dy[i] * z[i];
-        }
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-          float tq[VEC];
-          loadvf<VEC>(&dDs[i0 + 6 - k][sub * VEC], tq);   // dD[l - k + 3] (zero outside the clip)
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) o[i] += wk[k][i] * tq[i];
-          const int lx = l + k - 3;
-          const int lxc = lx < 0 ? 0 : (lx >= L ? L - 1 : lx);
-          const float mx = (lx >= 0 && lx < L) ? 1.f : 0.f;
-          float x[VEC];
-          loadvf<VEC>(X + (rb + lxc) * C + sub * VEC, x);
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) aw[k][i] += dd[i] * (x[i] * mx);
-        }
-        storevf<VEC>(dX + (rb + l) * C + sub * VEC, o);
+        for (int i = 0; i < VEC; ++i) ag[i] += fv * dy[i] * z[i];
       }
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        float tq[VEC];
+        loadvf<VEC>(&dDs[i0c + 6 - k][sub * VEC], tq);   // dD[l - k + 3] (zero outside the clip)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] += wk[k][i] * tq[i];
+        const int lx = lcl + k - 3;
+        const int lxc = lx < 0 ? 0 : (lx >= L ? L - 1 : lx);
+        const float mx = (lx >= 0 && lx < L) ? 1.f : 0.f;
+        float x[VEC];
+        loadvf<VEC>(X + (rb + lxc) * C + sub * VEC, x);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) aw[k][i] += dd[i] * (x[i] * mx);
+      }
+      if (valid) storevf<VEC>(dX + (rb + l) * C + sub * VEC, o);
     }
   }
   // all eleven column sums through LDS with three barriers in total
@@ -460,9 +466,7 @@ __global__ __launch_bounds__(256) void dwblock_bwd_kernel(
   auto fold = [&](const float (&acc)[VEC], int slot) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      float v = acc[i];
-#pragma unroll
-      for (int o = LPR; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      float v = strided_sum<LPR>(acc[i]);
       if (rw == 0) atomicAdd(&smem[slot * C + sub * VEC + i], v);
     }
   };

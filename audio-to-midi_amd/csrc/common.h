@@ -189,15 +189,67 @@ AMT_DEV float gelu_tanh_grad(float x) {
 }
 AMT_DEV float sigmoidf(float z) { return 1.f / (1.f + __expf(-z)); }
 
-// wave-level all-lanes sum over groups of `width` consecutive lanes (width power of two <= 64)
+// ------------------------------------------------------------------ cross-lane reductions
+// __shfl_xor lowers to ds_bpermute_b32 (an LDS-crossbar round trip, ~100+ cycles, serialised by
+// its wait): 176-264 of them made the reduction tail of the backward row kernels cost ~12 us.
+// These use DPP (one VALU instruction, fused into v_add_f32_dpp) inside a 16-lane row and the
+// gfx950 v_permlane16_swap / v_permlane32_swap across rows.
+template <int CTRL> AMT_DEV float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7 - i inside each group of 8
+constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15 - i inside each row of 16
+constexpr int DPP_ROR4 = 0x124;        // rotate right by 4 inside each row of 16
+constexpr int DPP_ROR8 = 0x128;
+// value of lane (l ^ 16) / (l ^ 32) paired with the own value: both halves of the swap result
+// Inline asm on purpose: with both operands holding the same value, hipcc (ROCm 7.2) folded the two
+// results of __builtin_amdgcn_permlane{16,32}_swap into one register (a + a instead of a + b).
+// Two read-write operands cannot share a register.  s_nop 1 covers the VALU-write -> permlane
+// read hazard (cdna_hip_programming.md T21).
+AMT_DEV void xrow16(float v, float& a, float& b) {
+  float x = v, y = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(x), "+v"(y));
+  a = x; b = y;
+}
+AMT_DEV void xrow32(float v, float& a, float& b) {
+  float x = v, y = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(x), "+v"(y));
+  a = x; b = y;
+}
+AMT_DEV float sum_xor16(float v) { float a, b; xrow16(v, a, b); return a + b; }
+AMT_DEV float sum_xor32(float v) { float a, b; xrow32(v, a, b); return a + b; }
+AMT_DEV float max_xor16(float v) { float a, b; xrow16(v, a, b); return fmaxf(a, b); }
+AMT_DEV float max_xor32(float v) { float a, b; xrow32(v, a, b); return fmaxf(a, b); }
+
+// all-reduce over groups of WIDTH consecutive lanes (WIDTH power of two <= 64)
 template <int WIDTH> AMT_DEV float group_sum(float v) {
-#pragma unroll
-  for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if constexpr (WIDTH >= 2) v += dpp_mov<DPP_XOR1>(v);
+  if constexpr (WIDTH >= 4) v += dpp_mov<DPP_XOR2>(v);
+  if constexpr (WIDTH >= 8) v += dpp_mov<DPP_HALF_MIRROR>(v);
+  if constexpr (WIDTH >= 16) v += dpp_mov<DPP_MIRROR>(v);
+  if constexpr (WIDTH >= 32) v = sum_xor16(v);
+  if constexpr (WIDTH >= 64) v = sum_xor32(v);
   return v;
 }
 template <int WIDTH> AMT_DEV float group_max(float v) {
-#pragma unroll
-  for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if constexpr (WIDTH >= 2) v = fmaxf(v, dpp_mov<DPP_XOR1>(v));
+  if constexpr (WIDTH >= 4) v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
+  if constexpr (WIDTH >= 8) v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v));
+  if constexpr (WIDTH >= 16) v = fmaxf(v, dpp_mov<DPP_MIRROR>(v));
+  if constexpr (WIDTH >= 32) v = max_xor16(v);
+  if constexpr (WIDTH >= 64) v = max_xor32(v);
+  return v;
+}
+// all-reduce over the lanes that share (lane % STRIDE) (STRIDE power of two <= 32)
+template <int STRIDE> AMT_DEV float strided_sum(float v) {
+  if constexpr (STRIDE <= 1) v += dpp_mov<DPP_XOR1>(v);
+  if constexpr (STRIDE <= 2) v += dpp_mov<DPP_XOR2>(v);
+  if constexpr (STRIDE <= 4) v += dpp_mov<DPP_ROR4>(v);
+  if constexpr (STRIDE <= 8) v += dpp_mov<DPP_ROR8>(v);
+  if constexpr (STRIDE <= 16) v = sum_xor16(v);
+  if constexpr (STRIDE <= 32) v = sum_xor32(v);
   return v;
 }
 

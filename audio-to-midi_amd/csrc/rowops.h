@@ -30,9 +30,7 @@ AMT_DEV void reduce_cols_to_global(const float (&acc)[VEC], float* gdst, float* 
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    float v = acc[i];
-#pragma unroll
-    for (int o = LPR; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    float v = strided_sum<LPR>(acc[i]);
     if (rw == 0) atomicAdd(&smem[sub * VEC + i], v);
   }
   __syncthreads();
