@@ -524,13 +524,21 @@ AMT_DEV uint32_t ldrop_idx(int b, int H, int h, int nW, int win, int iw, int j) 
   return (uint32_t)((((b * H + h) * nW + win) * 16 + iw) * 16 + j);
 }
 
-// load one 8-feature chunk of token (padded position p) or zeros
+// load one 8-feature chunk of the token at padded position p.  The load is unconditional (clamped
+// token) so that a thread's loads can all be in flight together; `mask8` zeroes pad tokens later.
 template <typename T>
-AMT_DEV void load_tok_chunk(const T* base, int ld, int b, int S, int p, int padL, int off, float (&x)[8]) {
+AMT_DEV bool load_tok_chunk(const T* base, int ld, int b, int S, int p, int padL, int off, float (&x)[8]) {
   int t = p - padL;
+  bool ok = (t >= 0) && (t < S);
+  int tc = t < 0 ? 0 : (t >= S ? S - 1 : t);
+  load8f(base + (size_t)(b * S + tc) * ld + off, x);
+  return ok;
+}
+AMT_DEV void mask8(float (&x)[8], bool ok) {
+  if (!ok) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) x[i] = 0.f;
-  if (t >= 0 && t < S) load8f(base + (size_t)(b * S + t) * ld + off, x);
+    for (int i = 0; i < 8; ++i) x[i] = 0.f;
+  }
 }
 
 template <typename T>
@@ -553,23 +561,31 @@ __global__ __launch_bounds__(64) void attn_local_fwd_kernel(AttnArgs a, int padL
   const T* QC = reinterpret_cast<const T*>(a.QC);
   const T* KV = reinterpret_cast<const T*>(a.KV);
   {
-    int i = lane >> 3, c = lane & 7;
-    float x[8];
-    load_tok_chunk(QC, a.ldqc, b, S, 8 * s + i, padL, h * 64 + 8 * c, x);
-    store_roped<T>(qA, i, c, x, a.cos, a.sin, 8 + i, 0.125f);
-    store_roped<T>(qB, i, c, x, a.cos, a.sin, i, 0.125f);
-  }
+    // issue all seven loads of this lane, then rotate / store
+    float qx[8], kx[3][8], vx[3][8];
+    bool okq, okk[3];
+    const int qi = lane >> 3, qc = lane & 7;
+    okq = load_tok_chunk(QC, a.ldqc, b, S, 8 * s + qi, padL, h * 64 + 8 * qc, qx);
 #pragma unroll
-  for (int it = 0; it < 3; ++it) {
-    int id = lane + 64 * it, jp = id >> 3, c = id & 7;
-    int p = 8 * s - 8 + jp;
-    float x[8];
-    load_tok_chunk(KV, a.ldkv, b, S, p, padL, h * 64 + 8 * c, x);
-    if (jp < 16) store_roped<T>(kA, jp, c, x, a.cos, a.sin, jp, 1.f);
-    if (jp >= 8) store_roped<T>(kB, jp - 8, c, x, a.cos, a.sin, jp - 8, 1.f);
-    load_tok_chunk(KV, a.ldkv, b, S, p, padL, 256 + h * 64 + 8 * c, x);
+    for (int it = 0; it < 3; ++it) {
+      int id = lane + 64 * it, jp = id >> 3, c = id & 7;
+      int p = 8 * s - 8 + jp;
+      okk[it] = load_tok_chunk(KV, a.ldkv, b, S, p, padL, h * 64 + 8 * c, kx[it]);
+      load_tok_chunk(KV, a.ldkv, b, S, p, padL, 256 + h * 64 + 8 * c, vx[it]);
+    }
+    mask8(qx, okq);
+    store_roped<T>(qA, qi, qc, qx, a.cos, a.sin, 8 + qi, 0.125f);
+    store_roped<T>(qB, qi, qc, qx, a.cos, a.sin, qi, 0.125f);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) vs[jp][8 * c + i] = x[i];
+    for (int it = 0; it < 3; ++it) {
+      int id = lane + 64 * it, jp = id >> 3, c = id & 7;
+      mask8(kx[it], okk[it]);
+      mask8(vx[it], okk[it]);
+      if (jp < 16) store_roped<T>(kA, jp, c, kx[it], a.cos, a.sin, jp, 1.f);
+      if (jp >= 8) store_roped<T>(kB, jp - 8, c, kx[it], a.cos, a.sin, jp - 8, 1.f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) vs[jp][8 * c + i] = vx[it][i];
+    }
   }
   __syncthreads();
   {
@@ -638,31 +654,40 @@ __global__ __launch_bounds__(64) void attn_local_bwd_kernel(AttnBwdArgs ba, int 
   const T* QC = reinterpret_cast<const T*>(a.QC);
   const T* KV = reinterpret_cast<const T*>(a.KV);
   const T* dO = reinterpret_cast<const T*>(ba.dO);
+  {
+    // issue all twelve loads of this lane, then rotate / store
+    float qx[3][8], kx[3][8], vx[3][8], dx[3][8];
+    bool okt[3];
 #pragma unroll
-  for (int it = 0; it < 3; ++it) {
-    int id = lane + 64 * it, jp = id >> 3, c = id & 7;
-    int p = 8 * s - 8 + jp;
-    float x[8];
-    load_tok_chunk(QC, a.ldqc, b, S, p, padL, h * 64 + 8 * c, x);
-    if (jp < 16) store_roped<T>(qA, jp, c, x, a.cos, a.sin, jp, 0.125f);
-    if (jp >= 8) store_roped<T>(qB, jp - 8, c, x, a.cos, a.sin, jp - 8, 0.125f);
-    load_tok_chunk(KV, a.ldkv, b, S, p, padL, h * 64 + 8 * c, x);
-    if (jp < 16) store_roped<T>(kA, jp, c, x, a.cos, a.sin, jp, 1.f);
-    if (jp >= 8) store_roped<T>(kB, jp - 8, c, x, a.cos, a.sin, jp - 8, 1.f);
-    load_tok_chunk(KV, a.ldkv, b, S, p, padL, 256 + h * 64 + 8 * c, x);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) vs[jp][8 * c + i] = x[i];
-    // window-output gradient at OUTPUT coordinate p (no pad shift), divided by the cover count
-#pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = 0.f;
-    if (p >= 0 && p < S) {
-      load8f(dO + (size_t)(b * S + p) * ba.lddo + h * 64 + 8 * c, x);
-      float ic = 1.f / local_cnt(p, nW);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] *= ic;
+    for (int it = 0; it < 3; ++it) {
+      int id = lane + 64 * it, jp = id >> 3, c = id & 7;
+      int p = 8 * s - 8 + jp;
+      okt[it] = load_tok_chunk(QC, a.ldqc, b, S, p, padL, h * 64 + 8 * c, qx[it]);
+      load_tok_chunk(KV, a.ldkv, b, S, p, padL, h * 64 + 8 * c, kx[it]);
+      load_tok_chunk(KV, a.ldkv, b, S, p, padL, 256 + h * 64 + 8 * c, vx[it]);
+      int pc = p < 0 ? 0 : (p >= S ? S - 1 : p);   // dO lives at OUTPUT coordinate p (no pad shift)
+      load8f(dO + (size_t)(b * S + pc) * ba.lddo + h * 64 + 8 * c, dx[it]);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dOs[jp][8 * c + i] = x[i];
+    for (int it = 0; it < 3; ++it) {
+      int id = lane + 64 * it, jp = id >> 3, c = id & 7;
+      int p = 8 * s - 8 + jp;
+      mask8(qx[it], okt[it]);
+      mask8(kx[it], okt[it]);
+      mask8(vx[it], okt[it]);
+      if (jp < 16) store_roped<T>(qA, jp, c, qx[it], a.cos, a.sin, jp, 0.125f);
+      if (jp >= 8) store_roped<T>(qB, jp - 8, c, qx[it], a.cos, a.sin, jp - 8, 0.125f);
+      if (jp < 16) store_roped<T>(kA, jp, c, kx[it], a.cos, a.sin, jp, 1.f);
+      if (jp >= 8) store_roped<T>(kB, jp - 8, c, kx[it], a.cos, a.sin, jp - 8, 1.f);
+      // window-output gradient divided by the cover count; zero outside [0, S)
+      const bool okp = (p >= 0) && (p < S);
+      const float ic = okp ? 1.f / local_cnt(okp ? p : 0, nW) : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        vs[jp][8 * c + i] = vx[it][i];
+        dOs[jp][8 * c + i] = dx[it][i] * ic;
+      }
+    }
   }
   __syncthreads();
   {
