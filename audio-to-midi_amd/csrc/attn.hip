@@ -122,8 +122,13 @@ __global__ __launch_bounds__(256) void attn_global_fwd_kernel(AttnArgs a) {
   T* Vs = Ks + 64 * ALD;
   T* Ps = Vs + 64 * ALD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-  const int h = blockIdx.y, b = blockIdx.z, S = a.S;
-  const int qrow = blockIdx.x * 64 + wave * 16 + r;
+  // XCD-aware order: the query tiles of one (clip, head) share K/V, so they get the same id % 8
+  const int S = a.S, ntile = (S + 63) / 64;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int bh = (jj / ntile) * 8 + xcd, qtile = jj % ntile;
+  if (bh >= a.B * a.H) return;
+  const int h = bh % a.H, b = bh / a.H;
+  const int qrow = qtile * 64 + wave * 16 + r;
   const T* QC = reinterpret_cast<const T*>(a.QC);
   const T* KV = reinterpret_cast<const T*>(a.KV);
   T* Pw = Ps + wave * 16 * ALD;
@@ -225,13 +230,13 @@ __global__ __launch_bounds__(256) void attn_global_fwd_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------ global backward: dQ (and delta)
 template <typename T>
-AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, unsigned char* smem_raw) {
+AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, int b, int h, unsigned char* smem_raw) {
   const AttnArgs& a = ba.f;
   T* Ks = reinterpret_cast<T*>(smem_raw);
   T* Vs = Ks + 64 * ALD;
   T* Ps = Vs + 64 * ALD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-  const int h = blockIdx.y, b = blockIdx.z, S = a.S;
+  const int S = a.S;
   const int qrow = tile * 64 + wave * 16 + r;
   const T* QC = reinterpret_cast<const T*>(a.QC);
   const T* KV = reinterpret_cast<const T*>(a.KV);
@@ -325,7 +330,7 @@ AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, unsigned c
 
 // ------------------------------------------------------------------ global backward: dK, dV
 template <typename T>
-AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, unsigned char* smem_raw) {
+AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, int h, unsigned char* smem_raw) {
   const AttnArgs& a = ba.f;
   T* Qs = reinterpret_cast<T*>(smem_raw);
   T* dOs = Qs + 64 * ALD;
@@ -334,7 +339,7 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, unsigned 
   float* lse_s = reinterpret_cast<float*>(dST + 4 * 16 * ALD);
   float* delta_s = lse_s + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-  const int h = blockIdx.y, b = blockIdx.z, S = a.S;
+  const int S = a.S;
   const int key = tile * 64 + wave * 16 + r;
   const T* QC = reinterpret_cast<const T*>(a.QC);
   const T* KV = reinterpret_cast<const T*>(a.KV);
@@ -460,8 +465,14 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, unsigned 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_global_bwd_kernel(AttnBwdArgs ba, int ntile) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  if ((int)blockIdx.x < ntile) attn_global_bwd_dq_body<T>(ba, blockIdx.x, smem_raw);
-  else attn_global_bwd_dkv_body<T>(ba, blockIdx.x - ntile, smem_raw);
+  // XCD-aware order: the 2 * ntile workgroups of one (clip, head) share its Q/K/V/dO: same id % 8
+  const int per = 2 * ntile;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int bh = (jj / per) * 8 + xcd, role = jj % per;
+  if (bh >= ba.f.B * ba.f.H) return;
+  const int h = bh % ba.f.H, b = bh / ba.f.H;
+  if (role < ntile) attn_global_bwd_dq_body<T>(ba, role, b, h, smem_raw);
+  else attn_global_bwd_dkv_body<T>(ba, role - ntile, b, h, smem_raw);
 }
 
 template <typename K> static void set_max_lds(K kernel, size_t bytes) {
@@ -470,7 +481,7 @@ template <typename K> static void set_max_lds(K kernel, size_t bytes) {
 }
 
 void attn_global_fwd(hipStream_t s, DType dt, const AttnArgs& a) {
-  dim3 grid((a.S + 63) / 64, a.H, a.B);
+  dim3 grid(((a.B * a.H + 7) / 8 * 8) * ((a.S + 63) / 64));
   ProfScope ps(s, "attn_global_fwd", 4.0 * a.B * a.H * (double)a.S * a.S * 64,
                4.0 * a.B * a.S * a.H * 64 * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) {
@@ -486,7 +497,7 @@ void attn_global_fwd(hipStream_t s, DType dt, const AttnArgs& a) {
 
 void attn_global_bwd(hipStream_t s, DType dt, const AttnBwdArgs& a) {
   const int ntile = (a.f.S + 63) / 64;
-  dim3 grid(2 * ntile, a.f.H, a.f.B);
+  dim3 grid(((a.f.B * a.f.H + 7) / 8 * 8) * 2 * ntile);
   ProfScope ps(s, "attn_global_bwd", 8.0 * a.f.B * a.f.H * (double)a.f.S * a.f.S * 64,
                8.0 * a.f.B * a.f.S * a.f.H * 64 * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) {
