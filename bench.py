@@ -203,16 +203,26 @@ def main():
                 f"  {b['tflops']} TFLOP/s  {b['gbs']} GB/s")
         log(f"  sum of kernel time per step: {tot / args.profile_steps:.3f} ms (timed step {ms_per_step:.3f} ms)")
         top = ents[0]
+        # HBM bytes per launch from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate passes, gfx950 corrections applied by profiles/make_traffic.py); PMC counters cannot
+        # be collected from inside this process, so `traffic` is null when the summary has no entry.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic_by_class.json")) as f:
+                traffic = json.load(f).get(top["name"], {}).get("hbm_bytes_per_launch")
+        except OSError:
+            pass
         if top["flops"] > 0:
             ach = top["flops"] / top["total_ms"] / 1e9
             roofline = {"bound": "mfma", "kernel": top["name"], "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 5), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 5), "traffic": traffic,
                         "avg_launch_us": round(1e3 * top["total_ms"] / top["launches"], 2),
-                        "flops_per_launch": top["flops"] / top["launches"]}
+                        "flops_per_launch": top["flops"] / top["launches"],
+                        "algorithmic_bytes_per_launch": top["bytes"] / top["launches"]}
         else:
             ach = top["bytes"] / top["total_ms"] / 1e6
             roofline = {"bound": "hbm", "kernel": top["name"], "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
-                        "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5), "traffic": None,
+                        "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5), "traffic": traffic,
                         "avg_launch_us": round(1e3 * top["total_ms"] / top["launches"], 2),
                         "bytes_per_launch": top["bytes"] / top["launches"]}
 

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs (separate passes, as MI355X_MICROARCH.md
+prescribes) into HBM bytes per launch per bench.py kernel class.
+
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --profile-steps 0
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python bench.py ... (same)
+  python profiles/make_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic_by_class.json
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE is in KB and reports exactly half of the
+bytes of wide coalesced reads -> x2; WRITE_SIZE (KB) is exact.  bytes = (2*FETCH + WRITE) * 1024.
+"""
+import collections, csv, glob, json, re, sys
+
+EPI = {0: "store", 1: "store_f32", 2: "resid", 3: "gelu", 4: "scale_resid", 5: "glu", 6: "glu_bwd", 7: "gelu_bwd"}
+
+
+def classify(name):
+    m = re.search(r"gemm_nt_kernelIDF16bLi(\d+)ELi(\d+)ELi\d+E", name)
+    if m:
+        return f"gemm_nt<bf16,{EPI[int(m.group(1))]},{m.group(2)}>"
+    m = re.search(r"gemm_nt_kernel<.*ELi(\d+)E", name)   # demangler-confused names: GLU_BWD (Li6)
+    if m:
+        return f"gemm_nt<bf16,glu_bwd,{m.group(1)}>"
+    for key, cls in (("gemm_tn_group_kernel", "gemm_tn_wgrad_group<bf16>"), ("dwblock_bwd_kernel", "dwblock_bwd"),
+                     ("attn_global_bwd_kernel", "attn_global_bwd"), ("attn_global_fwd_kernel", "attn_global_fwd"),
+                     ("attn_local_bwd_kernel", "attn_local_bwd"), ("attn_local_fwd_kernel", "attn_local_fwd"),
+                     ("ln_bwd_kernel", "layernorm_bwd"), ("ln_fwd_kernel", "layernorm_fwd"),
+                     ("dwln_fwd_kernel", "dwln_fwd"), ("stem_fwd_kernel", "stem_fwd"), ("stem_bwd_kernel", "stem_bwd")):
+        if key in name:
+            return cls
+    return None
+
+
+def load(d, counter):
+    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        c = classify(r["Kernel_Name"])
+        if c:
+            acc[c][0] += float(r["Counter_Value"]); acc[c][1] += 1
+    return acc
+
+
+if __name__ == "__main__":
+    fe, wr = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for c in fe:
+        if c in wr and fe[c][1] == wr[c][1]:
+            n = fe[c][1]
+            out[c] = {"launches_sampled": n, "fetch_size_kb_raw_per_launch": fe[c][0] / n,
+                      "write_size_kb_per_launch": wr[c][0] / n,
+                      "hbm_bytes_per_launch": (2 * fe[c][0] + wr[c][0]) * 1024 / n}
+    json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True))
