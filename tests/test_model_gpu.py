@@ -154,3 +154,44 @@ def test_error_behaviour():
     bad = dict(np_model.MODEL_CONFIG); bad["dims"] = [8, 16, 32, 64, 128, 256, 512]
     with pytest.raises(ValueError):
         amt.OutputSequenceGenerator(bad)
+
+
+def test_cfg1_wav_to_midi_events_bit_exact(tmp_path):
+    """BASELINE configs[0]: WAV -> windows -> model -> stitch -> extract_events -> .mid
+    (audio_to_midi.py:33-57).  fp32 device path vs the float64 oracle forward + the Python restatement
+    of the Rust post-processing: stitched probabilities within 2e-4, events bit-exact (no oracle
+    probability lies within the tolerance of a threshold 0.5 / 0.4 / 0.1, common.rs:51-54)."""
+    import wave
+    from audio_to_midi_amd import infer
+    from oracle import post as opost
+    conf = np_model.MODEL_CONFIG
+    params = np_model.init_params(conf, seed=1234, gamma=1.0)
+    for k in ("decoder.decoder_pooling.weight", "decoder.decoder_pooling.bias"):
+        params[k] = params[k] * 6.0     # spread the sigmoids over (0, 1) so that notes start and stop
+    audio, _ = synth.make_batch(1, 12 * 16000, seed=42)
+    pcm = np.clip(np.round(audio[0].T / np.abs(audio).max() * 30000.0), -32768, 32767).astype("<i2")
+    path = tmp_path / "clip.wav"
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+    model = amt.OutputSequenceGenerator(conf, dtype="float32")
+    model.load_equinox_params(params)
+    out = tmp_path / "clip.mid"
+    events, stitched, dpf = infer.audio_to_midi(model, path, out, overlap=0.5)
+    # oracle path on the same windows
+    windows, dur = infer.load_and_slice_full_audio(path, overlap=0.5)
+    assert windows.shape == (3, 2, 80000) and dpf == 5.0 / 250
+    pt = torch_model.to_torch(params, torch.float64)
+    _, probs_ref = torch_model.forward(pt, torch.from_numpy(windows).double(), conf)
+    probs_ref = probs_ref.numpy().astype(np.float32)
+    st_ref = opost.stitch_probs(probs_ref, 0.5, dpf)
+    assert stitched.shape == st_ref.shape == (250 * 3 - 25 * 2, 90)
+    tol = 2e-4
+    assert np.abs(stitched - st_ref).max() <= tol
+    margin = min(np.abs(st_ref - t).min() for t in (0.5, 0.4, 0.1))
+    assert margin > tol, f"oracle probability within {tol} of a threshold ({margin}): pick another seed"
+    ev_ref = opost.extract_events(st_ref)
+    assert len(ev_ref) > 10
+    assert events == ev_ref
+    data = out.read_bytes()
+    assert data[:4] == b"MThd" and data[14:18] == b"MTrk" and data[-4:] == b"\x00\xff\x2f\x00"
+    assert len(data) == 22 + int.from_bytes(data[18:22], "big")
