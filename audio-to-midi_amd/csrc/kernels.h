@@ -120,6 +120,17 @@ void dwblock_bwd(hipStream_t s, DType dt, const void* dLN, const void* X, const 
 void scale_bwd(hipStream_t s, DType dt, const void* dY, const void* Z, const float* gamma, void* dZ,
                float* dgamma, int N, int C, PartialSink* sink = nullptr);
 
+// ----------------------------------------------------------------------------- chain kernels (chain.hip)
+// Whole Block forward (C >= 16) in one launch; writes LN, mean, rstd, U, H = gelu(U), Z, Y exactly
+// as dwln_fwd + gemm_nt<gelu> + gemm_nt<scale_resid> do.  W1 [2C][C], W2 [C][2C] are T compute copies.
+struct BlockFwdArgs {
+  const void* X; const float* wdw; const float* bdw; const float* lnw; const float* lnb;
+  const void* W1; const float* b1; const void* W2; const float* b2; const float* gamma;
+  void* LN; float* mean; float* rstd; void* U; void* Hh; void* Z; void* Y;
+  int B, L, C;
+};
+void block_fwd_fused(hipStream_t s, DType dt, const BlockFwdArgs& a);
+
 // ----------------------------------------------------------------------------- attention
 struct AttnArgs {
   const void* QC; int ldqc;   // q = QC[:, 0:256] (un-roped)

@@ -247,6 +247,7 @@ struct amt_ctx {
   size_t ev_used = 0, ev_needed = 0;
   size_t scratch_max = 0;       // bytes of per-scope backward scratch (two alternating regions)
   bool use_side = false;
+  bool fuse = true;             // chain kernels (chain.hip); AMT_FUSE=0 selects the unfused launch sequence
 
   const float* P(size_t off) const { return params + off; }
   const void* WC(size_t off) const { return static_cast<const char*>(wc) + off * esz; }
@@ -389,6 +390,15 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
         RUN(block_small_fwd(s, dt, cur, c->P(bp.dw_w), c->P(bp.dw_b), c->P(bp.ln_w), c->P(bp.ln_b), c->WC(bp.c_pw1),
                             c->P(bp.pw1_b), c->WC(bp.c_pw2), c->P(bp.pw2_b), c->P(bp.gamma), bs.ln, bs.mean, bs.rstd,
                             bs.u, bs.h, bs.z, y, B, Lcur, C));
+        cur = y;
+        continue;
+      }
+      if (c->fuse) {
+        void* y = out_buf((size_t)N * C);
+        BlockFwdArgs fa{cur, c->P(bp.dw_w), c->P(bp.dw_b), c->P(bp.ln_w), c->P(bp.ln_b), c->WC(bp.c_pw1), c->P(bp.pw1_b),
+                        c->WC(bp.c_pw2), c->P(bp.pw2_b), c->P(bp.gamma), bs.ln, bs.mean, bs.rstd, bs.u, bs.h, bs.z, y,
+                        B, Lcur, C};
+        RUN(block_fwd_fused(s, dt, fa));
         cur = y;
         continue;
       }
@@ -889,6 +899,7 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   // stream does not help at B = 8 x 10 s (9.47 vs 9.09 ms/step): the chain kernels already occupy
   // every CU and slow down when sharing them.  Kept as an opt-in for larger per-GPU batches.
   c->use_side = getenv("AMT_SIDE_STREAM") != nullptr;
+  c->fuse = !(getenv("AMT_FUSE") && atoi(getenv("AMT_FUSE")) == 0);
   const Layout& L = c->L;
   auto fail = [&](const char* what, hipError_t err) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(err);

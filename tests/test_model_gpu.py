@@ -159,8 +159,8 @@ def test_error_behaviour():
 def test_cfg1_wav_to_midi_events_bit_exact(tmp_path):
     """BASELINE configs[0]: WAV -> windows -> model -> stitch -> extract_events -> .mid
     (audio_to_midi.py:33-57).  fp32 device path vs the float64 oracle forward + the Python restatement
-    of the Rust post-processing: stitched probabilities within 2e-4, events bit-exact (no oracle
-    probability lies within the tolerance of a threshold 0.5 / 0.4 / 0.1, common.rs:51-54)."""
+    of the Rust post-processing: stitched probabilities within 2e-4, events bit-exact on the
+    margin-filtered track (thresholds 0.5 / 0.4 / 0.1, common.rs:51-54)."""
     import wave
     from audio_to_midi_amd import infer
     from oracle import post as opost
@@ -187,8 +187,14 @@ def test_cfg1_wav_to_midi_events_bit_exact(tmp_path):
     assert stitched.shape == st_ref.shape == (250 * 3 - 25 * 2, 90)
     tol = 2e-4
     assert np.abs(stitched - st_ref).max() <= tol
-    margin = min(np.abs(st_ref - t).min() for t in (0.5, 0.4, 0.1))
-    assert margin > tol, f"oracle probability within {tol} of a threshold ({margin}): pick another seed"
+    # margin filter: cells whose oracle probability lies within the tolerance of a
+    # threshold cannot be decided by either side; they take the device's value (which is within the
+    # tolerance of the oracle's), every other cell is the oracle's own
+    near = np.zeros(st_ref.shape, dtype=bool)
+    for t in (0.5, 0.4, 0.1):
+        near |= np.abs(st_ref - t) <= tol
+    assert near.mean() < 2e-3
+    st_ref = np.where(near, stitched, st_ref)
     ev_ref = opost.extract_events(st_ref)
     assert len(ev_ref) > 10
     assert events == ev_ref
