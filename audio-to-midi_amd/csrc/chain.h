@@ -15,30 +15,86 @@
 
 namespace amt {
 
-// acc[rb][ti] += W[m0 + 16 rb + .][0..K) . Xs[t0 + 16 ti + .][0..K)^T
-//   W : row-major [..][ldw] in global memory (T compute copy), rows m0 + 16 rb + r
+// One stage:  acc[rb][ti] += W[m0 + 16 rb + .][0..K) . Xs[t0 + 16 ti + .][0..K)^T
+//   W : fragment-packed T compute copy in global memory (rows m0 + 16 rb + r)
 //   Xs: LDS panel [..][ldx] (T), rows t0 + 16 ti + r; columns >= K are never read as data
-// K % 8 == 0.  The accumulation order over K equals gemm_nt's (one 32-deep step after the other into
-// a single accumulator), so a chain kernel reproduces the unfused path bit for bit.
-template <typename T, int RB, int NT, int K>
-AMT_DEV void chain_gemm(f32x4 (&acc)[RB][NT], const T* __restrict__ W, int ldw, int m0, const T* Xs, int ldx, int t0,
-                        int lane) {
-  const int r = lane & 15, g = lane >> 4;
+// K % 8 == 0.  The K axis is cut into chunks of KC 32-deep steps.  The caller loads chunk 0 with
+// chain_load_w as EARLY as it can (the weights depend on nothing, so their L2/HBM round trip overlaps
+// the activation loads of the row phase); chain_stage prefetches chunk j + 1 into the other register
+// set while chunk j is multiplied.  The accumulation order over K equals gemm_nt's (one 32-deep step
+// after the other into a single accumulator), so a chain kernel reproduces the unfused path bit
+// for bit.
+// W is the fragment-PACKED copy (kernels.h: chain_packed_elems): [M/16][KS][64 lanes][8]; m0 % 16 == 0.
+template <typename T, int RB, int KC, int K>
+AMT_DEV void chain_load_w(Frag<T> (&wf)[KC][RB], const T* __restrict__ W, int m0, int chunk, int lane) {
   constexpr int KS = (K + 31) / 32;
-  const T* wp = W + (size_t)(m0 + r) * ldw + 8 * g;
-  const T* xp = Xs + (t0 + r) * ldx + 8 * g;
+  const T* wp = W + ((size_t)(m0 >> 4) * KS) * 512 + lane * 8;
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    Frag<T> wf[RB], xf[NT];
-    const bool ok = (K % 32 == 0) || (32 * ks + 8 * g < K);
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) wf[rb] = ok ? frag_row(wp + (size_t)rb * 16 * ldw + 32 * ks) : frag_zero<T>();
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti) xf[ti] = ok ? frag_row(xp + ti * 16 * ldx + 32 * ks) : frag_zero<T>();
+  for (int kc = 0; kc < KC; ++kc) {
+    const int ks = chunk * KC + kc;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
+      wf[kc][rb] = ks < KS ? frag_row(wp + ((size_t)rb * KS + ks) * 512) : frag_zero<T>();
+  }
+}
+
+template <typename T, int RB, int NT, int KC, int K>
+AMT_DEV void chain_mma_chunk(f32x4 (&acc)[RB][NT], const Frag<T> (&wf)[KC][RB], const T* Xs, int ldx, int t0, int chunk,
+                             int lane) {
+  const int r = lane & 15, g = lane >> 4;
+  constexpr int KS = (K + 31) / 32;
+  const T* xp = Xs + (t0 + r) * ldx + 8 * g;
 #pragma unroll
-      for (int ti = 0; ti < NT; ++ti) mma(acc[rb][ti], wf[rb], xf[ti]);
+  for (int kc = 0; kc < KC; ++kc) {
+    const int ks = chunk * KC + kc;
+    if (ks < KS) {
+      const bool ok = (K % 32 == 0) || (32 * ks + 8 * g < K);
+      Frag<T> xf[NT];
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti) xf[ti] = ok ? frag_row(xp + ti * 16 * ldx + 32 * ks) : frag_zero<T>();
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) mma(acc[rb][ti], wf[kc][rb], xf[ti]);
+    }
+  }
+}
+
+template <typename T, int RB, int NT, int KC, int K>
+AMT_DEV void chain_stage(f32x4 (&acc)[RB][NT], Frag<T> (&w0)[KC][RB], const T* __restrict__ W, int m0, const T* Xs,
+                         int ldx, int t0, int lane) {
+  constexpr int KS = (K + 31) / 32, NCH = (KS + KC - 1) / KC;
+  Frag<T> w1[KC][RB];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    if (ch + 1 < NCH) {
+      if (ch & 1) chain_load_w<T, RB, KC, K>(w0, W, m0, ch + 1, lane);
+      else chain_load_w<T, RB, KC, K>(w1, W, m0, ch + 1, lane);
+    }
+    if (ch & 1) chain_mma_chunk<T, RB, NT, KC, K>(acc, w1, Xs, ldx, t0, ch, lane);
+    else chain_mma_chunk<T, RB, NT, KC, K>(acc, w0, Xs, ldx, t0, ch, lane);
+  }
+}
+
+// chunk depth: keep at most ~16 (bf16) / ~8 (f32) fragments of a stage in flight per register set
+template <typename T, int RB, int K> struct ChainChunk {
+  static constexpr int KS = (K + 31) / 32;
+  static constexpr int BUDGET = sizeof(T) == 2 ? 16 : 8;
+  static constexpr int KC = (BUDGET / RB) < 1 ? 1 : ((BUDGET / RB) > KS ? KS : (BUDGET / RB));
+};
+
+// LDS panel [TT][ld] -> global rows n0 .. n0 + TT (row-major, W features), 16 bytes (bf16: 8
+// elements) per lane, consecutive lanes on consecutive chunks of a row: whole-line stores.
+template <typename T, int TT, int W, int LD>
+AMT_DEV void chain_copy_out(const T* Ps, T* __restrict__ G, long n0, long N, int tid) {
+  constexpr int CPR = W / 8;                 // chunks per row
+  constexpr int TOTAL = TT * CPR;
+#pragma unroll
+  for (int i = 0; i < (TOTAL + 255) / 256; ++i) {
+    const int id = tid + i * 256;
+    const int p = id / CPR, c = id % CPR;
+    if ((TOTAL % 256 == 0 || id < TOTAL) && n0 + p < N)
+      chunk_store(G + (n0 + p) * W + 8 * c, chunk_load(Ps + p * LD + 8 * c));
   }
 }
 

@@ -170,10 +170,15 @@ __global__ __launch_bounds__(256) void convert_batch_kernel(const float* __restr
   const float* sp = src + d.src_off;
   T* dp = dst + d.dst_off;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int ksteps = (d.cols + 31) / 32;
+  auto didx = [&](int r, int c) -> size_t {
+    if (!d.pack) return (size_t)r * d.cols + c;
+    return ((size_t)(r >> 4) * ksteps + (c >> 5)) * 512 + (size_t)((((c & 31) >> 3) << 4) + (r & 15)) * 8 + (c & 7);
+  };
   if (!d.transpose) {
     for (int i = ty; i < 32; i += 8) {
       int r = r0 + i, c = c0 + tx;
-      if (r < d.rows && c < d.cols) dp[(size_t)r * d.cols + c] = from_f<T>(r < d.src_rows ? sp[(size_t)r * d.cols + c] : 0.f);
+      if (r < d.rows && c < d.cols) dp[didx(r, c)] = from_f<T>(r < d.src_rows ? sp[(size_t)r * d.cols + c] : 0.f);
     }
   } else {
     // src is [src_rows(valid cols of dst)][rows]
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256) void convert_batch_kernel(const float* __restr
       if (r < d.rows && c < d.cols) {
         float v = tile[tx][i];
         if (d.scale_off >= 0) v *= src[d.scale_off + c];
-        dp[(size_t)r * d.cols + c] = from_f<T>(v);
+        dp[didx(r, c)] = from_f<T>(v);
       }
     }
   }

@@ -122,12 +122,13 @@ void scale_bwd(hipStream_t s, DType dt, const void* dY, const void* Z, const flo
 
 // ----------------------------------------------------------------------------- chain kernels (chain.hip)
 // Whole Block forward (C >= 16) in one launch; writes LN, mean, rstd, U, H = gelu(U), Z, Y exactly
-// as dwln_fwd + gemm_nt<gelu> + gemm_nt<scale_resid> do.  W1 [2C][C], W2 [C][2C] are T compute copies.
+// as dwln_fwd + gemm_nt<gelu> + gemm_nt<scale_resid> do.  W1 [2C][C], W2 [C][2C] are fragment-PACKED T copies.
 struct BlockFwdArgs {
   const void* X; const float* wdw; const float* bdw; const float* lnw; const float* lnb;
   const void* W1; const float* b1; const void* W2; const float* b2; const float* gamma;
   void* LN; float* mean; float* rstd; void* U; void* Hh; void* Z; void* Y;
   int B, L, C;
+  int dbg_slot;   // micro-benchmark only (AMT_CHAIN_TIMING)
 };
 void block_fwd_fused(hipStream_t s, DType dt, const BlockFwdArgs& a);
 
@@ -180,7 +181,12 @@ void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, const
 
 // batched fp32 -> T weight conversion (plain copy or transpose), one launch for the whole model
 struct ConvDesc { uint64_t src_off; uint64_t dst_off; int rows, cols; int src_rows; int transpose;
-                  long long scale_off; /* >= 0: dst[r][c] *= params[scale_off + c] */ };
+                  long long scale_off; /* >= 0: dst[r][c] *= params[scale_off + c] */
+                  int pack;            /* != 0: dst in MFMA-fragment order (chain.h: chain_packed_index) */ };
+// Fragment-packed weight copy for the chain kernels: [rows/16][ceil(cols/32)][64 lanes][8], lane = 16 g + r
+// holds W[16 rb + r][32 ks + 8 g .. + 8) — one wave-level A-fragment load is 1 KiB contiguous
+// (row-major gives 16 rows x 64 B per load: half of every cache line per instruction).
+static inline size_t chain_packed_elems(int rows, int cols) { return (size_t)(rows / 16) * ((cols + 31) / 32) * 512; }
 void convert_batch(hipStream_t s, DType dt, const float* src, void* dst, const ConvDesc* descs_dev,
                    const int* tile_prefix_dev, int n_desc, int total_tiles);
 

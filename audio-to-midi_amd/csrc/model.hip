@@ -35,6 +35,7 @@ struct BlockP {  // offsets into the flat fp32 vector
   size_t dw_w, dw_b, ln_w, ln_b, pw1_w, pw1_b, pw2_w, pw2_b, gamma;
   size_t c_pw1, c_pw1t, c_pw2, c_pw2t;  // compute-copy offsets (elements of T)
   size_t c_pw2tg;                       // pw2^T with its columns scaled by gamma (layer scale folded)
+  size_t c_pw1p, c_pw2p;                // fragment-packed copies for the chain kernels (C >= 16)
 };
 struct StageP {
   int C, Cin, depth;
@@ -94,8 +95,13 @@ Layout build_layout(const amt_config& c) {
   auto cpair = [&](size_t src, int rows, int cols, size_t& cw, size_t& cwt) {
     cw = cbuf((size_t)rows * cols);
     cwt = cbuf((size_t)rows * cols);
-    L.conv.push_back(ConvDesc{src, cw, rows, cols, rows, 0, -1});
-    L.conv.push_back(ConvDesc{src, cwt, cols, rows, rows, 1, -1});
+    L.conv.push_back(ConvDesc{src, cw, rows, cols, rows, 0, -1, 0});
+    L.conv.push_back(ConvDesc{src, cwt, cols, rows, rows, 1, -1, 0});
+  };
+  auto cpacked = [&](size_t src, int rows, int cols) {
+    size_t o = cbuf(chain_packed_elems(rows, cols));
+    L.conv.push_back(ConvDesc{src, o, rows, cols, rows, 0, -1, 1});
+    return o;
   };
   int depth_base = 0;
   for (int s = 0; s < c.n_stages; ++s) {
@@ -135,7 +141,12 @@ Layout build_layout(const amt_config& c) {
       cpair(b.pw1_w, 2 * C, C, b.c_pw1, b.c_pw1t);
       cpair(b.pw2_w, C, 2 * C, b.c_pw2, b.c_pw2t);
       b.c_pw2tg = cbuf((size_t)2 * C * C);
-      L.conv.push_back(ConvDesc{b.pw2_w, b.c_pw2tg, 2 * C, C, C, 1, (long long)b.gamma});
+      L.conv.push_back(ConvDesc{b.pw2_w, b.c_pw2tg, 2 * C, C, C, 1, (long long)b.gamma, 0});
+      b.c_pw1p = b.c_pw2p = 0;
+      if (C >= 16) {
+        b.c_pw1p = cpacked(b.pw1_w, 2 * C, C);
+        b.c_pw2p = cpacked(b.pw2_w, C, 2 * C);
+      }
       st.blocks.push_back(b);
     }
     depth_base += st.depth;
@@ -178,8 +189,8 @@ Layout build_layout(const amt_config& c) {
   // head: padded to VP rows so that every GEMM has M % 4 == 0 and K % 8 == 0
   L.c_hw = cbuf((size_t)L.VP * H);
   L.c_hwt = cbuf((size_t)L.VP * H);
-  L.conv.push_back(ConvDesc{L.hd_w, L.c_hw, L.VP, H, c.n_events, 0, -1});
-  L.conv.push_back(ConvDesc{L.hd_w, L.c_hwt, H, L.VP, c.n_events, 1, -1});
+  L.conv.push_back(ConvDesc{L.hd_w, L.c_hw, L.VP, H, c.n_events, 0, -1, 0});
+  L.conv.push_back(ConvDesc{L.hd_w, L.c_hwt, H, L.VP, c.n_events, 1, -1, 0});
   L.n_params = off;
   L.n_compute = coff;
   return L;
@@ -350,6 +361,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
   };
 
   void* cur = nullptr;
+  int dbg_slot = 0;   // micro-benchmark builds only (AMT_CHAIN_TIMING)
   for (int si = 0; si < cfg.n_stages; ++si) {
     const StageP& st = L.stages[si];
     StageSave& sv = c->ssave[si];
@@ -395,9 +407,9 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
       }
       if (c->fuse) {
         void* y = out_buf((size_t)N * C);
-        BlockFwdArgs fa{cur, c->P(bp.dw_w), c->P(bp.dw_b), c->P(bp.ln_w), c->P(bp.ln_b), c->WC(bp.c_pw1), c->P(bp.pw1_b),
-                        c->WC(bp.c_pw2), c->P(bp.pw2_b), c->P(bp.gamma), bs.ln, bs.mean, bs.rstd, bs.u, bs.h, bs.z, y,
-                        B, Lcur, C};
+        BlockFwdArgs fa{cur, c->P(bp.dw_w), c->P(bp.dw_b), c->P(bp.ln_w), c->P(bp.ln_b), c->WC(bp.c_pw1p), c->P(bp.pw1_b),
+                        c->WC(bp.c_pw2p), c->P(bp.pw2_b), c->P(bp.gamma), bs.ln, bs.mean, bs.rstd, bs.u, bs.h, bs.z, y,
+                        B, Lcur, C, (dbg_slot++) | (getenv("AMT_DBG_MODE") ? atoi(getenv("AMT_DBG_MODE")) : 0)};
         RUN(block_fwd_fused(s, dt, fa));
         cur = y;
         continue;
@@ -909,6 +921,7 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   if ((he = hipMalloc(&c->params, L.n_params * sizeof(float))) != hipSuccess) return fail("hipMalloc(params)", he);
   if ((he = hipMemset(c->params, 0, L.n_params * sizeof(float))) != hipSuccess) return fail("hipMemset", he);
   if ((he = hipMalloc(&c->wc, L.n_compute * c->esz)) != hipSuccess) return fail("hipMalloc(compute copies)", he);
+  if ((he = hipMemset(c->wc, 0, L.n_compute * c->esz)) != hipSuccess) return fail("hipMemset", he);   // packed copies: padding stays zero
   if ((he = hipMalloc(&c->head_bias, L.VP * sizeof(float))) != hipSuccess) return fail("hipMalloc(head bias)", he);
   if ((he = hipMalloc(&c->loss_acc, 2 * sizeof(float))) != hipSuccess) return fail("hipMalloc(loss)", he);
   std::vector<int> prefix(L.conv.size() + 1, 0);

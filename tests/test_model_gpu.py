@@ -201,3 +201,27 @@ def test_cfg1_wav_to_midi_events_bit_exact(tmp_path):
     data = out.read_bytes()
     assert data[:4] == b"MThd" and data[14:18] == b"MTrk" and data[-4:] == b"\x00\xff\x2f\x00"
     assert len(data) == 22 + int.from_bytes(data[18:22], "big")
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_chain_kernels_equal_unfused_launch_sequence(small_conf, dtype, monkeypatch):
+    """csrc/chain.hip evaluates whole operator chains per token tile with the roundings and the
+    accumulation order of the unfused launches (AMT_FUSE=0): logits and loss agree bit for bit,
+    gradients up to the atomic summation order of the weight-gradient kernels."""
+    conf = dict(small_conf)
+    conf["depths"] = [1, 1, 2, 1, 1, 2, 1]
+    params = np_model.init_params(conf, seed=21, gamma=1.0)
+    audio, labels = synth.make_batch(3, 320 * 77, seed=9)      # 231 frames: ragged last tiles everywhere
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("AMT_FUSE", fuse)
+        model = amt.OutputSequenceGenerator(conf, dtype=dtype)
+        model.load_equinox_params(params)
+        outs.append(model.loss_and_grads(torch.from_numpy(audio), torch.from_numpy(labels), seed=5, train=True,
+                                         return_logits=True))
+        model.close()
+    a, b = outs
+    assert torch.equal(a.logits, b.logits)
+    assert abs(a.loss - b.loss) <= 1e-6 * abs(b.loss)      # summed with float atomics
+    rel = float((a.grads_flat - b.grads_flat).norm() / b.grads_flat.norm())
+    assert rel < 1e-5, rel
