@@ -98,6 +98,61 @@ AMT_DEV void chain_copy_out(const T* Ps, T* __restrict__ G, long n0, long N, int
   }
 }
 
+// Column sums of per-lane accumulators: v[j], j = 8 * slot + i, of the lane that owns feature chunk
+// sub = lane % LPR (features 8 sub + i) are summed over every lane of the WAVE with the same sub and
+// stored to part[slot * C + 8 sub + i] (the wave's own LDS slice of NV / 8 * C floats: plain stores, the
+// caller sums the four slices after a barrier).  LDS float atomics were the bound of the previous
+// form: ~3.6 cycles per lane-add, 20 k cycles per workgroup at C = 128.
+// Strides below 16 lanes are DPP adds; the 16- and 32-lane strides use the two-register permlane swaps
+// so that ONE swap reduces two accumulators and the 4 (LPR <= 16) or 2 (LPR = 32) row groups of a wave
+// end up owning the totals of 4 / 2 different accumulators.
+template <int LPR, int NV>
+AMT_DEV void fold_columns(float (&v)[NV], float* part, int C, int lane) {
+  static_assert(NV % 4 == 0, "accumulators are folded four at a time");
+  const int sub = lane % LPR;
+  if constexpr (LPR < 16) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      float x = v[j];
+      if constexpr (LPR <= 1) x += dpp_mov<DPP_XOR1>(x);
+      if constexpr (LPR <= 2) x += dpp_mov<DPP_XOR2>(x);
+      if constexpr (LPR <= 4) x += dpp_mov<DPP_ROR4>(x);
+      if constexpr (LPR <= 8) x += dpp_mov<DPP_ROR8>(x);
+      v[j] = x;
+    }
+  }
+  if constexpr (LPR <= 16) {
+    float t[NV / 4];
+#pragma unroll
+    for (int q = 0; q < NV / 4; ++q) {
+      float a = v[4 * q], b = v[4 * q + 1], c = v[4 * q + 2], d = v[4 * q + 3];
+      swap16(a, b);
+      float sab = a + b;          // rows: a01 b01 a23 b23
+      swap16(c, d);
+      float scd = c + d;          // rows: c01 d01 c23 d23
+      swap32(sab, scd);
+      t[q] = sab + scd;           // rows: a b c d
+    }
+    if ((lane & 15) < LPR) {
+      const int rho = lane >> 4;
+#pragma unroll
+      for (int q = 0; q < NV / 4; ++q) {
+        const int j = 4 * q + rho;
+        part[(j >> 3) * C + sub * 8 + (j & 7)] = t[q];
+      }
+    }
+  } else {
+    const int eta = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < NV / 2; ++q) {
+      float a = v[2 * q], b = v[2 * q + 1];
+      swap32(a, b);
+      const int j = 2 * q + eta;
+      part[(j >> 3) * C + sub * 8 + (j & 7)] = a + b;
+    }
+  }
+}
+
 template <int RB, int NT> AMT_DEV void chain_zero(f32x4 (&acc)[RB][NT]) {
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)

@@ -13,10 +13,10 @@
 
 // Phase timestamps for the micro-benchmark (scratch/chain_bench.hip): compiled out of the library.
 #ifdef AMT_CHAIN_TIMING
-__device__ unsigned long long amt_stamps[64][256][8];   // [launch slot][workgroup][phase]
-#define AMT_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) amt_stamps[a.dbg_slot & 63][blockIdx.x][k] = __builtin_readcyclecounter(); } while (0)
-#define AMT_STAMP_RT(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) amt_stamps[a.dbg_slot & 63][blockIdx.x][k] = wall_clock64(); } while (0)
-extern "C" int amt_debug_read_stamps(unsigned long long* out) {   // [64][256][8]; slots 6, 7 = 100 MHz real-time clock
+__device__ unsigned long long amt_stamps[128][256][8];   // [launch slot][workgroup][phase]
+#define AMT_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) amt_stamps[a.dbg_slot & 127][blockIdx.x][k] = __builtin_readcyclecounter(); } while (0)
+#define AMT_STAMP_RT(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) amt_stamps[a.dbg_slot & 127][blockIdx.x][k] = wall_clock64(); } while (0)
+extern "C" int amt_debug_read_stamps(unsigned long long* out) {   // [128][256][8]; slots 6, 7 = 100 MHz real-time clock
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(amt_stamps), sizeof(amt_stamps));
 }
 #else
@@ -263,6 +263,289 @@ void block_fwd_fused(hipStream_t s, DType dt, const BlockFwdArgs& a) {
     default: break;
   }
 #undef AMT_BF_CASE
+}
+
+// ------------------------------------------------------------------ Block backward
+// One launch for the data-gradient chain of a Block (replaces gemm_nt<gelu_bwd> + gemm_nt<store> +
+// dwblock_bwd):
+//   du  = (dy . (gamma * W2)) * gelu'(u)            stage A   (layer scale folded into the weight copy)
+//   dln = du . W1                                    stage B
+//   dD  = LN'(dln) w.r.t. the depthwise-conv output (recomputed from x), rows +-3 around the tile
+//   dx  = dy + conv^T(dD);  dlnw, dlnb, dwdw[7][C], dbdw, dgamma = sum dy * z   -> per-workgroup records
+// A tile is TT consecutive positions of ONE clip: TL = TT - 6 interior rows + 3 halo rows each side
+// (the two GEMM stages are evaluated for the halo rows too: 6 / TT extra work instead of an exchange).
+// du is written to HBM for the weight-gradient launch; everything else stays in LDS.
+template <typename T, int C> struct BlockBwdTile {   // == DwTile<C>::ROWS of the unfused kernel
+  static constexpr int TT = C <= 32 ? 128 : (C <= 64 ? 64 : (sizeof(T) == 4 && C == 256 ? 16 : 32));
+};
+
+template <typename T, int C, int TT>
+__global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a) {
+  constexpr int H2 = 2 * C, LDX = C + 8, LDH = H2 + 8, TL = TT - 6;
+  constexpr int LPR = C / 8, RPP = 256 / LPR;
+  static_assert(TT % RPP == 0, "row phases cover the tile in whole passes");
+  using SA = ChainSplit<H2, TT>;
+  using SB = ChainSplit<C, TT>;
+  constexpr int KCA = ChainChunk<T, SA::RB, C>::KC, KCB = ChainChunk<T, SB::RB, H2>::KC;
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  T* DYs = reinterpret_cast<T*>(chain_smem);           // [TT][LDX]      dy (zero outside the clip)
+  T* Us = DYs + TT * LDX;                              // [TT][LDH]      u, then du in place
+  T* DLs = Us + TT * LDH;                              // [TT][LDX]      dln, then dD in place
+  T* Xt = DLs + TT * LDX;                              // [TT + 6][LDX]  block input, rows l0 - 6 .. (zero outside)
+  float* part = reinterpret_cast<float*>(chain_smem);   // [4 waves][11 * C], over DYs/Us/DLs once they are dead
+  static_assert(sizeof(T) * TT * (2 * LDX + LDH) >= sizeof(float) * 44 * C, "column-sum slices fit over the dead panels");
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / a.tiles_per_clip, l0 = (blockIdx.x % a.tiles_per_clip) * TL;
+  const int L = a.L;
+  const long rb = (long)b * L;
+  const T* dY = reinterpret_cast<const T*>(a.dY);
+  const T* X = reinterpret_cast<const T*>(a.X);
+  const T* U = reinterpret_cast<const T*>(a.U);
+  const T* WA = reinterpret_cast<const T*>(a.W2tg);
+  const T* WB = reinterpret_cast<const T*>(a.W1t);
+  const int mA = (wave % SA::WF) * SA::RB * 16, tA = (wave / SA::WF) * SA::NT * 16;
+  const int mB = (wave % SB::WF) * SB::RB * 16, tB = (wave / SB::WF) * SB::NT * 16;
+  const int sub = tid % LPR, prow = tid / LPR;
+
+  AMT_STAMP_RT(6);
+  AMT_STAMP(0);
+  Frag<T> wa[KCA][SA::RB], wb[KCB][SB::RB];
+  chain_load_w<T, SA::RB, KCA, C>(wa, WA, mA, 0, lane);
+  chain_load_w<T, SB::RB, KCB, H2>(wb, WB, mB, 0, lane);   // registers are idle until the row phases
+
+  // ---- staging: dy and u rows l0 - 3 .. l0 + TL + 2, x rows l0 - 6 .. l0 + TL + 5; rows outside the
+  // clip are loaded from a clamped row and zeroed (unconditional loads, see cnn.hip)
+#pragma unroll
+  for (int pp = 0; pp < TT / RPP; ++pp) {
+    const int p = pp * RPP + prow;
+    const int l = l0 - 3 + p;
+    const bool in = l >= 0 && l < L;
+    const int lc = l < 0 ? 0 : (l >= L ? L - 1 : l);
+    Chunk8<T> dyc = chunk_load(dY + (rb + lc) * C + sub * 8);
+    if (!in) dyc = chunk_zero<T>();
+    chunk_store(DYs + p * LDX + sub * 8, dyc);
+    chunk_store(Us + p * LDH + sub * 8, chunk_load(U + (rb + lc) * H2 + sub * 8));
+    chunk_store(Us + p * LDH + C + sub * 8, chunk_load(U + (rb + lc) * H2 + C + sub * 8));
+  }
+#pragma unroll
+  for (int pp = 0; pp < (TT + 6 + RPP - 1) / RPP; ++pp) {
+    const int p = pp * RPP + prow;
+    const int l = l0 - 6 + p;
+    const bool in = l >= 0 && l < L;
+    const int lc = l < 0 ? 0 : (l >= L ? L - 1 : l);
+    Chunk8<T> xc = chunk_load(X + (rb + lc) * C + sub * 8);
+    if (!in) xc = chunk_zero<T>();
+    if (p < TT + 6) chunk_store(Xt + p * LDX + sub * 8, xc);
+  }
+  __syncthreads();
+  AMT_STAMP(1);
+
+  // ---- stage A: du = (W2tg . dy^T) * gelu'(u), in place over u
+  {
+    f32x4 acc[SA::RB][SA::NT];
+    chain_zero(acc);
+    chain_stage<T, SA::RB, SA::NT, KCA, C>(acc, wa, WA, mA, DYs, LDX, tA, lane);
+#pragma unroll
+    for (int rbk = 0; rbk < SA::RB; ++rbk) {
+      const int m = mA + 16 * rbk + 4 * g;
+#pragma unroll
+      for (int ti = 0; ti < SA::NT; ++ti) {
+        const int p = tA + 16 * ti + r;
+        float u[4], du[4];
+        load4f(Us + p * LDH + m, u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) du[i] = acc[rbk][ti][i] * gelu_tanh_grad(u[i]);
+        store4f(Us + p * LDH + m, du);
+      }
+    }
+  }
+  __syncthreads();
+  // du of the interior rows leaves for the weight-gradient launch (whole rows, 16 B per lane)
+  {
+    constexpr int CPR = H2 / 8, TOTAL = TL * CPR;
+#pragma unroll
+    for (int i = 0; i < (TOTAL + 255) / 256; ++i) {
+      const int id = tid + i * 256;
+      const int q = id / CPR, cc = id % CPR;
+      if (id < TOTAL && l0 + q < L)
+        chunk_store(reinterpret_cast<T*>(a.dU) + (rb + l0 + q) * H2 + 8 * cc, chunk_load(Us + (q + 3) * LDH + 8 * cc));
+    }
+  }
+
+  // ---- stage B: dln = W1t . du^T
+  {
+    f32x4 acc[SB::RB][SB::NT];
+    chain_zero(acc);
+    chain_stage<T, SB::RB, SB::NT, KCB, H2>(acc, wb, WB, mB, Us, LDH, tB, lane);
+#pragma unroll
+    for (int rbk = 0; rbk < SB::RB; ++rbk) {
+      const int m = mB + 16 * rbk + 4 * g;
+#pragma unroll
+      for (int ti = 0; ti < SB::NT; ++ti) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[rbk][ti][i];
+        store4f(DLs + (tB + 16 * ti + r) * LDX + m, v);
+      }
+    }
+  }
+  __syncthreads();
+  AMT_STAMP(2);
+
+  // ---- row phase 1: dD = LN'(dln) for every tile row (zero outside the clip), in place over dln
+  // column-sum accumulators in record order: [0] lnw, [1] lnb, [2..8] the seven taps, [9] conv bias, [10] gamma
+  float wk[7][8], cs[11][8];
+  float (&alw)[8] = cs[0], (&alb)[8] = cs[1], (&ab)[8] = cs[9], (&ag)[8] = cs[10];
+  float (&aw)[7][8] = *reinterpret_cast<float (*)[7][8]>(&cs[2]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int q = 0; q < 11; ++q) cs[q][i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) wk[k][i] = a.wdw[k * C + sub * 8 + i];
+  }
+  {
+    float bv[8], wv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { bv[i] = a.bdw[sub * 8 + i]; wv[i] = a.lnw[sub * 8 + i]; }
+#pragma unroll
+    for (int pp = 0; pp < TT / RPP; ++pp) {
+      const int p = pp * RPP + prow;
+      const int l = l0 - 3 + p;
+      const bool valid = l >= 0 && l < L;
+      const int lc = l < 0 ? 0 : (l >= L ? L - 1 : l);
+      const float mu = a.mean[rb + lc], rs = a.rstd[rb + lc];
+      float d[8], dl[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d[i] = bv[i];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {     // x[l + k - 3] = Xt row p + k (zero outside the clip)
+        float x[8];
+        load8f(Xt + (p + k) * LDX + sub * 8, x);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] += wk[k][i] * x[i];
+      }
+      load8f(DLs + p * LDX + sub * 8, dl);
+      const float fin = (valid && p >= 3 && p < TL + 3) ? 1.f : 0.f;
+      float s1 = 0.f, s2 = 0.f, gy[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        d[i] = (d[i] - mu) * rs;
+        gy[i] = dl[i] * wv[i];
+        s1 += gy[i];
+        s2 += gy[i] * d[i];
+        alw[i] += fin * dl[i] * d[i];
+        alb[i] += fin * dl[i];
+      }
+      s1 = group_sum<LPR>(s1) * (1.f / C);
+      s2 = group_sum<LPR>(s2) * (1.f / C);
+      const float fv = valid ? 1.f : 0.f;
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = fv * rs * (gy[i] - s1 - d[i] * s2);
+      store8f(DLs + p * LDX + sub * 8, o);
+    }
+  }
+  __syncthreads();
+  AMT_STAMP(3);
+
+  // ---- row phase 2 (interior rows): dx = dy + conv^T(dD); depthwise weight / bias / gamma gradients
+#pragma unroll
+  for (int pp = 0; pp < (TL + RPP - 1) / RPP; ++pp) {
+    const int i0 = pp * RPP + prow;
+    const int l = l0 + i0;
+    const bool valid = (i0 < TL) && (l < L);
+    const int i0c = i0 < TL ? i0 : TL - 1;
+    const int lcl = l < L ? l : L - 1;
+    const float fv = valid ? 1.f : 0.f;
+    float o[8], dd[8];
+    load8f(DYs + (i0c + 3) * LDX + sub * 8, o);
+    load8f(DLs + (i0c + 3) * LDX + sub * 8, dd);
+    if (a.Z != nullptr) {
+      float z[8];
+      load8f(reinterpret_cast<const T*>(a.Z) + (rb + lcl) * C + sub * 8, z);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ag[i] += fv * o[i] * z[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dd[i] *= fv; ab[i] += dd[i]; }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      float tq[8], x[8];
+      load8f(DLs + (i0c + 6 - k) * LDX + sub * 8, tq);   // dD[l - k + 3]
+      load8f(Xt + (i0c + 3 + k) * LDX + sub * 8, x);     // x[l + k - 3]
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { o[i] += wk[k][i] * tq[i]; aw[k][i] += dd[i] * x[i]; }
+    }
+    if (valid) store8f(reinterpret_cast<T*>(a.dX) + (rb + l) * C + sub * 8, o);
+  }
+
+  AMT_STAMP(4);
+  // ---- the eleven column sums of this workgroup -> its record [lnw | lnb | taps 7C | bias | gamma]
+  __syncthreads();            // every wave is done with the panels the slices alias
+  fold_columns<LPR, 88>(*reinterpret_cast<float (*)[88]>(&cs[0][0]), part + wave * 11 * C, C, lane);
+  __syncthreads();
+  float* rec = a.rec + (size_t)blockIdx.x * a.rec_stride;
+  const int nrec = a.Z != nullptr ? 11 * C : 10 * C;
+  for (int t = tid; t < nrec; t += 256)
+    rec[t] = (part[t] + part[11 * C + t]) + (part[22 * C + t] + part[33 * C + t]);
+  AMT_STAMP(5);
+  AMT_STAMP_RT(7);
+}
+
+template <typename T, int C>
+static void block_bwd_fused_launch(hipStream_t s, const BlockBwdArgs& a) {
+  constexpr int TT = BlockBwdTile<T, C>::TT;
+  constexpr size_t lds = sizeof(T) * ((size_t)TT * (2 * (C + 8) + (2 * C + 8)) + (size_t)(TT + 6) * (C + 8));
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool once = (lds > 64 * 1024
+                          ? (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block_bwd_fused_kernel<T, C, TT>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                          : (void)0,
+                      true);
+  (void)once;
+  hipLaunchKernelGGL((block_bwd_fused_kernel<T, C, TT>), dim3(a.B * a.tiles_per_clip), dim3(256), lds, s, a);
+}
+
+int block_bwd_fused_tile_len(DType dt, int C) {
+  if (dt == DT_F32) return (C <= 32 ? 128 : (C <= 64 ? 64 : (C == 256 ? 16 : 32))) - 6;
+  return (C <= 32 ? 128 : (C <= 64 ? 64 : 32)) - 6;
+}
+
+void block_bwd_fused(hipStream_t s, DType dt, const BlockBwdArgs& a_in, float* dlnw, float* dlnb, float* dwdw,
+                     float* dbdw, float* dgamma, PartialSink* sink) {
+  BlockBwdArgs a = a_in;
+  const int C = a.C, TL = block_bwd_fused_tile_len(dt, C);
+  a.tiles_per_clip = (a.L + TL - 1) / TL;
+  const int nb = a.B * a.tiles_per_clip;
+  const int rec = 11 * C;
+  size_t o = sink->take((size_t)nb * rec);
+  sink->add(o, nb, rec, C, dlnw);
+  sink->add(o + C, nb, rec, C, dlnb);
+  sink->add(o + 2 * C, nb, rec, 7 * C, dwdw);
+  sink->add(o + 9 * C, nb, rec, C, dbdw);
+  if (dgamma) sink->add(o + 10 * C, nb, rec, C, dgamma);
+  if (sink->dry) return;
+  a.rec = sink->ws + o;
+  a.rec_stride = rec;
+  const double N = (double)a.B * a.L, es = dt == DT_F32 ? 4 : 2;
+  ProfScope ps(s, "block_bwd_fused", 2.0 * N * (21.0 * C + 4.0 * C * C), (8.0 * N * C + 4.0 * C * C) * es);
+#define AMT_BB_CASE(CC_)                                                  \
+  case CC_:                                                               \
+    if (dt == DT_F32) block_bwd_fused_launch<float, CC_>(s, a);           \
+    else block_bwd_fused_launch<bf16, CC_>(s, a);                         \
+    break
+  switch (C) {
+    AMT_BB_CASE(16);
+    AMT_BB_CASE(32);
+    AMT_BB_CASE(64);
+    AMT_BB_CASE(128);
+    AMT_BB_CASE(256);
+    default: break;
+  }
+#undef AMT_BB_CASE
 }
 
 }  // namespace amt

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void dwln_bwd_kernel(const T* __restrict__ dY,
                                                        int L, int pstride) {
   using R = RowCfg<C>;
   constexpr int VEC = R::VEC, LPR = R::LPR;
-  __shared__ float smem[C];
+  __shared__ float smem[4 * C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPR, rw = lane / LPR;
   float wk[7][VEC], bv[VEC], wv[VEC], aw[VEC], ab[VEC];
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
                                                          int L, int pstride) {
   using R = RowCfg<C>;
   constexpr int VEC = R::VEC, LPR = R::LPR;
-  __shared__ float smem[C];
+  __shared__ float smem[4 * C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPR, rw = lane / LPR;
   float wk[7][VEC], aw[7][VEC], ab[VEC];
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void scale_bwd_kernel(const T* __restrict__ dY
                                                         float* __restrict__ dgamma, long N, int pstride) {
   using R = RowCfg<C>;
   constexpr int VEC = R::VEC, LPR = R::LPR;
-  __shared__ float smem[C];
+  __shared__ float smem[4 * C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPR, rw = lane / LPR;
   float gv[VEC], ag[VEC];

@@ -220,6 +220,15 @@ AMT_DEV void xrow32(float v, float& a, float& b) {
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(x), "+v"(y));
   a = x; b = y;
 }
+// two-register forms: x = [x.r0, y.r0, x.r2, y.r2], y = [x.r1, y.r1, x.r3, y.r3] (rows of 16 lanes) and
+// x = [x.lo, y.lo], y = [x.hi, y.hi] (halves of 32 lanes).  x + y then holds the pairwise row / half sums
+// of BOTH inputs: one swap reduces two values (fold_columns in chain.h).
+AMT_DEV void swap16(float& x, float& y) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(x), "+v"(y));
+}
+AMT_DEV void swap32(float& x, float& y) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(x), "+v"(y));
+}
 AMT_DEV float sum_xor16(float v) { float a, b; xrow16(v, a, b); return a + b; }
 AMT_DEV float sum_xor32(float v) { float a, b; xrow32(v, a, b); return a + b; }
 AMT_DEV float max_xor16(float v) { float a, b; xrow16(v, a, b); return fmaxf(a, b); }

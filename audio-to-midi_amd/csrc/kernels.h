@@ -132,6 +132,21 @@ struct BlockFwdArgs {
 };
 void block_fwd_fused(hipStream_t s, DType dt, const BlockFwdArgs& a);
 
+// Data-gradient chain of a Block (C >= 16) in one launch: du, dln (LDS only), dD, dx and the per-workgroup
+// records of dlnw, dlnb, dwdw[7][C], dbdw, dgamma (summed by reduce_partials; `sink` is mandatory).
+// W2tg [2C][C] (pw2^T, columns scaled by gamma) and W1t [C][2C] are fragment-PACKED T copies.
+struct BlockBwdArgs {
+  const void* dY; const void* X; const void* U; const void* Z;   // Z may be null (no dgamma)
+  const void* W2tg; const void* W1t;
+  const float* wdw; const float* bdw; const float* lnw; const float* mean; const float* rstd;
+  void* dU; void* dX;
+  float* rec; int rec_stride;      // set by the launcher
+  int B, L, C, tiles_per_clip;     // tiles_per_clip set by the launcher
+  int dbg_slot;
+};
+void block_bwd_fused(hipStream_t s, DType dt, const BlockBwdArgs& a, float* dlnw, float* dlnb, float* dwdw,
+                     float* dbdw, float* dgamma, PartialSink* sink);
+
 // ----------------------------------------------------------------------------- attention
 struct AttnArgs {
   const void* QC; int ldqc;   // q = QC[:, 0:256] (un-roped)

@@ -36,6 +36,7 @@ struct BlockP {  // offsets into the flat fp32 vector
   size_t c_pw1, c_pw1t, c_pw2, c_pw2t;  // compute-copy offsets (elements of T)
   size_t c_pw2tg;                       // pw2^T with its columns scaled by gamma (layer scale folded)
   size_t c_pw1p, c_pw2p;                // fragment-packed copies for the chain kernels (C >= 16)
+  size_t c_pw2tgp, c_pw1tp;             // packed pw2^T * gamma and pw1^T (backward chain)
 };
 struct StageP {
   int C, Cin, depth;
@@ -142,10 +143,14 @@ Layout build_layout(const amt_config& c) {
       cpair(b.pw2_w, C, 2 * C, b.c_pw2, b.c_pw2t);
       b.c_pw2tg = cbuf((size_t)2 * C * C);
       L.conv.push_back(ConvDesc{b.pw2_w, b.c_pw2tg, 2 * C, C, C, 1, (long long)b.gamma, 0});
-      b.c_pw1p = b.c_pw2p = 0;
+      b.c_pw1p = b.c_pw2p = b.c_pw2tgp = b.c_pw1tp = 0;
       if (C >= 16) {
         b.c_pw1p = cpacked(b.pw1_w, 2 * C, C);
         b.c_pw2p = cpacked(b.pw2_w, C, 2 * C);
+        b.c_pw2tgp = cbuf(chain_packed_elems(2 * C, C));
+        L.conv.push_back(ConvDesc{b.pw2_w, b.c_pw2tgp, 2 * C, C, C, 1, (long long)b.gamma, 1});
+        b.c_pw1tp = cbuf(chain_packed_elems(C, 2 * C));
+        L.conv.push_back(ConvDesc{b.pw1_w, b.c_pw1tp, C, 2 * C, 2 * C, 1, -1, 1});
       }
       st.blocks.push_back(b);
     }
@@ -519,6 +524,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   sink.dry = dry;
   if (dry) { c->part_descs.clear(); sink.descs = &c->part_descs; }
 
+  int dbg_bwd = 0;   // micro-benchmark builds only (AMT_CHAIN_TIMING)
   auto G = [&](size_t off) { return grads + off; };
   std::vector<WgradArgs> pending, pending_skinny;
   auto wgrad = [&](const void* Gm, int ldg, const void* Am, int lda, int n, int M, int Kp, size_t w_off, int ldw,
@@ -703,6 +709,20 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       // and dgamma = sum dy * z is formed in the fused tail kernel.
       wgrad(dy, C, bs.h, 2 * C, Nn, C, 2 * C, bp.pw2_w, 2 * C, (long)bp.pw2_b, 0, c->P(bp.gamma));
       void* du = A.alloc((size_t)Nn * 2 * C * es);
+      if (c->fuse && C >= 16) {
+        wgrad(du, 2 * C, bs.ln, C, Nn, 2 * C, C, bp.pw1_w, C, (long)bp.pw1_b, 0);
+        di = (di + 1) % 3;
+        void* dx = dbuf[di];
+        BlockBwdArgs ba;
+        memset(&ba, 0, sizeof(ba));
+        ba.dY = dy; ba.X = bs.x; ba.U = bs.u; ba.Z = bs.z; ba.W2tg = c->WC(bp.c_pw2tgp); ba.W1t = c->WC(bp.c_pw1tp);
+        ba.wdw = c->P(bp.dw_w); ba.bdw = c->P(bp.dw_b); ba.lnw = c->P(bp.ln_w); ba.mean = bs.mean; ba.rstd = bs.rstd;
+        ba.dU = du; ba.dX = dx; ba.B = B; ba.L = Lcur; ba.C = C; ba.dbg_slot = 64 + dbg_bwd++;
+        block_bwd_fused(s, dt, ba, G(bp.ln_w), G(bp.ln_b), G(bp.dw_w), G(bp.dw_b), G(bp.gamma), &sink);
+        dcur = dx;
+        end_scope();
+        continue;
+      }
       void* dln = A.alloc((size_t)Nn * C * es);
       if (C <= 8) {
         RUN(block_small_bwd(s, dt, dy, bs.u, c->WC(bp.c_pw2tg), c->WC(bp.c_pw1t), du, dln, (long)Nn, C));

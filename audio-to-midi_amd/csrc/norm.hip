@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dY, c
                                                      float* __restrict__ db, int N, int pstride) {
   using R = RowCfg<C>;
   constexpr int VEC = R::VEC, LPR = R::LPR;
-  __shared__ float smem[C];
+  __shared__ float smem[4 * C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPR, rw = lane / LPR;
   float wv[VEC], aw[VEC], ab[VEC];

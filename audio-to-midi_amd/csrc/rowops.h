@@ -20,26 +20,26 @@ template <int VEC, int LPR>
 // pstride == 0: atomicAdd into gdst[0..C).  pstride > 0: plain store into this block's record,
 // gdst[blockIdx.x * pstride + 0..C) — the records are summed once per step by reduce_partials,
 // which removes the same-address atomic contention of hundreds of blocks.
-AMT_DEV void reduce_cols_to_global(const float (&acc)[VEC], float* gdst, float* smem /* >= VEC*LPR floats */,
+AMT_DEV void reduce_cols_to_global(const float (&acc)[VEC], float* gdst, float* smem /* >= 4*VEC*LPR floats */,
                                    int pstride = 0) {
+  // every wave stores its column totals into its own slice and the four slices are summed after a
+  // barrier: LDS float atomics cost ~3.6 cycles per lane-add (measured in chain.hip: 20 k cycles per
+  // workgroup for 88 accumulators), plain stores are free by comparison
   constexpr int C = VEC * LPR;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPR, rw = lane / LPR;
-  __syncthreads();
-  for (int t = tid; t < C; t += 256) smem[t] = 0.f;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     float v = strided_sum<LPR>(acc[i]);
-    if (rw == 0) atomicAdd(&smem[sub * VEC + i], v);
+    if (rw == 0) smem[wave * C + sub * VEC + i] = v;
   }
   __syncthreads();
   if (gdst != nullptr) {
-    if (pstride > 0) {
-      float* rec = gdst + (size_t)blockIdx.x * pstride;
-      for (int t = tid; t < C; t += 256) rec[t] = smem[t];
-    } else {
-      for (int t = tid; t < C; t += 256) atomicAdd(&gdst[t], smem[t]);
+    for (int t = tid; t < C; t += 256) {
+      const float sum = (smem[t] + smem[C + t]) + (smem[2 * C + t] + smem[3 * C + t]);
+      if (pstride > 0) gdst[(size_t)blockIdx.x * pstride + t] = sum;
+      else atomicAdd(&gdst[t], sum);
     }
   }
 }

@@ -34,11 +34,11 @@ if os.environ.get("PREDICT") == "1":
         model.predict(None, audio)
 torch.cuda.synchronize()
 L = amtlib.load()
-buf = np.zeros((64, 256, 8), dtype=np.uint64)
+buf = np.zeros((128, 256, 8), dtype=np.uint64)
 rc = L.amt_debug_read_stamps(C.c_void_p(buf.ctypes.data))
 print("rc", rc)
 prev_end = None
-for slot in range(64):
+for slot in range(128):
     s = buf[slot]
     live = s[:, 0] > 0
     if not live.any():
