@@ -10,6 +10,7 @@
 #include "kernels.h"
 #include "prof.h"
 #include "rowops.h"
+#include "wgrad.h"
 
 // Phase timestamps for the micro-benchmark (scratch/chain_bench.hip): compiled out of the library.
 #ifdef AMT_CHAIN_TIMING
@@ -280,7 +281,7 @@ template <typename T, int C> struct BlockBwdTile {   // == DwTile<C>::ROWS of th
 };
 
 template <typename T, int C, int TT>
-__global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a) {
+__global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a, WgradGroup riders) {
   constexpr int H2 = 2 * C, LDX = C + 8, LDH = H2 + 8, TL = TT - 6;
   constexpr int LPR = C / 8, RPP = 256 / LPR;
   static_assert(TT % RPP == 0, "row phases cover the tile in whole passes");
@@ -288,6 +289,10 @@ __global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a) {
   using SB = ChainSplit<C, TT>;
   constexpr int KCA = ChainChunk<T, SA::RB, C>::KC, KCB = ChainChunk<T, SB::RB, H2>::KC;
   extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  if ((int)blockIdx.x >= a.n_chain) {   // weight gradients of the previous scope ride on this launch
+    wgrad_group_dispatch<T>(riders, (int)blockIdx.x - a.n_chain, chain_smem);
+    return;
+  }
   T* DYs = reinterpret_cast<T*>(chain_smem);           // [TT][LDX]      dy (zero outside the clip)
   T* Us = DYs + TT * LDX;                              // [TT][LDH]      u, then du in place
   T* DLs = Us + TT * LDH;                              // [TT][LDX]      dln, then dD in place
@@ -496,9 +501,10 @@ __global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a) {
 }
 
 template <typename T, int C>
-static void block_bwd_fused_launch(hipStream_t s, const BlockBwdArgs& a) {
+static void block_bwd_fused_launch(hipStream_t s, const BlockBwdArgs& a, const WgradGroup& riders, int n_rider_wgs) {
   constexpr int TT = BlockBwdTile<T, C>::TT;
-  constexpr size_t lds = sizeof(T) * ((size_t)TT * (2 * (C + 8) + (2 * C + 8)) + (size_t)(TT + 6) * (C + 8));
+  constexpr size_t lds_chain = sizeof(T) * ((size_t)TT * (2 * (C + 8) + (2 * C + 8)) + (size_t)(TT + 6) * (C + 8));
+  constexpr size_t lds = lds_chain > TnLds<T>::BYTES ? lds_chain : TnLds<T>::BYTES;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool once = (lds > 64 * 1024
                           ? (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block_bwd_fused_kernel<T, C, TT>),
@@ -506,7 +512,7 @@ static void block_bwd_fused_launch(hipStream_t s, const BlockBwdArgs& a) {
                           : (void)0,
                       true);
   (void)once;
-  hipLaunchKernelGGL((block_bwd_fused_kernel<T, C, TT>), dim3(a.B * a.tiles_per_clip), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((block_bwd_fused_kernel<T, C, TT>), dim3(a.n_chain + n_rider_wgs), dim3(256), lds, s, a, riders);
 }
 
 int block_bwd_fused_tile_len(DType dt, int C) {
@@ -515,7 +521,7 @@ int block_bwd_fused_tile_len(DType dt, int C) {
 }
 
 void block_bwd_fused(hipStream_t s, DType dt, const BlockBwdArgs& a_in, float* dlnw, float* dlnb, float* dwdw,
-                     float* dbdw, float* dgamma, PartialSink* sink) {
+                     float* dbdw, float* dgamma, PartialSink* sink, const WgradArgs* riders, int n_riders) {
   BlockBwdArgs a = a_in;
   const int C = a.C, TL = block_bwd_fused_tile_len(dt, C);
   a.tiles_per_clip = (a.L + TL - 1) / TL;
@@ -527,15 +533,20 @@ void block_bwd_fused(hipStream_t s, DType dt, const BlockBwdArgs& a_in, float* d
   sink->add(o + 2 * C, nb, rec, 7 * C, dwdw);
   sink->add(o + 9 * C, nb, rec, C, dbdw);
   if (dgamma) sink->add(o + 10 * C, nb, rec, C, dgamma);
+  WgradGroup rg;
+  double rfl = 0, rby = 0;
+  const int n_rider_wgs = wgrad_group_prepare(dt, riders, n_riders, sink, &rg, &rfl, &rby);
   if (sink->dry) return;
   a.rec = sink->ws + o;
   a.rec_stride = rec;
+  a.n_chain = nb;
   const double N = (double)a.B * a.L, es = dt == DT_F32 ? 4 : 2;
-  ProfScope ps(s, "block_bwd_fused", 2.0 * N * (21.0 * C + 4.0 * C * C), (8.0 * N * C + 4.0 * C * C) * es);
+  ProfScope ps(s, n_rider_wgs > 0 ? "block_bwd_fused+wgrad" : "block_bwd_fused",
+               2.0 * N * (21.0 * C + 4.0 * C * C) + rfl, (8.0 * N * C + 4.0 * C * C) * es + rby);
 #define AMT_BB_CASE(CC_)                                                  \
   case CC_:                                                               \
-    if (dt == DT_F32) block_bwd_fused_launch<float, CC_>(s, a);           \
-    else block_bwd_fused_launch<bf16, CC_>(s, a);                         \
+    if (dt == DT_F32) block_bwd_fused_launch<float, CC_>(s, a, rg, n_rider_wgs);   \
+    else block_bwd_fused_launch<bf16, CC_>(s, a, rg, n_rider_wgs);                 \
     break
   switch (C) {
     AMT_BB_CASE(16);

@@ -10,6 +10,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
+#include "wgrad.h"
 #include <string>
 #include <cstring>
 #include <cstdlib>
@@ -278,146 +279,19 @@ void gemm_nt(hipStream_t s, DType dt, EpiKind epi, const GemmArgs& a) {
   if (dt == DT_F32) dispatch_nt<float>(s, epi, a); else dispatch_nt<bf16>(s, epi, a);
 }
 
-// ------------------------------------------------------------------ gemm_tn_wgrad
-// dW[m][k] += sum_n G[n][m] A[n][k].  Tokens are the MFMA K axis, so both operands are read as
-// COLUMNS of row-major LDS tiles.  Workgroup tile 64 (m) x 64 (k); the token range is split over
-// blockIdx.y and partial tiles are combined with fp32 atomics (unordered: last-bit differences
-// between runs are expected).
-constexpr int WLD = 72;   // LDS row stride (elements) for the [32 tokens][64 features] tiles
-
-template <typename T>
-AMT_DEV Chunk8<T> load_f_chunk(const T* rowp, int f, int F) {
-  if (f + 8 <= F) return chunk_load(rowp + f);
-  if (f + 4 <= F) return chunk_load4(rowp + f);
-  return chunk_zero<T>();
-}
-
-template <typename T>
-AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx, int by) {
-  // TOK tokens per LDS stage (4 MFMA k-steps for bf16): every thread keeps 8 sixteen-byte loads in
-  // flight per stage, so a split of a few hundred tokens costs 2-4 memory round trips instead of
-  // one per 32 tokens.  One LDS buffer + register prefetch of the next stage.
-  constexpr int TOK = sizeof(T) == 2 ? 128 : 64;
-  constexpr int NCH = TOK * 8 / 256;          // chunks per thread per operand per stage
-  __shared__ __attribute__((aligned(16))) T Gs[TOK][WLD];
-  __shared__ __attribute__((aligned(16))) T As[TOK][WLD];
-  __shared__ float red[32][65];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, g = lane >> 4;
-  const int wm = wave >> 1, wk = wave & 1;
-  const int m0 = (bx / tiles_k) * 64, k0 = (bx % tiles_k) * 64;
-  const int nbeg = by * rows_per_split;
-  const int nend = min(a.N, nbeg + rows_per_split);
-  const T* G = reinterpret_cast<const T*>(a.G);
-  const T* A = reinterpret_cast<const T*>(a.A);
-  const bool do_bias = (a.dbias != nullptr) && (bx % tiles_k == 0);
-  const int Mst = a.M_store > 0 ? a.M_store : a.M;
-
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
-
-  const int lrow = tid >> 3, lc = tid & 7;   // thread covers rows lrow + 32 i, chunk lc
-  Chunk8<T> gr[NCH], ar[NCH];
-  auto load_tiles = [&](int nb) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      int n = nb + lrow + 32 * i;
-      bool ok = n < nend;
-      gr[i] = ok ? load_f_chunk(G + (size_t)n * a.ldg, m0 + 8 * lc, a.M) : chunk_zero<T>();
-      ar[i] = ok ? load_f_chunk(A + (size_t)n * a.lda, k0 + 8 * lc, a.Kp) : chunk_zero<T>();
-    }
-  };
-  auto store_tiles = [&]() {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      chunk_store(&Gs[lrow + 32 * i][8 * lc], gr[i]);
-      chunk_store(&As[lrow + 32 * i][8 * lc], ar[i]);
-      if (do_bias) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bsum[e] += chunk_get(gr[i], e);
-      }
-    }
-  };
-
-  const int nsteps = (nend - nbeg + TOK - 1) / TOK;
-  if (nsteps > 0) load_tiles(nbeg);
-  for (int st = 0; st < nsteps; ++st) {
-    __syncthreads();                 // previous stage fully consumed
-    store_tiles();
-    __syncthreads();
-    if (st + 1 < nsteps) load_tiles(nbeg + (st + 1) * TOK);
-#pragma unroll
-    for (int kk = 0; kk < TOK / 32; ++kk) {
-      Frag<T> gf[2], af[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) gf[i] = frag_col16(&Gs[32 * kk + 8 * g][wm * 32 + i * 16], WLD, r);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) af[j] = frag_col16(&As[32 * kk + 8 * g][wk * 32 + j * 16], WLD, r);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) mma(acc[i][j], gf[i], af[j]);
-    }
-  }
-
-  // acc[i][j][e] = dW[m0 + wm*32 + i*16 + 4g + e][k0 + wk*32 + j*16 + r]
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int k = k0 + wk * 32 + j * 16 + r;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int m = m0 + wm * 32 + i * 16 + 4 * g + e;
-        if (m < Mst && k < a.Kp) {
-          float v = acc[i][j][e];
-          if (a.row_scale) v *= a.row_scale[m];
-          if (a.part) a.part[(size_t)by * a.part_stride + (size_t)m * a.Kp + k] = v;
-          else atomicAdd(&a.dW[(size_t)m * a.ldw + k], v);
-        }
-      }
-    }
-
-  if (do_bias) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) red[lrow][8 * lc + i] = bsum[i];
-    __syncthreads();
-    if (tid < 64) {
-      float s = 0.f;
-#pragma unroll 8
-      for (int q = 0; q < 32; ++q) s += red[q][tid];
-      int m = m0 + tid;
-      if (m < Mst) {
-        if (a.row_scale) s *= a.row_scale[m];
-        if (a.part) a.part[(size_t)by * a.part_stride + (size_t)Mst * a.Kp + m] = s;
-        else atomicAdd(&a.dbias[m], s);
-      }
-    }
-  }
-}
-
+// ------------------------------------------------------------------ gemm_tn_wgrad (body: wgrad.h)
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs a, int tiles_k, int rows_per_split) {
-  tn_body<T>(a, tiles_k, rows_per_split, blockIdx.x, blockIdx.y);
+  extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
+  tn_body<T>(a, tiles_k, rows_per_split, blockIdx.x, blockIdx.y, tn_smem);
 }
 
 // several independent weight-gradient problems in ONE launch (all wgrads of a transformer layer or
-// of a CNN block): blockIdx.x -> (problem, tile, token split)
+// of a CNN block)
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_tn_group_kernel(WgradGroup g) {
-  const int b = blockIdx.x;
-  int i = 0;
-  while (i + 1 < g.n && b >= g.prefix[i + 1]) ++i;
-  const int local = b - g.prefix[i];
-  tn_body<T>(g.p[i], g.tiles_k[i], g.rps[i], local % g.tiles[i], local / g.tiles[i]);
+  extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
+  wgrad_group_dispatch<T>(g, blockIdx.x, tn_smem);
 }
 
 void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a_in, PartialSink* sink) {
@@ -442,8 +316,8 @@ void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a_in, PartialSink* 
     ProfScope ps(s, dt == DT_F32 ? "gemm_tn_wgrad_skinny<f32>" : "gemm_tn_wgrad_skinny<bf16>",
                  2.0 * a.N * (double)a.M * a.Kp, ((double)a.N * a.M + (double)a.N * a.Kp) * (dt == DT_F32 ? 4 : 2));
     dim3 grid(1, splits);
-    if (dt == DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, s, a, 1, rps);
-    else hipLaunchKernelGGL((gemm_tn_kernel<bf16>), grid, dim3(256), 0, s, a, 1, rps);
+    if (dt == DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), TnLds<float>::BYTES, s, a, 1, rps);
+    else hipLaunchKernelGGL((gemm_tn_kernel<bf16>), grid, dim3(256), TnLds<bf16>::BYTES, s, a, 1, rps);
     return;
   }
   if (sink && sink->dry) return;
@@ -462,29 +336,50 @@ void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a_in, PartialSink* 
   ProfScope ps(s, dt == DT_F32 ? "gemm_tn_wgrad<f32>" : "gemm_tn_wgrad<bf16>", 2.0 * a.N * (double)a.M * a.Kp,
                ((double)a.N * a.M + (double)a.N * a.Kp) * es + (double)a.M * a.Kp * 4);
   if (dt == DT_F32)
-    hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, s, a, tiles_k, rps);
+    hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), TnLds<float>::BYTES, s, a, tiles_k, rps);
   else
-    hipLaunchKernelGGL((gemm_tn_kernel<bf16>), grid, dim3(256), 0, s, a, tiles_k, rps);
+    hipLaunchKernelGGL((gemm_tn_kernel<bf16>), grid, dim3(256), TnLds<bf16>::BYTES, s, a, tiles_k, rps);
 }
 
-void gemm_tn_wgrad_group(hipStream_t s, DType dt, const WgradArgs* probs, int n, PartialSink* sink) {
-  if (n <= 0) return;
-  if (sink && sink->dry) return;
-  if (n == 1) { gemm_tn_wgrad(s, dt, probs[0], nullptr); return; }
-  WgradGroup g;
+// Fills `g` for up to 8 problems and returns the number of workgroups (0: nothing to launch, e.g.
+// while planning).  One-tile problems with a very long token axis ("skinny", C <= 32 blocks) get many
+// short splits that write per-split records into the sink instead of atomics.
+int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* sink, WgradGroup* gp, double* flops,
+                        double* bytes) {
+  WgradGroup& g = *gp;
   memset(&g, 0, sizeof(g));
+  if (n <= 0) return 0;
   g.n = n;
   int total_tiles = 0;
+  bool skinny[8];
   for (int i = 0; i < n; ++i) {
     g.p[i] = probs[i];
     g.tiles_k[i] = (probs[i].Kp + 63) / 64;
     g.tiles[i] = ((probs[i].M + 63) / 64) * g.tiles_k[i];
-    total_tiles += g.tiles[i];
+    skinny[i] = sink && g.tiles[i] == 1 && probs[i].N >= 16384 && probs[i].ldw == probs[i].Kp;
+    if (!skinny[i]) total_tiles += g.tiles[i];
   }
   double fl = 0, by = 0;
   const double es = dt == DT_F32 ? 4 : 2;
   for (int i = 0; i < n; ++i) {
-    const WgradArgs& a = probs[i];
+    WgradArgs& a = g.p[i];
+    fl += 2.0 * a.N * (double)a.M * a.Kp;
+    by += ((double)a.N * a.M + (double)a.N * a.Kp) * es + (double)a.M * a.Kp * 4;
+    if (skinny[i]) {
+      const int Mst = a.M_store > 0 ? a.M_store : a.M;
+      int rps = 256;
+      int splits = (a.N + rps - 1) / rps;
+      if (splits > 1024) { splits = 1024; rps = ((a.N + splits - 1) / splits + 127) / 128 * 128; splits = (a.N + rps - 1) / rps; }
+      const size_t rec = (size_t)Mst * a.Kp + (a.dbias ? Mst : 0);
+      size_t o = sink->take((size_t)splits * rec);
+      sink->add(o, splits, (uint32_t)rec, (uint32_t)(Mst * a.Kp), a.dW);
+      if (a.dbias) sink->add(o + (size_t)Mst * a.Kp, splits, (uint32_t)rec, (uint32_t)Mst, a.dbias);
+      a.part = sink->dry ? nullptr : sink->ws + o;
+      a.part_stride = (int)rec;
+      g.rps[i] = rps;
+      g.prefix[i + 1] = g.prefix[i] + splits;
+      continue;
+    }
     // few token splits: every split adds M*Kp*4 bytes of fp32 atomics and the chip-wide atomic rate
     // (~1.3 TB/s) was the bound at 1536 workgroups (38 us per layer group vs 24 us at ~224)
     static const int target_wgs = getenv("AMT_WGRAD_TARGET_WGS") ? atoi(getenv("AMT_WGRAD_TARGET_WGS")) : 224;
@@ -497,13 +392,23 @@ void gemm_tn_wgrad_group(hipStream_t s, DType dt, const WgradArgs* probs, int n,
     splits = (a.N + rps - 1) / rps;
     g.rps[i] = rps;
     g.prefix[i + 1] = g.prefix[i] + g.tiles[i] * splits;
-    fl += 2.0 * a.N * (double)a.M * a.Kp;
-    by += ((double)a.N * a.M + (double)a.N * a.Kp) * es + (double)a.M * a.Kp * 4;
   }
+  if (flops) *flops = fl;
+  if (bytes) *bytes = by;
+  if (sink && sink->dry) return 0;
+  return g.prefix[n];
+}
+
+void gemm_tn_wgrad_group(hipStream_t s, DType dt, const WgradArgs* probs, int n, PartialSink* sink) {
+  if (n <= 0) return;
+  if (n == 1) { gemm_tn_wgrad(s, dt, probs[0], sink); return; }
+  WgradGroup g;
+  double fl = 0, by = 0;
+  const int nwg = wgrad_group_prepare(dt, probs, n, sink, &g, &fl, &by);
+  if (nwg <= 0) return;
   ProfScope ps(s, dt == DT_F32 ? "gemm_tn_wgrad_group<f32>" : "gemm_tn_wgrad_group<bf16>", fl, by);
-  dim3 grid(g.prefix[n]);
-  if (dt == DT_F32) hipLaunchKernelGGL((gemm_tn_group_kernel<float>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm_tn_group_kernel<bf16>), grid, dim3(256), 0, s, g);
+  if (dt == DT_F32) hipLaunchKernelGGL((gemm_tn_group_kernel<float>), dim3(nwg), dim3(256), TnLds<float>::BYTES, s, g);
+  else hipLaunchKernelGGL((gemm_tn_group_kernel<bf16>), dim3(nwg), dim3(256), TnLds<bf16>::BYTES, s, g);
 }
 
 }  // namespace amt

@@ -56,6 +56,11 @@ void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a, PartialSink* sin
 // up to 8 independent problems in one launch
 struct WgradGroup { int n; int prefix[9]; int tiles[8]; int tiles_k[8]; int rps[8]; WgradArgs p[8]; };
 void gemm_tn_wgrad_group(hipStream_t s, DType dt, const WgradArgs* probs, int n, PartialSink* sink = nullptr);
+// fills the group (one-tile / long-N problems get per-split records from `sink`); returns the number of
+// workgroups, 0 while planning.  Used by gemm_tn_wgrad_group and by chain kernels that carry the
+// previous scope's weight gradients in extra workgroups of their own launch.
+int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* sink, WgradGroup* g, double* flops = nullptr,
+                        double* bytes = nullptr);
 
 // ----------------------------------------------------------------------------- per-block partial sums
 // Row kernels that produce parameter gradients (LayerNorm w/b, depthwise conv w/b, gamma) can write
@@ -142,10 +147,13 @@ struct BlockBwdArgs {
   void* dU; void* dX;
   float* rec; int rec_stride;      // set by the launcher
   int B, L, C, tiles_per_clip;     // tiles_per_clip set by the launcher
+  int n_chain;                     // workgroups of the chain; the rest of the grid runs `riders` (launcher)
   int dbg_slot;
 };
+// `riders` (may be null / n == 0): weight-gradient problems of the PREVIOUS scope, executed by extra
+// workgroups of this launch (they only feed the gradient buffer, so they leave the dependent chain).
 void block_bwd_fused(hipStream_t s, DType dt, const BlockBwdArgs& a, float* dlnw, float* dlnb, float* dwdw,
-                     float* dbdw, float* dgamma, PartialSink* sink);
+                     float* dbdw, float* dgamma, PartialSink* sink, const WgradArgs* riders = nullptr, int n_riders = 0);
 
 // ----------------------------------------------------------------------------- attention
 struct AttnArgs {

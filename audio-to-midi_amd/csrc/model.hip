@@ -553,16 +553,37 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     if (dry) { c->ev_needed++; return nullptr; }
     return c->ev_pool[c->ev_used++];
   };
-  auto begin_scope = [&]() {
+  // Deferred weight gradients ("riders"): without the side stream, the weight-gradient problems of a
+  // scope are not launched when the scope ends.  If the NEXT scope starts with a chain kernel that can
+  // carry them (block_bwd_fused), they run in extra workgroups of that launch, off the dependent
+  // chain and without a launch of their own; otherwise they are launched when the next scope begins.
+  // The buffers they read stay valid for exactly one more scope (two alternating scratch regions,
+  // three rotating residual-gradient buffers), which is all either form needs.
+  std::vector<WgradArgs> deferred;
+  auto flush_deferred = [&]() {
+    for (size_t i = 0; i < deferred.size(); i += 8) {
+      int cnt = (int)std::min<size_t>(8, deferred.size() - i);
+      gemm_tn_wgrad_group(s, dt, deferred.data() + i, cnt, &sink);
+    }
+    deferred.clear();
+  };
+  auto begin_scope = [&](bool carrier = false) {
     const size_t j = side_done.size();
     if (side_on && j >= 2 && side_done[j - 2] != nullptr) RUN((void)hipStreamWaitEvent(s, side_done[j - 2], 0));
     A.off = mark + (j & 1) * c->scratch_max;
+    if (!carrier || deferred.size() > 8) flush_deferred();
   };
   auto end_scope = [&]() {
     const size_t j = side_done.size();
     const size_t base = mark + (j & 1) * c->scratch_max;
     if (A.off > base && A.off - base > scratch_used) scratch_used = A.off - base;
     hipEvent_t done = nullptr;
+    if (!side_on) {
+      deferred.insert(deferred.end(), pending_skinny.begin(), pending_skinny.end());
+      deferred.insert(deferred.end(), pending.begin(), pending.end());
+      pending.clear();
+      pending_skinny.clear();
+    }
     if (!pending.empty() || !pending_skinny.empty()) {
       if (side_on) {
         hipEvent_t ev = next_event();
@@ -702,7 +723,8 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     for (int j = (int)st.blocks.size() - 1; j >= 0; --j) {
       const BlockP& bp = st.blocks[j];
       const BlockSave& bs = sv.blocks[j];
-      begin_scope();
+      const bool carrier = c->fuse && C >= 16 && !side_on;
+      begin_scope(carrier);
       const void* dy = dcur;
       // layer scale folded away: dz = gamma * dy is never materialised.  The data-gradient GEMM uses a
       // gamma-scaled copy of pw2^T, the pw2 weight/bias gradients are row-scaled in their epilogue
@@ -718,7 +740,9 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
         ba.dY = dy; ba.X = bs.x; ba.U = bs.u; ba.Z = bs.z; ba.W2tg = c->WC(bp.c_pw2tgp); ba.W1t = c->WC(bp.c_pw1tp);
         ba.wdw = c->P(bp.dw_w); ba.bdw = c->P(bp.dw_b); ba.lnw = c->P(bp.ln_w); ba.mean = bs.mean; ba.rstd = bs.rstd;
         ba.dU = du; ba.dX = dx; ba.B = B; ba.L = Lcur; ba.C = C; ba.dbg_slot = 64 + dbg_bwd++;
-        block_bwd_fused(s, dt, ba, G(bp.ln_w), G(bp.ln_b), G(bp.dw_w), G(bp.dw_b), G(bp.gamma), &sink);
+        block_bwd_fused(s, dt, ba, G(bp.ln_w), G(bp.ln_b), G(bp.dw_w), G(bp.dw_b), G(bp.gamma), &sink,
+                        deferred.data(), (int)deferred.size());
+        deferred.clear();
         dcur = dx;
         end_scope();
         continue;
@@ -762,6 +786,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
                    G(st.ln_w), G(st.ln_b), B, T));
     }
   }
+  flush_deferred();
   // train.py:319-322: grads / grad_scale, all-finite flag
   RUN(hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, grads_valid, 1));
   // join: the main stream waits for the side work of the last two scopes (older ones were waited for

@@ -1,0 +1,148 @@
+// Weight-gradient GEMM body shared by gemm.hip (stand-alone launches) and chain.hip (weight-gradient
+// workgroups that ride on a chain kernel's launch).
+#pragma once
+#include "common.h"
+#include "kernels.h"
+
+namespace amt {
+
+// dW[m][k] += sum_n G[n][m] A[n][k].  Tokens are the MFMA K axis, so both operands are read as
+// COLUMNS of row-major LDS tiles.  Workgroup tile 64 (m) x 64 (k); the token range is split over
+// blockIdx.y and partial tiles are combined with fp32 atomics (unordered: last-bit differences
+// between runs are expected).
+constexpr int WLD = 72;   // LDS row stride (elements) for the [32 tokens][64 features] tiles
+
+template <typename T>
+AMT_DEV Chunk8<T> load_f_chunk(const T* rowp, int f, int F) {
+  if (f + 8 <= F) return chunk_load(rowp + f);
+  if (f + 4 <= F) return chunk_load4(rowp + f);
+  return chunk_zero<T>();
+}
+
+template <typename T> struct TnLds {
+  static constexpr int TOK = sizeof(T) == 2 ? 128 : 64;
+  static constexpr size_t BYTES = 2 * sizeof(T) * TOK * WLD + sizeof(float) * 32 * 65;
+};
+
+template <typename T>
+AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx, int by, unsigned char* smem) {
+  // TOK tokens per LDS stage (4 MFMA k-steps for bf16): every thread keeps 8 sixteen-byte loads in
+  // flight per stage, so a split of a few hundred tokens costs 2-4 memory round trips instead of
+  // one per 32 tokens.  One LDS buffer + register prefetch of the next stage.
+  constexpr int TOK = sizeof(T) == 2 ? 128 : 64;
+  constexpr int NCH = TOK * 8 / 256;          // chunks per thread per operand per stage
+  T (*Gs)[WLD] = reinterpret_cast<T (*)[WLD]>(smem);
+  T (*As)[WLD] = reinterpret_cast<T (*)[WLD]>(smem + sizeof(T) * TOK * WLD);
+  float (*red)[65] = reinterpret_cast<float (*)[65]>(smem + 2 * sizeof(T) * TOK * WLD);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wk = wave & 1;
+  const int m0 = (bx / tiles_k) * 64, k0 = (bx % tiles_k) * 64;
+  const int nbeg = by * rows_per_split;
+  const int nend = min(a.N, nbeg + rows_per_split);
+  const T* G = reinterpret_cast<const T*>(a.G);
+  const T* A = reinterpret_cast<const T*>(a.A);
+  const bool do_bias = (a.dbias != nullptr) && (bx % tiles_k == 0);
+  const int Mst = a.M_store > 0 ? a.M_store : a.M;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
+
+  const int lrow = tid >> 3, lc = tid & 7;   // thread covers rows lrow + 32 i, chunk lc
+  Chunk8<T> gr[NCH], ar[NCH];
+  auto load_tiles = [&](int nb) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int n = nb + lrow + 32 * i;
+      bool ok = n < nend;
+      gr[i] = ok ? load_f_chunk(G + (size_t)n * a.ldg, m0 + 8 * lc, a.M) : chunk_zero<T>();
+      ar[i] = ok ? load_f_chunk(A + (size_t)n * a.lda, k0 + 8 * lc, a.Kp) : chunk_zero<T>();
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      chunk_store(&Gs[lrow + 32 * i][8 * lc], gr[i]);
+      chunk_store(&As[lrow + 32 * i][8 * lc], ar[i]);
+      if (do_bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] += chunk_get(gr[i], e);
+      }
+    }
+  };
+
+  const int nsteps = (nend - nbeg + TOK - 1) / TOK;
+  if (nsteps > 0) load_tiles(nbeg);
+  for (int st = 0; st < nsteps; ++st) {
+    __syncthreads();                 // previous stage fully consumed
+    store_tiles();
+    __syncthreads();
+    if (st + 1 < nsteps) load_tiles(nbeg + (st + 1) * TOK);
+#pragma unroll
+    for (int kk = 0; kk < TOK / 32; ++kk) {
+      Frag<T> gf[2], af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) gf[i] = frag_col16(&Gs[32 * kk + 8 * g][wm * 32 + i * 16], WLD, r);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) af[j] = frag_col16(&As[32 * kk + 8 * g][wk * 32 + j * 16], WLD, r);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma(acc[i][j], gf[i], af[j]);
+    }
+  }
+
+  // acc[i][j][e] = dW[m0 + wm*32 + i*16 + 4g + e][k0 + wk*32 + j*16 + r]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int k = k0 + wk * 32 + j * 16 + r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int m = m0 + wm * 32 + i * 16 + 4 * g + e;
+        if (m < Mst && k < a.Kp) {
+          float v = acc[i][j][e];
+          if (a.row_scale) v *= a.row_scale[m];
+          if (a.part) a.part[(size_t)by * a.part_stride + (size_t)m * a.Kp + k] = v;
+          else atomicAdd(&a.dW[(size_t)m * a.ldw + k], v);
+        }
+      }
+    }
+
+  if (do_bias) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[lrow][8 * lc + i] = bsum[i];
+    __syncthreads();
+    if (tid < 64) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int q = 0; q < 32; ++q) s += red[q][tid];
+      int m = m0 + tid;
+      if (m < Mst) {
+        if (a.row_scale) s *= a.row_scale[m];
+        if (a.part) a.part[(size_t)by * a.part_stride + (size_t)Mst * a.Kp + m] = s;
+        else atomicAdd(&a.dbias[m], s);
+      }
+    }
+  }
+}
+
+// several independent weight-gradient problems in one grid: b -> (problem, tile, token split)
+template <typename T>
+AMT_DEV void wgrad_group_dispatch(const WgradGroup& g, int b, unsigned char* smem) {
+  int i = 0;
+  while (i + 1 < g.n && b >= g.prefix[i + 1]) ++i;
+  const int local = b - g.prefix[i];
+  tn_body<T>(g.p[i], g.tiles_k[i], g.rps[i], local % g.tiles[i], local / g.tiles[i], smem);
+}
+
+}  // namespace amt
