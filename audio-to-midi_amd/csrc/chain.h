@@ -77,9 +77,9 @@ AMT_DEV void chain_stage(f32x4 (&acc)[RB][NT], Frag<T> (&w0)[KC][RB], const T* _
 }
 
 // chunk depth: keep at most ~16 (bf16) / ~8 (f32) fragments of a stage in flight per register set
-template <typename T, int RB, int K> struct ChainChunk {
+template <typename T, int RB, int K, int BF16_BUDGET = 16> struct ChainChunk {
   static constexpr int KS = (K + 31) / 32;
-  static constexpr int BUDGET = sizeof(T) == 2 ? 16 : 8;
+  static constexpr int BUDGET = sizeof(T) == 2 ? BF16_BUDGET : 8;
   static constexpr int KC = (BUDGET / RB) < 1 ? 1 : ((BUDGET / RB) > KS ? KS : (BUDGET / RB));
 };
 
@@ -149,6 +149,79 @@ AMT_DEV void fold_columns(float (&v)[NV], float* part, int C, int lane) {
       swap32(a, b);
       const int j = 2 * q + eta;
       part[(j >> 3) * C + sub * 8 + (j & 7)] = a + b;
+    }
+  }
+}
+
+// global rows n0 .. n0 + TT (row-major, W features) -> LDS panel [TT][ld]; rows >= N are zero
+template <typename T, int TT, int W, int LD>
+AMT_DEV void chain_copy_in(T* Ps, const T* __restrict__ G, long n0, long N, int tid) {
+  constexpr int CPR = W / 8;
+  constexpr int TOTAL = TT * CPR;
+#pragma unroll
+  for (int i = 0; i < (TOTAL + 255) / 256; ++i) {
+    const int id = tid + i * 256;
+    const int p = id / CPR, c = id % CPR;
+    if (TOTAL % 256 == 0 || id < TOTAL) {
+      const long row = n0 + p;
+      Chunk8<T> v = chunk_load(G + (row < N ? row : N - 1) * W + 8 * c);
+      if (row >= N) v = chunk_zero<T>();
+      chunk_store(Ps + p * LD + 8 * c, v);
+    }
+  }
+}
+
+// Row LayerNorm over C = 8 * LPR features of the rows of an LDS panel (fp32 statistics, eqx LayerNorm):
+// Ys = LN(Xs) (may alias Xs row-for-row), mean / rstd to global for rows < N.
+template <typename T, int TT, int C, int LD>
+AMT_DEV void chain_ln_rows(const T* Xs, T* Ys, const float* __restrict__ w, const float* __restrict__ b,
+                           float* __restrict__ mean, float* __restrict__ rstd, long n0, long N, int tid) {
+  constexpr int LPR = C / 8, RPP = 256 / LPR;
+  static_assert(TT % RPP == 0, "row phase covers the tile in whole passes");
+  const int sub = tid % LPR, prow = tid / LPR;
+  float wv[8], bv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { wv[i] = w[sub * 8 + i]; bv[i] = b[sub * 8 + i]; }
+#pragma unroll
+  for (int pp = 0; pp < TT / RPP; ++pp) {
+    const int p = pp * RPP + prow;
+    float x[8];
+    load8f(Xs + p * LD + sub * 8, x);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x[i];
+    const float mu = group_sum<LPR>(s) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { x[i] -= mu; q += x[i] * x[i]; }
+    const float rs = 1.f / sqrtf(group_sum<LPR>(q) * (1.f / C) + 1e-5f);
+    float y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = x[i] * rs * wv[i] + bv[i];
+    store8f(Ys + p * LD + sub * 8, y);
+    if (sub == 0 && n0 + p < N) { mean[n0 + p] = mu; rstd[n0 + p] = rs; }
+  }
+}
+
+// Cooperative L2 warm-up of a weight range.  Every workgroup of a chain kernel streams the SAME
+// weights, and the workgroups of one XCD (blockIdx % 8) run in lockstep, so a cold weight stream
+// advances at the miss rate of ONE compute unit's request window (~25 GB/s measured) while the other
+// CUs of the XCD wait for the same lines.  Here workgroup q = blockIdx / 8 of its XCD touches slice q of
+// the range (16 B per lane, results only folded into `sink`), so that the whole range is requested from
+// HBM at once by `nslices` CUs and the later fragment loads hit the XCD's L2.
+// Issue it FIRST: vmcnt completes in order, so the first wait for real data covers these loads too.
+template <int MAXLD>
+AMT_DEV void chain_l2_warm(const void* base, size_t bytes, int q, int nslices, int tid, uint32_t& sink) {
+  if (q >= nslices) return;
+  const size_t per = ((bytes + nslices - 1) / nslices + 4095) & ~(size_t)4095;   // whole 4 KiB rounds
+  const size_t beg = (size_t)q * per;
+  const char* p = static_cast<const char*>(base) + beg + (size_t)tid * 16;
+#pragma unroll
+  for (int i = 0; i < MAXLD; ++i) {
+    const size_t off = (size_t)i * 4096;
+    if (off < per && beg + off + (size_t)tid * 16 + 16 <= bytes) {
+      const uint4 v = *reinterpret_cast<const uint4*>(p + off);
+      sink ^= v.x ^ v.y ^ v.z ^ v.w;
     }
   }
 }

@@ -559,4 +559,295 @@ void block_bwd_fused(hipStream_t s, DType dt, const BlockBwdArgs& a_in, float* d
 #undef AMT_BB_CASE
 }
 
+
+// ------------------------------------------------------------------ transformer layer, second half, forward
+// One workgroup per tile of TT tokens; all 256 hidden features of a token stay in the workgroup, so
+// the LayerNorm between the output projection and the FFN is a row pass over an LDS panel.
+template <typename T> struct FfnTile { static constexpr int TT = sizeof(T) == 2 ? 32 : 16; };
+
+// FULL = false stops after the LayerNorm (h, hn, mean, rstd written): the production form.  The full
+// chain streams 896 KiB of weights through every compute unit (~28 B/clk L2-hit rate per CU, less for
+// the cold first touch) and measured 27 us against ~31 us for the four separate launches; with only
+// the 128 KiB output projection in the chain the kernel takes ~6 us and W1 / W2 stay tiled GEMMs,
+// whose 64 x 64 tiles move 3.5x fewer weight bytes per CU (profiles/r01_notes.md).
+template <typename T, int TT, bool FULL>
+__global__ __launch_bounds__(256) void ffn_fwd_fused_kernel(FfnFwdArgs a) {
+  constexpr int H = 256, I = 512, I2 = 1024, LDX = H + 8, LDG = I + 8;
+  using SO = ChainSplit<H, TT>;        // Wo and W2 stages: 256 output features
+  using S1 = ChainSplit<I2 / 2, TT>;   // W1 in two halves of 512 permuted rows
+  // one wave per SIMD (125 workgroups): the register file is the prefetch buffer.  32 fragments
+  // (32 KiB per wave, 128 KiB per CU) per chunk and two chunks in flight; with 16 the cold weight
+  // stream ran at ~21 GB/s per CU (one HBM round trip per 64 KiB).
+  constexpr int KCO = ChainChunk<T, SO::RB, H, 32>::KC, KC1 = ChainChunk<T, S1::RB, H, 32>::KC,
+                KC2 = ChainChunk<T, SO::RB, I, 32>::KC;
+  static_assert(S1::RB % 2 == 0, "a wave owns whole (u1 | u2) row-block pairs");
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  T* As = reinterpret_cast<T*>(chain_smem);   // [TT][LDX]  attention output, then LN2(h)
+  T* Xs = As + TT * LDX;                      // [TT][LDX]  x, then y (staged for the copy-out)
+  T* Hs = Xs + TT * LDX;                      // [TT][LDX]  h
+  T* Gs = Hs + TT * LDX;                      // [TT][LDG]  g
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const long N = a.N, n0 = (long)blockIdx.x * TT;
+  const T* Wo = reinterpret_cast<const T*>(a.Wo);
+  const T* W1 = reinterpret_cast<const T*>(a.W1);
+  const T* W2 = reinterpret_cast<const T*>(a.W2);
+  const int mO = (wave % SO::WF) * SO::RB * 16, tO = (wave / SO::WF) * SO::NT * 16;
+  const int m1 = (wave % S1::WF) * S1::RB * 16, t1 = (wave / S1::WF) * S1::NT * 16;
+
+  AMT_STAMP_RT(6);
+  AMT_STAMP(0);
+  uint32_t warm = 0;
+  if constexpr (FULL) {
+    const int q = blockIdx.x >> 3, ns = max(1, (int)(gridDim.x >> 3));
+    chain_l2_warm<8>(W1, sizeof(T) * (size_t)I2 * H, q, ns, tid, warm);
+    chain_l2_warm<4>(W2, sizeof(T) * (size_t)H * I, q, ns, tid, warm);
+  }
+  Frag<T> wo[KCO][SO::RB];
+  chain_load_w<T, SO::RB, KCO, H>(wo, Wo, mO, 0, lane);
+  chain_copy_in<T, TT, H, LDX>(As, reinterpret_cast<const T*>(a.AO), n0, N, tid);
+  chain_copy_in<T, TT, H, LDX>(Xs, reinterpret_cast<const T*>(a.X), n0, N, tid);
+  __syncthreads();
+  AMT_STAMP(1);
+
+  // ---- h = x + ao . Wo^T
+  Frag<T> w1a[KC1][S1::RB];
+  {
+    f32x4 acc[SO::RB][SO::NT];
+    chain_zero(acc);
+    chain_stage<T, SO::RB, SO::NT, KCO, H>(acc, wo, Wo, mO, As, LDX, tO, lane);
+    if constexpr (FULL) chain_load_w<T, S1::RB, KC1, H>(w1a, W1, m1, 0, lane);   // in flight during the LayerNorm pass
+#pragma unroll
+    for (int rb = 0; rb < SO::RB; ++rb) {
+      const int m = mO + 16 * rb + 4 * g;
+#pragma unroll
+      for (int ti = 0; ti < SO::NT; ++ti) {
+        const int p = tO + 16 * ti + r;
+        float x[4], h[4];
+        load4f(Xs + p * LDX + m, x);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = acc[rb][ti][i] + x[i];
+        store4f(Hs + p * LDX + m, h);
+      }
+    }
+  }
+  __syncthreads();
+  AMT_STAMP(2);
+  // ---- hn = LN2(h) over the panel rows (As is dead: it receives hn)
+  chain_ln_rows<T, TT, H, LDX>(Hs, As, a.ln_w, a.ln_b, a.mean, a.rstd, n0, N, tid);
+  chain_copy_out<T, TT, H, LDX>(Hs, reinterpret_cast<T*>(a.Hout), n0, N, tid);
+  __syncthreads();
+  chain_copy_out<T, TT, H, LDX>(As, reinterpret_cast<T*>(a.HN), n0, N, tid);
+  AMT_STAMP(3);
+  if constexpr (!FULL) {
+    AMT_STAMP(4);
+    AMT_STAMP(5);
+    AMT_STAMP_RT(7);
+    return;
+  }
+
+  // ---- u = hn . W1^T + b1 ; g = gelu(u1) * u2, in two halves of 512 permuted rows
+  Frag<T> w2f[KC2][SO::RB], w1b[KC1][S1::RB];
+  auto glu_half = [&](int mh, Frag<T> (&wpre)[KC1][S1::RB], bool last) {
+    f32x4 acc[S1::RB][S1::NT];
+    chain_zero(acc);
+    chain_stage<T, S1::RB, S1::NT, KC1, H>(acc, wpre, W1, mh, As, LDX, t1, lane);
+    // the next stage's first weights are requested before the GLU epilogue (exp, stores) runs
+    if (!last) chain_load_w<T, S1::RB, KC1, H>(w1b, W1, mh + I2 / 2, 0, lane);
+    else chain_load_w<T, SO::RB, KC2, I>(w2f, W2, mO, 0, lane);
+#pragma unroll
+    for (int rb = 0; rb < S1::RB; rb += 2) {
+      const int m = mh + 16 * rb + 4 * g;          // permuted row of u1; u2 sits 16 rows further
+      float b1a[4], b1b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { b1a[i] = a.b1[m + i]; b1b[i] = a.b1[m + 16 + i]; }
+      const int j = (m >> 5) * 16 + (m & 15);      // g column
+#pragma unroll
+      for (int ti = 0; ti < S1::NT; ++ti) {
+        const int p = t1 + 16 * ti + r;
+        const long row = n0 + p;
+        float u1[4], u2[4], gl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          u1[i] = to_f(from_f<T>(acc[rb][ti][i] + b1a[i]));
+          u2[i] = to_f(from_f<T>(acc[rb + 1][ti][i] + b1b[i]));
+          gl[i] = gelu_tanh(u1[i]) * u2[i];
+        }
+        store4f(Gs + p * LDG + j, gl);
+        if (row < N) {
+          T* up = reinterpret_cast<T*>(a.U) + row * I2 + m;
+          store4f(up, u1);
+          store4f(up + 16, u2);
+        }
+      }
+    }
+  };
+  glu_half(m1, w1a, false);
+  glu_half(I2 / 2 + m1, w1b, true);
+  __syncthreads();
+  AMT_STAMP(4);
+  chain_copy_out<T, TT, I, LDG>(Gs, reinterpret_cast<T*>(a.G), n0, N, tid);
+
+  // ---- y = h + dropout(g . W2^T + b2)
+  {
+    f32x4 acc[SO::RB][SO::NT];
+    chain_zero(acc);
+    chain_stage<T, SO::RB, SO::NT, KC2, I>(acc, w2f, W2, mO, Gs, LDG, tO, lane);
+#pragma unroll
+    for (int rb = 0; rb < SO::RB; ++rb) {
+      const int m = mO + 16 * rb + 4 * g;
+      float bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bb[i] = a.b2[m + i];
+#pragma unroll
+      for (int ti = 0; ti < SO::NT; ++ti) {
+        const int p = tO + 16 * ti + r;
+        const long row = n0 + p;
+        float h[4], y[4];
+        load4f(Hs + p * LDX + m, h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = acc[rb][ti][i] + bb[i];
+          if (a.drop_thresh24) {
+            const bool keep = rng_keep(a.seed, a.stream, (uint32_t)row * (uint32_t)H + (uint32_t)(m + i), a.drop_thresh24);
+            v = keep ? v * a.inv_keep : 0.f;
+          }
+          y[i] = v + h[i];
+        }
+        store4f(Xs + p * LDX + m, y);
+      }
+    }
+  }
+  __syncthreads();
+  chain_copy_out<T, TT, H, LDX>(Xs, reinterpret_cast<T*>(a.Y), n0, N, tid);
+  if (warm == 0x9e3779b9u && a.N < 0) a.mean[0] = 0.f;   // keeps the warm-up loads alive; never true
+  AMT_STAMP(5);
+  AMT_STAMP_RT(7);
+}
+
+template <typename T, bool FULL>
+static void ffn_fwd_fused_launch(hipStream_t s, const FfnFwdArgs& a) {
+  constexpr int TT = FfnTile<T>::TT;
+  constexpr size_t lds = sizeof(T) * (size_t)TT * (3 * (256 + 8) + (FULL ? 512 + 8 : 0));
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool once = (lds > 64 * 1024
+                          ? (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_fwd_fused_kernel<T, TT, FULL>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                          : (void)0,
+                      true);
+  (void)once;
+  hipLaunchKernelGGL((ffn_fwd_fused_kernel<T, TT, FULL>), dim3((a.N + TT - 1) / TT), dim3(256), lds, s, a);
+}
+
+void ffn_fwd_fused(hipStream_t s, DType dt, const FfnFwdArgs& a) {
+  const double N = a.N, es = dt == DT_F32 ? 4 : 2;
+  if (a.W1 == nullptr) {   // output projection + residual + LayerNorm only
+    ProfScope ps(s, "attn_out_fused", 2.0 * N * 256.0 * 256, (N * 256.0 * 4 + 256.0 * 256) * es);
+    if (dt == DT_F32) ffn_fwd_fused_launch<float, false>(s, a);
+    else ffn_fwd_fused_launch<bf16, false>(s, a);
+    return;
+  }
+  ProfScope ps(s, "ffn_fwd_fused", 2.0 * N * (256.0 * 256 + 1024.0 * 256 + 256.0 * 512),
+               (N * (256.0 * 6 + 1024 + 512) + 256.0 * 256 + 1024.0 * 256 + 256.0 * 512) * es);
+  if (dt == DT_F32) ffn_fwd_fused_launch<float, true>(s, a);
+  else ffn_fwd_fused_launch<bf16, true>(s, a);
+}
+
+
+// ------------------------------------------------------------------ transformer layer, first half, forward
+template <typename T, int TT>
+__global__ __launch_bounds__(256) void qkv_fwd_fused_kernel(QkvFwdArgs a) {
+  constexpr int H = 256, QC = 320, CK = 64, KV = 512, LDX = H + 8, LDQ = QC + 8, LDK = KV + 8;
+  using SQ = ChainSplit<QC, TT>;
+  using SK = ChainSplit<KV, TT>;
+  constexpr int KCQ = ChainChunk<T, SQ::RB, H, 32>::KC, KCK = ChainChunk<T, SK::RB, CK>::KC;
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  T* Xs = reinterpret_cast<T*>(chain_smem);   // [TT][LDX]  x, then LN1(x) in place
+  T* Qs = Xs + TT * LDX;                      // [TT][LDQ]  qc
+  T* Ks = Qs + TT * LDQ;                      // [TT][LDK]  kv
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const long N = a.N, n0 = (long)blockIdx.x * TT;
+  const T* Wq = reinterpret_cast<const T*>(a.Wqc);
+  const T* Wk = reinterpret_cast<const T*>(a.Wkv);
+  const int mQ = (wave % SQ::WF) * SQ::RB * 16, tQ = (wave / SQ::WF) * SQ::NT * 16;
+  const int mK = (wave % SK::WF) * SK::RB * 16, tK = (wave / SK::WF) * SK::NT * 16;
+
+  AMT_STAMP_RT(6);
+  AMT_STAMP(0);
+  Frag<T> wq[KCQ][SQ::RB], wk[KCK][SK::RB];
+  chain_load_w<T, SQ::RB, KCQ, H>(wq, Wq, mQ, 0, lane);
+  chain_copy_in<T, TT, H, LDX>(Xs, reinterpret_cast<const T*>(a.X), n0, N, tid);
+  __syncthreads();
+  AMT_STAMP(1);
+  chain_ln_rows<T, TT, H, LDX>(Xs, Xs, a.ln_w, a.ln_b, a.mean, a.rstd, n0, N, tid);
+  chain_load_w<T, SK::RB, KCK, CK>(wk, Wk, mK, 0, lane);
+  __syncthreads();
+  AMT_STAMP(2);
+  chain_copy_out<T, TT, H, LDX>(Xs, reinterpret_cast<T*>(a.XN), n0, N, tid);
+
+  // ---- qc = xn . Wqc^T
+  {
+    f32x4 acc[SQ::RB][SQ::NT];
+    chain_zero(acc);
+    chain_stage<T, SQ::RB, SQ::NT, KCQ, H>(acc, wq, Wq, mQ, Xs, LDX, tQ, lane);
+#pragma unroll
+    for (int rb = 0; rb < SQ::RB; ++rb)
+#pragma unroll
+      for (int ti = 0; ti < SQ::NT; ++ti) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[rb][ti][i];
+        store4f(Qs + (tQ + 16 * ti + r) * LDQ + mQ + 16 * rb + 4 * g, v);
+      }
+  }
+  __syncthreads();
+  AMT_STAMP(3);
+  chain_copy_out<T, TT, QC, LDQ>(Qs, reinterpret_cast<T*>(a.QC), n0, N, tid);
+
+  // ---- kv = c . Wkv^T, c = qc[:, 256:320] as stored
+  {
+    f32x4 acc[SK::RB][SK::NT];
+    chain_zero(acc);
+    chain_stage<T, SK::RB, SK::NT, KCK, CK>(acc, wk, Wk, mK, Qs + H, LDQ, tK, lane);
+#pragma unroll
+    for (int rb = 0; rb < SK::RB; ++rb)
+#pragma unroll
+      for (int ti = 0; ti < SK::NT; ++ti) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[rb][ti][i];
+        store4f(Ks + (tK + 16 * ti + r) * LDK + mK + 16 * rb + 4 * g, v);
+      }
+  }
+  __syncthreads();
+  AMT_STAMP(4);
+  chain_copy_out<T, TT, KV, LDK>(Ks, reinterpret_cast<T*>(a.KV), n0, N, tid);
+  AMT_STAMP(5);
+  AMT_STAMP_RT(7);
+}
+
+template <typename T>
+static void qkv_fwd_fused_launch(hipStream_t s, const QkvFwdArgs& a) {
+  constexpr int TT = FfnTile<T>::TT;
+  constexpr size_t lds = sizeof(T) * (size_t)TT * ((256 + 8) + (320 + 8) + (512 + 8));
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool once = (lds > 64 * 1024
+                          ? (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_fwd_fused_kernel<T, TT>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                          : (void)0,
+                      true);
+  (void)once;
+  hipLaunchKernelGGL((qkv_fwd_fused_kernel<T, TT>), dim3((a.N + TT - 1) / TT), dim3(256), lds, s, a);
+}
+
+void qkv_fwd_fused(hipStream_t s, DType dt, const QkvFwdArgs& a) {
+  const double N = a.N, es = dt == DT_F32 ? 4 : 2;
+  ProfScope ps(s, "qkv_fwd_fused", 2.0 * N * (320.0 * 256 + 512.0 * 64), (N * (256.0 * 2 + 320 + 512) + 320.0 * 256 + 512.0 * 64) * es);
+  if (dt == DT_F32) qkv_fwd_fused_launch<float>(s, a);
+  else qkv_fwd_fused_launch<bf16>(s, a);
+}
+
 }  // namespace amt

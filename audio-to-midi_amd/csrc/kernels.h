@@ -155,6 +155,36 @@ struct BlockBwdArgs {
 void block_bwd_fused(hipStream_t s, DType dt, const BlockBwdArgs& a, float* dlnw, float* dlnb, float* dwdw,
                      float* dbdw, float* dgamma, PartialSink* sink, const WgradArgs* riders = nullptr, int n_riders = 0);
 
+// Second half of a transformer layer forward in one launch (model.py:369, 545-556; H = 256, I = 512):
+//   h = x + ao . Wo^T ; hn = LN2(h) ; u = hn . W1^T + b1 ; g = gelu(u1) * u2 ; y = h + dropout(g . W2^T + b2)
+// Writes h, hn, mean, rstd, u (permuted GLU layout), g, y exactly as gemm_nt<resid> + layernorm_fwd +
+// gemm_nt<glu> + gemm_nt<resid> do.  Wo [256][256], W1 [1024][256], W2 [256][512]: fragment-PACKED.
+// W1 == nullptr: stop after the LayerNorm (h, hn, mean, rstd) — the production form; the full chain is
+// an opt-in (AMT_FUSE_FFN=1) that measured slower at 8 clips per GPU (chain.hip).
+struct FfnFwdArgs {
+  const void* AO; const void* X;
+  const void* Wo; const float* ln_w; const float* ln_b;
+  const void* W1; const float* b1; const void* W2; const float* b2;
+  void* Hout; void* HN; float* mean; float* rstd; void* U; void* G; void* Y;
+  int N;
+  uint64_t seed; uint32_t stream; uint32_t drop_thresh24; float inv_keep;
+  int dbg_slot;
+};
+void ffn_fwd_fused(hipStream_t s, DType dt, const FfnFwdArgs& a);
+
+// First half of a transformer layer forward up to the attention core, in one launch (model.py:539,
+// 300-334, 353-357; H = 256, 4 heads x 64, kv_compress 64):
+//   xn = LN1(x) ; qc = xn . Wqc^T  ([q (256) | c (64)]) ; kv = c . Wkv^T  ([k (256) | v (256)])
+// Writes xn, mean, rstd, qc, kv exactly as layernorm_fwd + gemm_nt + gemm_nt do.  Wqc [320][256],
+// Wkv [512][64]: fragment-PACKED.
+struct QkvFwdArgs {
+  const void* X; const float* ln_w; const float* ln_b; const void* Wqc; const void* Wkv;
+  void* XN; float* mean; float* rstd; void* QC; void* KV;
+  int N;
+  int dbg_slot;
+};
+void qkv_fwd_fused(hipStream_t s, DType dt, const QkvFwdArgs& a);
+
 // ----------------------------------------------------------------------------- attention
 struct AttnArgs {
   const void* QC; int ldqc;   // q = QC[:, 0:256] (un-roped)

@@ -47,6 +47,7 @@ struct StageP {
 struct LayerP {
   size_t ln1_w, ln1_b, wqc, wkv, wo, ln2_w, ln2_b, w1, b1, w2, b2;
   size_t c_wqc, c_wqct, c_wkv, c_wkvt, c_wo, c_wot, c_w1, c_w1t, c_w2, c_w2t;
+  size_t c_wop, c_w1p, c_w2p, c_wqcp, c_wkvp;   // fragment-packed copies for the chain kernels
 };
 
 struct Layout {
@@ -185,6 +186,11 @@ Layout build_layout(const amt_config& c) {
     cpair(l.wo, H, HD, l.c_wo, l.c_wot);
     cpair(l.w1, L.I2, H, l.c_w1, l.c_w1t);
     cpair(l.w2, H, c.ffn_inter, l.c_w2, l.c_w2t);
+    l.c_wop = cpacked(l.wo, H, HD);
+    l.c_wqcp = cpacked(l.wqc, L.QC, H);
+    l.c_wkvp = cpacked(l.wkv, L.KVW, c.kv_compress);
+    l.c_w1p = cpacked(l.w1, L.I2, H);
+    l.c_w2p = cpacked(l.w2, H, c.ffn_inter);
     L.layers.push_back(l);
   }
   L.hd_lnw = seg("decoder.norm.weight", H, 1, -1);
@@ -264,6 +270,7 @@ struct amt_ctx {
   size_t scratch_max = 0;       // bytes of per-scope backward scratch (two alternating regions)
   bool use_side = false;
   bool fuse = true;             // chain kernels (chain.hip); AMT_FUSE=0 selects the unfused launch sequence
+  bool fuse_ffn = false;        // AMT_FUSE_FFN=1: whole second half of a layer in one launch (measured slower)
 
   const float* P(size_t off) const { return params + off; }
   const void* WC(size_t off) const { return static_cast<const char*>(wc) + off * esz; }
@@ -462,28 +469,54 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
     ls.r2 = (float*)A.alloc((size_t)N * sizeof(float));
     ls.u = A.alloc((size_t)N * L.I2 * es);
     ls.g = A.alloc((size_t)N * (L.I2 / 2) * es);
-    RUN(layernorm_fwd(s, dt, cur, c->P(lp.ln1_w), c->P(lp.ln1_b), ls.xn, ls.m1, ls.r1, N, H));
-    GemmArgs gq = gargs(ls.xn, H, c->WC(lp.c_wqc), H, N, L.QC, H, nullptr, ls.qc, L.QC);
-    RUN(gemm_nt(s, dt, EPI_STORE, gq));
-    const void* cptr = static_cast<const char*>(ls.qc) + (size_t)(L.QC - cfg.kv_compress) * es;
-    GemmArgs gk = gargs(cptr, L.QC, c->WC(lp.c_wkv), cfg.kv_compress, N, L.KVW, cfg.kv_compress, nullptr, ls.kv, L.KVW);
-    RUN(gemm_nt(s, dt, EPI_STORE, gk));
+    const bool chain_ok = c->fuse && H == 256 && cfg.ffn_inter == 512 && cfg.n_heads * cfg.head_dim == 256;
+    if (chain_ok) {
+      QkvFwdArgs qa;
+      memset(&qa, 0, sizeof(qa));
+      qa.X = cur; qa.ln_w = c->P(lp.ln1_w); qa.ln_b = c->P(lp.ln1_b); qa.Wqc = c->WC(lp.c_wqcp); qa.Wkv = c->WC(lp.c_wkvp);
+      qa.XN = ls.xn; qa.mean = ls.m1; qa.rstd = ls.r1; qa.QC = ls.qc; qa.KV = ls.kv; qa.N = N; qa.dbg_slot = 96 + (int)li;
+      RUN(qkv_fwd_fused(s, dt, qa));
+    } else {
+      RUN(layernorm_fwd(s, dt, cur, c->P(lp.ln1_w), c->P(lp.ln1_b), ls.xn, ls.m1, ls.r1, N, H));
+      GemmArgs gq = gargs(ls.xn, H, c->WC(lp.c_wqc), H, N, L.QC, H, nullptr, ls.qc, L.QC);
+      RUN(gemm_nt(s, dt, EPI_STORE, gq));
+      const void* cptr = static_cast<const char*>(ls.qc) + (size_t)(L.QC - cfg.kv_compress) * es;
+      GemmArgs gk = gargs(cptr, L.QC, c->WC(lp.c_wkv), cfg.kv_compress, N, L.KVW, cfg.kv_compress, nullptr, ls.kv, L.KVW);
+      RUN(gemm_nt(s, dt, EPI_STORE, gk));
+    }
     AttnArgs aa;
     memset(&aa, 0, sizeof(aa));
     aa.QC = ls.qc; aa.ldqc = L.QC; aa.KV = ls.kv; aa.ldkv = L.KVW; aa.O = ls.ao; aa.ldo = H; aa.LSE = ls.lse;
     aa.cos = c->rope_cos; aa.sin = c->rope_sin; aa.B = B; aa.S = S; aa.H = cfg.n_heads;
     aa.seed = seed; aa.stream = stream_attn((int)li); aa.drop_thresh24 = dp.thr; aa.inv_keep = dp.inv_keep;
     if (local) RUN(attn_local_fwd(s, dt, aa)); else RUN(attn_global_fwd(s, dt, aa));
-    // h = x + attn . Wo^T
+    // h = x + attn . Wo^T ; out = h + FFN(LN2(h))
     ls.h = save ? A.alloc((size_t)N * H * es) : out_buf(0);
-    GemmArgs go = gargs(ls.ao, H, c->WC(lp.c_wo), H, N, H, H, nullptr, ls.h, H);
-    go.R = cur; go.ldr = H;
-    RUN(gemm_nt(s, dt, EPI_RESID, go));
-    RUN(layernorm_fwd(s, dt, ls.h, c->P(lp.ln2_w), c->P(lp.ln2_b), ls.hn, ls.m2, ls.r2, N, H));
+    void* y = save ? A.alloc((size_t)N * H * es) : out_buf(0);
+    if (chain_ok) {
+      FfnFwdArgs fa;
+      memset(&fa, 0, sizeof(fa));
+      fa.AO = ls.ao; fa.X = cur; fa.Wo = c->WC(lp.c_wop); fa.ln_w = c->P(lp.ln2_w); fa.ln_b = c->P(lp.ln2_b);
+      fa.Hout = ls.h; fa.HN = ls.hn; fa.mean = ls.m2; fa.rstd = ls.r2; fa.N = N;
+      fa.dbg_slot = 40 + (int)li;
+      if (c->fuse_ffn) {
+        fa.W1 = c->WC(lp.c_w1p); fa.b1 = c->P(lp.b1); fa.W2 = c->WC(lp.c_w2p); fa.b2 = c->P(lp.b2);
+        fa.U = ls.u; fa.G = ls.g; fa.Y = y;
+        fa.seed = seed; fa.stream = stream_ffn((int)li); fa.drop_thresh24 = dp.thr; fa.inv_keep = dp.inv_keep;
+        RUN(ffn_fwd_fused(s, dt, fa));
+        cur = y;
+        continue;
+      }
+      RUN(ffn_fwd_fused(s, dt, fa));   // h = x + ao . Wo^T, hn = LN2(h)
+    } else {
+      GemmArgs go = gargs(ls.ao, H, c->WC(lp.c_wo), H, N, H, H, nullptr, ls.h, H);
+      go.R = cur; go.ldr = H;
+      RUN(gemm_nt(s, dt, EPI_RESID, go));
+      RUN(layernorm_fwd(s, dt, ls.h, c->P(lp.ln2_w), c->P(lp.ln2_b), ls.hn, ls.m2, ls.r2, N, H));
+    }
     GemmArgs g1 = gargs(ls.hn, H, c->WC(lp.c_w1), H, N, L.I2, H, c->P(lp.b1), ls.g, L.I2 / 2);
     g1.Y2 = ls.u; g1.ldy2 = L.I2;
     RUN(gemm_nt(s, dt, EPI_GLU, g1));
-    void* y = save ? A.alloc((size_t)N * H * es) : out_buf(0);
     GemmArgs g2 = gargs(ls.g, L.I2 / 2, c->WC(lp.c_w2), L.I2 / 2, N, H, L.I2 / 2, c->P(lp.b2), y, H);
     g2.R = ls.h; g2.ldr = H;
     g2.seed = seed; g2.stream = stream_ffn((int)li); g2.drop_thresh24 = dp.thr; g2.inv_keep = dp.inv_keep;
@@ -957,6 +990,7 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   // every CU and slow down when sharing them.  Kept as an opt-in for larger per-GPU batches.
   c->use_side = getenv("AMT_SIDE_STREAM") != nullptr;
   c->fuse = !(getenv("AMT_FUSE") && atoi(getenv("AMT_FUSE")) == 0);
+  c->fuse_ffn = getenv("AMT_FUSE_FFN") && atoi(getenv("AMT_FUSE_FFN")) != 0;
   const Layout& L = c->L;
   auto fail = [&](const char* what, hipError_t err) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(err);
