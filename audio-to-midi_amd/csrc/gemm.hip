@@ -382,7 +382,7 @@ int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* si
     }
     // few token splits: every split adds M*Kp*4 bytes of fp32 atomics and the chip-wide atomic rate
     // (~1.3 TB/s) was the bound at 1536 workgroups (38 us per layer group vs 24 us at ~224)
-    static const int target_wgs = getenv("AMT_WGRAD_TARGET_WGS") ? atoi(getenv("AMT_WGRAD_TARGET_WGS")) : 224;
+    static const int target_wgs = getenv("AMT_WGRAD_TARGET_WGS") ? atoi(getenv("AMT_WGRAD_TARGET_WGS")) : 336;
     int splits = (target_wgs + total_tiles - 1) / total_tiles;
     int max_splits = (a.N + 127) / 128;
     if (splits > max_splits) splits = max_splits;
