@@ -226,6 +226,68 @@ AMT_DEV void chain_l2_warm(const void* base, size_t bytes, int q, int nslices, i
   }
 }
 
+// LayerNorm backward over C = 256 features of TT rows (eqx LayerNorm, fp32 statistics):
+//   dX = dRes + LN'(dY),  aw += dY * xhat,  ab += dY   (column accumulators of this lane, cs[0] / cs[1])
+// dY rows come from an LDS panel (as stored, T), x / dRes rows from global memory; dX goes to an LDS
+// panel (Os, may alias DYs row-for-row) and, if DX != nullptr, to global rows (16 B per lane).
+// If DXD != nullptr a second copy with the FFN-output dropout mask of the consuming layer applied
+// (model.py:237) is written as well: the mask depends only on (seed, stream, row, column).
+template <typename T, int TT, int LD>
+AMT_DEV void chain_ln_bwd_rows(const T* DYs, T* Os, const T* __restrict__ X, const float* __restrict__ mean,
+                               const float* __restrict__ rstd, const float* __restrict__ w, const T* __restrict__ dRes,
+                               T* __restrict__ DX, T* __restrict__ DXD, uint64_t seed, uint32_t stream, uint32_t thr,
+                               float inv_keep, float (&cs)[2][8], long n0, long N, int tid) {
+  constexpr int C = 256, LPR = 32, RPP = 8;
+  static_assert(TT % RPP == 0, "row phase covers the tile in whole passes");
+  const int sub = tid % LPR, prow = tid / LPR;
+  float wv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) wv[i] = w[sub * 8 + i];
+#pragma unroll
+  for (int pp = 0; pp < TT / RPP; ++pp) {
+    const int p = pp * RPP + prow;
+    const long row = n0 + p;
+    const bool valid = row < N;
+    const long rc = valid ? row : N - 1;
+    float x[8], dy[8], rr[8];
+    load8f(X + rc * C + sub * 8, x);
+    load8f(dRes + rc * C + sub * 8, rr);
+    load8f(DYs + p * LD + sub * 8, dy);
+    const float mu = mean[rc], rs = rstd[rc];
+    const float fv = valid ? 1.f : 0.f;
+    // explicit roundings (no compiler-chosen fma contraction): layernorm_bwd (norm.hip) uses the same
+    // sequence, so the chain and the unfused launch agree bit for bit
+    float s1 = 0.f, s2 = 0.f, gy[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      x[i] = __fmul_rn(__fsub_rn(x[i], mu), rs);
+      gy[i] = __fmul_rn(dy[i], wv[i]);
+      s1 = __fadd_rn(s1, gy[i]);
+      s2 = __fmaf_rn(gy[i], x[i], s2);
+      cs[0][i] += fv * dy[i] * x[i];
+      cs[1][i] += fv * dy[i];
+    }
+    s1 = group_sum<LPR>(s1) * (1.f / C);
+    s2 = group_sum<LPR>(s2) * (1.f / C);
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      o[i] = __fadd_rn(__fmul_rn(rs, __fmaf_rn(-x[i], s2, __fsub_rn(gy[i], s1))), rr[i]);
+    store8f(Os + p * LD + sub * 8, o);
+    if (valid && DX != nullptr) store8f(DX + row * C + sub * 8, o);
+    if (valid && DXD != nullptr) {
+      float od[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = to_f(from_f<T>(o[i]));   // the unfused path applies the mask to the stored value
+        const bool keep = rng_keep(seed, stream, (uint32_t)row * (uint32_t)C + (uint32_t)(sub * 8 + i), thr);
+        od[i] = keep ? v * inv_keep : 0.f;
+      }
+      store8f(DXD + row * C + sub * 8, od);
+    }
+  }
+}
+
 template <int RB, int NT> AMT_DEV void chain_zero(f32x4 (&acc)[RB][NT]) {
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)

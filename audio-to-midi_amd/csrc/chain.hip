@@ -850,4 +850,216 @@ void qkv_fwd_fused(hipStream_t s, DType dt, const QkvFwdArgs& a) {
   else qkv_fwd_fused_launch<bf16>(s, a);
 }
 
+
+// ------------------------------------------------------------------ transformer layer backward chains
+template <typename T, int TT>
+__global__ __launch_bounds__(256) void qkv_bwd_fused_kernel(QkvBwdArgs a) {
+  constexpr int H = 256, QC = 320, CK = 64, KV = 512, LDX = H + 8, LDQ = QC + 8, LDK = KV + 8;
+  using SC = ChainSplit<CK, TT>;     // dc: 64 features
+  using SX = ChainSplit<H, TT>;      // dxn: 256 features
+  constexpr int KCC = ChainChunk<T, SC::RB, KV>::KC, KCX = ChainChunk<T, SX::RB, QC, 32>::KC;
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  T* Ks = reinterpret_cast<T*>(chain_smem);   // [TT][LDK]  dkv
+  T* Qs = Ks + TT * LDK;                      // [TT][LDQ]  dqc (dq | dc)
+  T* Xs = Qs + TT * LDQ;                      // [TT][LDX]  dxn, then dx
+  float* part = reinterpret_cast<float*>(chain_smem);   // [4][2 * 256] over Ks once it is dead
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const long N = a.N, n0 = (long)blockIdx.x * TT;
+  const T* Wk = reinterpret_cast<const T*>(a.Wkvt);
+  const T* Wq = reinterpret_cast<const T*>(a.Wqct);
+  const int mC = (wave % SC::WF) * SC::RB * 16, tC = (wave / SC::WF) * SC::NT * 16;
+  const int mX = (wave % SX::WF) * SX::RB * 16, tX = (wave / SX::WF) * SX::NT * 16;
+
+  AMT_STAMP_RT(6);
+  AMT_STAMP(0);
+  Frag<T> wk[KCC][SC::RB], wq[KCX][SX::RB];
+  chain_load_w<T, SC::RB, KCC, KV>(wk, Wk, mC, 0, lane);
+  chain_load_w<T, SX::RB, KCX, QC>(wq, Wq, mX, 0, lane);
+  chain_copy_in<T, TT, KV, LDK>(Ks, reinterpret_cast<const T*>(a.dKV), n0, N, tid);
+  {   // dq part of dqc (320-wide rows, the first 256 columns)
+    constexpr int CPR = H / 8, TOTAL = TT * CPR;
+#pragma unroll
+    for (int i = 0; i < (TOTAL + 255) / 256; ++i) {
+      const int id = tid + i * 256, p = id / CPR, c = id % CPR;
+      const long row = n0 + p;
+      Chunk8<T> v = chunk_load(reinterpret_cast<const T*>(a.dQC) + (row < N ? row : N - 1) * QC + 8 * c);
+      if (row >= N) v = chunk_zero<T>();
+      chunk_store(Qs + p * LDQ + 8 * c, v);
+    }
+  }
+  __syncthreads();
+  AMT_STAMP(1);
+
+  // ---- dc = dkv . Wkv  -> columns 256..319 of the dqc panel and of dQC
+  {
+    f32x4 acc[SC::RB][SC::NT];
+    chain_zero(acc);
+    chain_stage<T, SC::RB, SC::NT, KCC, KV>(acc, wk, Wk, mC, Ks, LDK, tC, lane);
+#pragma unroll
+    for (int rb = 0; rb < SC::RB; ++rb)
+#pragma unroll
+      for (int ti = 0; ti < SC::NT; ++ti) {
+        const int p = tC + 16 * ti + r, m = mC + 16 * rb + 4 * g;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[rb][ti][i];
+        store4f(Qs + p * LDQ + H + m, v);
+        if (n0 + p < N) store4f(reinterpret_cast<T*>(a.dQC) + (n0 + p) * QC + H + m, v);
+      }
+  }
+  __syncthreads();
+  AMT_STAMP(2);
+
+  // ---- dxn = dqc . Wqc
+  {
+    f32x4 acc[SX::RB][SX::NT];
+    chain_zero(acc);
+    chain_stage<T, SX::RB, SX::NT, KCX, QC>(acc, wq, Wq, mX, Qs, LDQ, tX, lane);
+#pragma unroll
+    for (int rb = 0; rb < SX::RB; ++rb)
+#pragma unroll
+      for (int ti = 0; ti < SX::NT; ++ti) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[rb][ti][i];
+        store4f(Xs + (tX + 16 * ti + r) * LDX + mX + 16 * rb + 4 * g, v);
+      }
+  }
+  __syncthreads();
+  AMT_STAMP(3);
+
+  // ---- dx = dh + LN1'(dxn) (+ masked copy), column sums
+  float cs[2][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { cs[0][i] = 0.f; cs[1][i] = 0.f; }
+  chain_ln_bwd_rows<T, TT, LDX>(Xs, Xs, reinterpret_cast<const T*>(a.X), a.mean, a.rstd, a.ln_w,
+                                reinterpret_cast<const T*>(a.dH), reinterpret_cast<T*>(a.dX),
+                                a.drop_thresh24 ? reinterpret_cast<T*>(a.dXD) : nullptr, a.seed, a.stream,
+                                a.drop_thresh24, a.inv_keep, cs, n0, N, tid);
+  AMT_STAMP(4);
+  fold_columns<32, 16>(*reinterpret_cast<float (*)[16]>(&cs[0][0]), part + wave * 2 * H, H, lane);
+  __syncthreads();
+  float* rec = a.rec + (size_t)blockIdx.x * a.rec_stride;
+  for (int t = tid; t < 2 * H; t += 256)
+    rec[t] = (part[t] + part[2 * H + t]) + (part[4 * H + t] + part[6 * H + t]);
+  AMT_STAMP(5);
+  AMT_STAMP_RT(7);
+}
+
+template <typename T, int TT>
+__global__ __launch_bounds__(256) void lnout_bwd_fused_kernel(LnOutBwdArgs a) {
+  constexpr int H = 256, LDX = H + 8;
+  using SO = ChainSplit<H, TT>;
+  constexpr int KCO = ChainChunk<T, SO::RB, H, 32>::KC;
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  T* Ds = reinterpret_cast<T*>(chain_smem);   // [TT][LDX]  dhn, then dh
+  T* Os = Ds + TT * LDX;                      // [TT][LDX]  dao (staged for the copy-out)
+  float* part = reinterpret_cast<float*>(Os); // [4][2 * 256] before Os is used
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const long N = a.N, n0 = (long)blockIdx.x * TT;
+  const T* Wo = reinterpret_cast<const T*>(a.Wot);
+  const int mO = (wave % SO::WF) * SO::RB * 16, tO = (wave / SO::WF) * SO::NT * 16;
+
+  AMT_STAMP_RT(6);
+  AMT_STAMP(0);
+  Frag<T> wo[KCO][SO::RB];
+  chain_load_w<T, SO::RB, KCO, H>(wo, Wo, mO, 0, lane);
+  chain_copy_in<T, TT, H, LDX>(Ds, reinterpret_cast<const T*>(a.dHN), n0, N, tid);
+  __syncthreads();
+  AMT_STAMP(1);
+  float cs[2][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { cs[0][i] = 0.f; cs[1][i] = 0.f; }
+  chain_ln_bwd_rows<T, TT, LDX>(Ds, Ds, reinterpret_cast<const T*>(a.Hres), a.mean, a.rstd, a.ln_w,
+                                reinterpret_cast<const T*>(a.dY), reinterpret_cast<T*>(a.dH), nullptr, 0, 0, 0, 1.f, cs,
+                                n0, N, tid);
+  fold_columns<32, 16>(*reinterpret_cast<float (*)[16]>(&cs[0][0]), part + wave * 2 * H, H, lane);
+  __syncthreads();
+  AMT_STAMP(2);
+  {
+    float* rec = a.rec + (size_t)blockIdx.x * a.rec_stride;
+    for (int t = tid; t < 2 * H; t += 256)
+      rec[t] = (part[t] + part[2 * H + t]) + (part[4 * H + t] + part[6 * H + t]);
+  }
+  // ---- dao = dh . Wo
+  f32x4 acc[SO::RB][SO::NT];
+  chain_zero(acc);
+  chain_stage<T, SO::RB, SO::NT, KCO, H>(acc, wo, Wo, mO, Ds, LDX, tO, lane);
+  __syncthreads();                                   // every thread has read its record values from `part`
+  AMT_STAMP(3);
+#pragma unroll
+  for (int rb = 0; rb < SO::RB; ++rb)
+#pragma unroll
+    for (int ti = 0; ti < SO::NT; ++ti) {
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = acc[rb][ti][i];
+      store4f(Os + (tO + 16 * ti + r) * LDX + mO + 16 * rb + 4 * g, v);
+    }
+  __syncthreads();
+  AMT_STAMP(4);
+  chain_copy_out<T, TT, H, LDX>(Os, reinterpret_cast<T*>(a.dAO), n0, N, tid);
+  AMT_STAMP(5);
+  AMT_STAMP_RT(7);
+}
+
+template <typename K> static void chain_set_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <typename T>
+static void qkv_bwd_fused_launch(hipStream_t s, const QkvBwdArgs& a, int nb) {
+  constexpr int TT = FfnTile<T>::TT;
+  constexpr size_t lds = sizeof(T) * (size_t)TT * ((512 + 8) + (320 + 8) + (256 + 8));
+  static_assert(lds <= 160 * 1024 && sizeof(T) * TT * (512 + 8) >= sizeof(float) * 8 * 256, "LDS budget");
+  static bool once = (chain_set_lds(qkv_bwd_fused_kernel<T, TT>, lds), true);
+  (void)once;
+  hipLaunchKernelGGL((qkv_bwd_fused_kernel<T, TT>), dim3(nb), dim3(256), lds, s, a);
+}
+template <typename T>
+static void lnout_bwd_fused_launch(hipStream_t s, const LnOutBwdArgs& a, int nb) {
+  constexpr int TT = FfnTile<T>::TT;
+  constexpr size_t lds = sizeof(T) * (size_t)TT * 2 * (256 + 8);
+  static_assert(sizeof(T) * TT * (256 + 8) >= sizeof(float) * 8 * 256, "column-sum slices fit in one panel");
+  static bool once = (chain_set_lds(lnout_bwd_fused_kernel<T, TT>, lds), true);
+  (void)once;
+  hipLaunchKernelGGL((lnout_bwd_fused_kernel<T, TT>), dim3(nb), dim3(256), lds, s, a);
+}
+
+static int chain_ln_records(DType dt, int N, float* dlnw, float* dlnb, PartialSink* sink, float** rec) {
+  const int TT = dt == DT_F32 ? 16 : 32, nb = (N + TT - 1) / TT;
+  size_t o = sink->take((size_t)nb * 512);
+  sink->add(o, nb, 512, 256, dlnw);
+  sink->add(o + 256, nb, 512, 256, dlnb);
+  *rec = sink->dry ? nullptr : sink->ws + o;
+  return nb;
+}
+
+void qkv_bwd_fused(hipStream_t s, DType dt, const QkvBwdArgs& a_in, float* dlnw, float* dlnb, PartialSink* sink) {
+  QkvBwdArgs a = a_in;
+  const int nb = chain_ln_records(dt, a.N, dlnw, dlnb, sink, &a.rec);
+  if (sink->dry) return;
+  a.rec_stride = 512;
+  const double N = a.N, es = dt == DT_F32 ? 4 : 2;
+  ProfScope ps(s, "qkv_bwd_fused", 2.0 * N * (64.0 * 512 + 256.0 * 320), (N * (512 + 320 + 64 + 256 * 4.0) + 64.0 * 512 + 256.0 * 320) * es);
+  if (dt == DT_F32) qkv_bwd_fused_launch<float>(s, a, nb);
+  else qkv_bwd_fused_launch<bf16>(s, a, nb);
+}
+
+void lnout_bwd_fused(hipStream_t s, DType dt, const LnOutBwdArgs& a_in, float* dlnw, float* dlnb, PartialSink* sink) {
+  LnOutBwdArgs a = a_in;
+  const int nb = chain_ln_records(dt, a.N, dlnw, dlnb, sink, &a.rec);
+  if (sink->dry) return;
+  a.rec_stride = 512;
+  const double N = a.N, es = dt == DT_F32 ? 4 : 2;
+  ProfScope ps(s, "lnout_bwd_fused", 2.0 * N * 256.0 * 256, (N * 256 * 5.0 + 256.0 * 256) * es);
+  if (dt == DT_F32) lnout_bwd_fused_launch<float>(s, a, nb);
+  else lnout_bwd_fused_launch<bf16>(s, a, nb);
+}
+
 }  // namespace amt

@@ -185,6 +185,36 @@ struct QkvFwdArgs {
 };
 void qkv_fwd_fused(hipStream_t s, DType dt, const QkvFwdArgs& a);
 
+// Backward of the first half of a transformer layer after the attention core, in one launch
+// (replaces gemm_nt (k/v-up^T) + gemm_nt (q/kv-down^T) + layernorm_bwd [+ the next layer's dropout_apply]):
+//   dc = dkv . Wkv (64)  -> dQC[:, 256:320] ;  dxn = dQC . Wqc ;  dx = dh + LN1'(dxn) ;  dln1 w/b records
+// DXD (optional): dx with the FFN-output dropout mask of the layer that consumes it.
+// Wkvt [64][512], Wqct [256][320]: fragment-PACKED.
+struct QkvBwdArgs {
+  const void* dKV; void* dQC;                 // dQC[:, 0:256] in, [:, 256:320] out
+  const void* Wkvt; const void* Wqct;
+  const void* X; const float* mean; const float* rstd; const float* ln_w; const void* dH;
+  void* dX; void* dXD;
+  float* rec; int rec_stride;                 // set by the launcher
+  int N;
+  uint64_t seed; uint32_t stream; uint32_t drop_thresh24; float inv_keep;
+  int dbg_slot;
+};
+void qkv_bwd_fused(hipStream_t s, DType dt, const QkvBwdArgs& a, float* dlnw, float* dlnb, PartialSink* sink);
+
+// Backward of the second half of a transformer layer below the FFN, in one launch (replaces
+// layernorm_bwd + gemm_nt (output-projection^T)):  dh = dy + LN2'(dhn) ; dao = dh . Wo ; dln2 w/b records.
+// Wot [256][256]: fragment-PACKED.
+struct LnOutBwdArgs {
+  const void* dHN; const void* Hres; const float* mean; const float* rstd; const float* ln_w; const void* dY;
+  const void* Wot;
+  void* dH; void* dAO;
+  float* rec; int rec_stride;
+  int N;
+  int dbg_slot;
+};
+void lnout_bwd_fused(hipStream_t s, DType dt, const LnOutBwdArgs& a, float* dlnw, float* dlnb, PartialSink* sink);
+
 // ----------------------------------------------------------------------------- attention
 struct AttnArgs {
   const void* QC; int ldqc;   // q = QC[:, 0:256] (un-roped)

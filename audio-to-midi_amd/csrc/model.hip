@@ -48,6 +48,7 @@ struct LayerP {
   size_t ln1_w, ln1_b, wqc, wkv, wo, ln2_w, ln2_b, w1, b1, w2, b2;
   size_t c_wqc, c_wqct, c_wkv, c_wkvt, c_wo, c_wot, c_w1, c_w1t, c_w2, c_w2t;
   size_t c_wop, c_w1p, c_w2p, c_wqcp, c_wkvp;   // fragment-packed copies for the chain kernels
+  size_t c_wotp, c_wqctp, c_wkvtp;              // packed transposes (backward chains)
 };
 
 struct Layout {
@@ -189,6 +190,14 @@ Layout build_layout(const amt_config& c) {
     l.c_wop = cpacked(l.wo, H, HD);
     l.c_wqcp = cpacked(l.wqc, L.QC, H);
     l.c_wkvp = cpacked(l.wkv, L.KVW, c.kv_compress);
+    auto cpacked_t = [&](size_t src, int rows, int cols) {   // packed copy of src^T: dst [rows][cols], src [cols][rows]
+      size_t o = cbuf(chain_packed_elems(rows, cols));
+      L.conv.push_back(ConvDesc{src, o, rows, cols, cols, 1, -1, 1});
+      return o;
+    };
+    l.c_wotp = cpacked_t(l.wo, HD, H);
+    l.c_wqctp = cpacked_t(l.wqc, H, L.QC);
+    l.c_wkvtp = cpacked_t(l.wkv, c.kv_compress, L.KVW);
     l.c_w1p = cpacked(l.w1, L.I2, H);
     l.c_w2p = cpacked(l.w2, H, c.ffn_inter);
     L.layers.push_back(l);
@@ -421,7 +430,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
         void* y = out_buf((size_t)N * C);
         BlockFwdArgs fa{cur, c->P(bp.dw_w), c->P(bp.dw_b), c->P(bp.ln_w), c->P(bp.ln_b), c->WC(bp.c_pw1p), c->P(bp.pw1_b),
                         c->WC(bp.c_pw2p), c->P(bp.pw2_b), c->P(bp.gamma), bs.ln, bs.mean, bs.rstd, bs.u, bs.h, bs.z, y,
-                        B, Lcur, C, (dbg_slot++) | (getenv("AMT_DBG_MODE") ? atoi(getenv("AMT_DBG_MODE")) : 0)};
+                        B, Lcur, C, dbg_slot++};
         RUN(block_fwd_fused(s, dt, fa));
         cur = y;
         continue;
@@ -669,6 +678,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
                     G(L.hd_lnb), N, H, &sink);
   end_scope();
 
+  const void* pre_dropped = nullptr;
   for (int li = (int)L.layers.size() - 1; li >= 0; --li) {
     const LayerP& lp = L.layers[li];
     const LayerSave& ls = c->lsave[li];
@@ -677,10 +687,15 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     const void* dy = dcur;
     const void* dyd = dy;
     if (dp.thr) {
-      void* t = A.alloc((size_t)N * H * es);
-      RUN(dropout_apply(s, dt, dy, t, (size_t)N * H, seed, stream_ffn(li), dp.thr, dp.inv_keep));
-      dyd = t;
+      if (pre_dropped != nullptr) {
+        dyd = pre_dropped;            // written by the previous scope's qkv_bwd_fused
+      } else {
+        void* t = A.alloc((size_t)N * H * es);
+        RUN(dropout_apply(s, dt, dy, t, (size_t)N * H, seed, stream_ffn(li), dp.thr, dp.inv_keep));
+        dyd = t;
+      }
     }
+    pre_dropped = nullptr;
     // FFN
     wgrad(dyd, H, ls.g, L.I2 / 2, N, H, L.I2 / 2, lp.w2, L.I2 / 2, (long)lp.b2, 0);
     void* du = A.alloc((size_t)N * L.I2 * es);
@@ -695,12 +710,21 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       GemmArgs g = gargs(du, L.I2, c->WC(lp.c_w1t), L.I2, N, H, L.I2, nullptr, dhn2, H);
       RUN(gemm_nt(s, dt, EPI_STORE, g));
     }
+    const bool chain_ok = c->fuse && H == 256 && cfg.ffn_inter == 512 && cfg.n_heads * cfg.head_dim == 256 &&
+                          cfg.kv_compress == 64;
     void* dh = A.alloc((size_t)N * H * es);
-    layernorm_bwd(s, dt, dhn2, ls.h, ls.m2, ls.r2, c->P(lp.ln2_w), dy, dh, G(lp.ln2_w), G(lp.ln2_b), N, H, &sink);
-    // attention output projection
-    wgrad(dh, H, ls.ao, H, N, H, H, lp.wo, H, -1, 0);
     void* dao = A.alloc((size_t)N * H * es);
-    {
+    if (chain_ok) {
+      LnOutBwdArgs la;
+      memset(&la, 0, sizeof(la));
+      la.dHN = dhn2; la.Hres = ls.h; la.mean = ls.m2; la.rstd = ls.r2; la.ln_w = c->P(lp.ln2_w); la.dY = dy;
+      la.Wot = c->WC(lp.c_wotp); la.dH = dh; la.dAO = dao; la.N = N; la.dbg_slot = 0;
+      lnout_bwd_fused(s, dt, la, G(lp.ln2_w), G(lp.ln2_b), &sink);
+      wgrad(dh, H, ls.ao, H, N, H, H, lp.wo, H, -1, 0);
+    } else {
+      layernorm_bwd(s, dt, dhn2, ls.h, ls.m2, ls.r2, c->P(lp.ln2_w), dy, dh, G(lp.ln2_w), G(lp.ln2_b), N, H, &sink);
+      // attention output projection
+      wgrad(dh, H, ls.ao, H, N, H, H, lp.wo, H, -1, 0);
       GemmArgs g = gargs(dh, H, c->WC(lp.c_wot), H, N, H, H, nullptr, dao, H);
       RUN(gemm_nt(s, dt, EPI_STORE, g));
     }
@@ -714,25 +738,40 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     ab.f.seed = seed; ab.f.stream = stream_attn(li); ab.f.drop_thresh24 = dp.thr; ab.f.inv_keep = dp.inv_keep;
     ab.dO = dao; ab.lddo = H; ab.dQC = dqc; ab.lddqc = L.QC; ab.dKV = dkv; ab.lddkv = L.KVW; ab.delta = delta;
     if (local) RUN(attn_local_bwd(s, dt, ab)); else RUN(attn_global_bwd(s, dt, ab));
-    // k/v up-projection
     const int ckv = cfg.kv_compress;
     const void* cptr = static_cast<const char*>(ls.qc) + (size_t)(L.QC - ckv) * es;
-    wgrad(dkv, L.KVW, cptr, L.QC, N, L.KVW, ckv, lp.wkv, ckv, -1, 0);
-    {
-      void* dcp = static_cast<char*>(dqc) + (size_t)(L.QC - ckv) * es;
-      GemmArgs g = gargs(dkv, L.KVW, c->WC(lp.c_wkvt), L.KVW, N, ckv, L.KVW, nullptr, dcp, L.QC);
-      RUN(gemm_nt(s, dt, EPI_STORE, g));
-    }
-    // q / kv-down projection
-    wgrad(dqc, L.QC, ls.xn, H, N, L.QC, H, lp.wqc, H, -1, 0);
-    void* dxn = A.alloc((size_t)N * H * es);
-    {
-      GemmArgs g = gargs(dqc, L.QC, c->WC(lp.c_wqct), L.QC, N, H, L.QC, nullptr, dxn, H);
-      RUN(gemm_nt(s, dt, EPI_STORE, g));
-    }
     di = (di + 1) % 3;
     void* dx = dbuf[di];
-    layernorm_bwd(s, dt, dxn, ls.x, ls.m1, ls.r1, c->P(lp.ln1_w), dh, dx, G(lp.ln1_w), G(lp.ln1_b), N, H, &sink);
+    if (chain_ok) {
+      QkvBwdArgs qa;
+      memset(&qa, 0, sizeof(qa));
+      qa.dKV = dkv; qa.dQC = dqc; qa.Wkvt = c->WC(lp.c_wkvtp); qa.Wqct = c->WC(lp.c_wqctp);
+      qa.X = ls.x; qa.mean = ls.m1; qa.rstd = ls.r1; qa.ln_w = c->P(lp.ln1_w); qa.dH = dh; qa.dX = dx; qa.N = N;
+      if (dp.thr && li > 0) {   // the next scope's FFN-output dropout mask is applied here (saves its dropout_apply launch)
+        void* dxd = A.alloc((size_t)N * H * es);
+        qa.dXD = dxd; qa.seed = seed; qa.stream = stream_ffn(li - 1); qa.drop_thresh24 = dp.thr; qa.inv_keep = dp.inv_keep;
+        pre_dropped = dxd;
+      }
+      qkv_bwd_fused(s, dt, qa, G(lp.ln1_w), G(lp.ln1_b), &sink);
+      wgrad(dkv, L.KVW, cptr, L.QC, N, L.KVW, ckv, lp.wkv, ckv, -1, 0);
+      wgrad(dqc, L.QC, ls.xn, H, N, L.QC, H, lp.wqc, H, -1, 0);
+    } else {
+      // k/v up-projection
+      wgrad(dkv, L.KVW, cptr, L.QC, N, L.KVW, ckv, lp.wkv, ckv, -1, 0);
+      {
+        void* dcp = static_cast<char*>(dqc) + (size_t)(L.QC - ckv) * es;
+        GemmArgs g = gargs(dkv, L.KVW, c->WC(lp.c_wkvt), L.KVW, N, ckv, L.KVW, nullptr, dcp, L.QC);
+        RUN(gemm_nt(s, dt, EPI_STORE, g));
+      }
+      // q / kv-down projection
+      wgrad(dqc, L.QC, ls.xn, H, N, L.QC, H, lp.wqc, H, -1, 0);
+      void* dxn = A.alloc((size_t)N * H * es);
+      {
+        GemmArgs g = gargs(dqc, L.QC, c->WC(lp.c_wqct), L.QC, N, H, L.QC, nullptr, dxn, H);
+        RUN(gemm_nt(s, dt, EPI_STORE, g));
+      }
+      layernorm_bwd(s, dt, dxn, ls.x, ls.m1, ls.r1, c->P(lp.ln1_w), dh, dx, G(lp.ln1_w), G(lp.ln1_b), N, H, &sink);
+    }
     dcur = dx;
     end_scope();
   }

@@ -57,13 +57,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dY, c
     loadvf<VEC>(X + row * C + sub * VEC, x);
     loadvf<VEC>(dY + row * C + sub * VEC, dy);
     float mu = mean[row], rs = rstd[row];
+    // explicit roundings (no compiler-chosen fma contraction): the chain kernels (chain.h:
+    // chain_ln_bwd_rows) use the same sequence
     float s1 = 0.f, s2 = 0.f, gy[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      x[i] = (x[i] - mu) * rs;          // xhat
-      gy[i] = dy[i] * wv[i];
-      s1 += gy[i];
-      s2 += gy[i] * x[i];
+      x[i] = __fmul_rn(__fsub_rn(x[i], mu), rs);          // xhat
+      gy[i] = __fmul_rn(dy[i], wv[i]);
+      s1 = __fadd_rn(s1, gy[i]);
+      s2 = __fmaf_rn(gy[i], x[i], s2);
       aw[i] += dy[i] * x[i];
       ab[i] += dy[i];
     }
@@ -71,12 +73,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dY, c
     s2 = group_sum<LPR>(s2) * (1.f / C);
     float o[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) o[i] = rs * (gy[i] - s1 - x[i] * s2);
+    for (int i = 0; i < VEC; ++i) o[i] = __fmul_rn(rs, __fmaf_rn(-x[i], s2, __fsub_rn(gy[i], s1)));
     if (dRes != nullptr) {
       float rr[VEC];
       loadvf<VEC>(dRes + row * C + sub * VEC, rr);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) o[i] += rr[i];
+      for (int i = 0; i < VEC; ++i) o[i] = __fadd_rn(o[i], rr[i]);
     }
     storevf<VEC>(dX + row * C + sub * VEC, o);
   }
