@@ -59,7 +59,9 @@ template <int C> struct BlockTile {   // tokens per workgroup (bf16); chosen for
   static constexpr int TT = C <= 16 ? 128 : (C <= 32 ? 64 : (C <= 64 ? 32 : 16));
 };
 
-template <typename T, int C, int TT>
+// SAVE = false (inference): nothing but y leaves the workgroup and the tile is 2-4x longer, so the
+// weights are streamed once per 64-512 tokens instead of once per 16-128.
+template <typename T, int C, int TT, bool SAVE>
 __global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
   constexpr int H2 = 2 * C, LDX = C + 8, LDH = H2 + 8;
   constexpr int LPR = C / 8, RPP = 256 / LPR;   // lanes per row, rows per pass of the row phase
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
   T* Xs = reinterpret_cast<T*>(chain_smem);            // [TT][LDX]  LN output
   T* Rs = Xs + TT * LDX;                               // [TT][LDX]  block input (residual)
   T* Hs = Rs + TT * LDX;                               // [TT][LDH]  gelu(u)
-  T* Us = Hs + TT * LDH;                               // [TT][LDH]  u (staged for a coalesced copy-out)
+  T* Us = Hs + TT * LDH;                               // [TT][LDH]  u (staged for a coalesced copy-out; SAVE only)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
 #ifdef AMT_CHAIN_TIMING
       if (!(a.dbg_slot & 1024))
 #endif
-      if (valid) {
+      if (SAVE && valid) {
         store8f(reinterpret_cast<T*>(a.LN) + row * C + sub * 8, y);
         if (sub == 0) { a.mean[row] = mu; a.rstd[row] = rs; }
       }
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
           h[i] = gelu_tanh(u[i]);
         }
         store4f(Hs + p * LDH + m, h);
-        store4f(Us + p * LDH + m, u);
+        if constexpr (SAVE) store4f(Us + p * LDH + m, u);
       }
     }
   }
@@ -193,8 +195,10 @@ __global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
   if (!(a.dbg_slot & 256))
 #endif
   {
-  chain_copy_out<T, TT, H2, LDH>(Us, reinterpret_cast<T*>(a.U), n0, N, tid);
-  chain_copy_out<T, TT, H2, LDH>(Hs, reinterpret_cast<T*>(a.Hh), n0, N, tid);
+  if constexpr (SAVE) {
+    chain_copy_out<T, TT, H2, LDH>(Us, reinterpret_cast<T*>(a.U), n0, N, tid);
+    chain_copy_out<T, TT, H2, LDH>(Hs, reinterpret_cast<T*>(a.Hh), n0, N, tid);
+  }
   }
 
   // ---- stage 2: z = h . W2^T + b2 ; y = x + gamma * z
@@ -225,35 +229,36 @@ __global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
 #ifdef AMT_CHAIN_TIMING
   if (!(a.dbg_slot & 512))
 #endif
-  chain_copy_out<T, TT, C, LDX>(Xs, reinterpret_cast<T*>(a.Z), n0, N, tid);
+  if constexpr (SAVE) chain_copy_out<T, TT, C, LDX>(Xs, reinterpret_cast<T*>(a.Z), n0, N, tid);
   chain_copy_out<T, TT, C, LDX>(Rs, reinterpret_cast<T*>(a.Y), n0, N, tid);
   AMT_STAMP(5);
   AMT_STAMP_RT(7);
 }
 
-template <typename T, int C>
+template <typename T, int C, bool SAVE>
 static void block_fwd_fused_launch(hipStream_t s, const BlockFwdArgs& a) {
-  constexpr int TT = BlockTile<C>::TT;
-  constexpr size_t lds = sizeof(T) * (size_t)TT * (2 * (C + 8) + 2 * (2 * C + 8));
+  constexpr int TT = BlockTile<C>::TT * (SAVE ? 1 : (sizeof(T) == 4 || C == 256 ? 2 : 4));
+  constexpr size_t lds = sizeof(T) * (size_t)TT * (2 * (C + 8) + (SAVE ? 2 : 1) * (2 * C + 8));
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool once = (lds > 64 * 1024
-                          ? (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block_fwd_fused_kernel<T, C, TT>),
+                          ? (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block_fwd_fused_kernel<T, C, TT, SAVE>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                           : (void)0,
                       true);
   (void)once;
   const long N = (long)a.B * a.L;
   const int grid = (int)((N + TT - 1) / TT);
-  hipLaunchKernelGGL((block_fwd_fused_kernel<T, C, TT>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((block_fwd_fused_kernel<T, C, TT, SAVE>), dim3(grid), dim3(256), lds, s, a);
 }
 
 void block_fwd_fused(hipStream_t s, DType dt, const BlockFwdArgs& a) {
   const double N = (double)a.B * a.L, es = dt == DT_F32 ? 4 : 2;
-  ProfScope ps(s, "block_fwd_fused", 2.0 * N * (7.0 * a.C + 4.0 * a.C * a.C), (8.0 * N * a.C + 4.0 * a.C * a.C) * es);
+  const bool save = a.U != nullptr;   // inference passes no save tensors
+  ProfScope ps(s, "block_fwd_fused", 2.0 * N * (7.0 * a.C + 4.0 * a.C * a.C), ((save ? 8.0 : 2.0) * N * a.C + 4.0 * a.C * a.C) * es);
 #define AMT_BF_CASE(CC_)                                                  \
   case CC_:                                                               \
-    if (dt == DT_F32) block_fwd_fused_launch<float, CC_>(s, a);           \
-    else block_fwd_fused_launch<bf16, CC_>(s, a);                         \
+    if (dt == DT_F32) { if (save) block_fwd_fused_launch<float, CC_, true>(s, a); else block_fwd_fused_launch<float, CC_, false>(s, a); }  \
+    else { if (save) block_fwd_fused_launch<bf16, CC_, true>(s, a); else block_fwd_fused_launch<bf16, CC_, false>(s, a); }                  \
     break
   switch (a.C) {
     AMT_BF_CASE(16);

@@ -431,6 +431,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
         BlockFwdArgs fa{cur, c->P(bp.dw_w), c->P(bp.dw_b), c->P(bp.ln_w), c->P(bp.ln_b), c->WC(bp.c_pw1p), c->P(bp.pw1_b),
                         c->WC(bp.c_pw2p), c->P(bp.pw2_b), c->P(bp.gamma), bs.ln, bs.mean, bs.rstd, bs.u, bs.h, bs.z, y,
                         B, Lcur, C, dbg_slot++};
+        if (!save) { fa.LN = nullptr; fa.mean = nullptr; fa.rstd = nullptr; fa.U = nullptr; fa.Hh = nullptr; fa.Z = nullptr; }
         RUN(block_fwd_fused(s, dt, fa));
         cur = y;
         continue;

@@ -85,6 +85,103 @@ def cpu_baseline(seconds_budget: float = 25.0):
                       f"({med:.2f} s/step); torch-CPU restatement of the reference (JAX unavailable offline)"}
 
 
+def named_rooflines(breakdown, profile_steps):
+    """north_star: achieved fraction of the attention-MFMA and the conv-frontend-HBM rooflines.
+    attention: QK^T + PV flops credited by the launchers (4 B H S^2 64 forward, 2x backward) over the time of
+    the four attention kernels.  conv frontend: SURVEY.md 8(d) algorithmic bytes (23.94 MB bf16 per 10-s clip
+    forward, backward counted 2x) over the time of the CNN kernel classes (the Block-backward launches also
+    carry weight-gradient workgroups, and the 6 downsample LayerNorm/GEMM launches are not separable from
+    the transformer's: the first overstates, the second understates the time by a few percent)."""
+    att = [b for b in breakdown if b["kernel"].startswith("attn_")]
+    cnn = [b for b in breakdown if b["kernel"].split("+")[0] in ("stem_fwd", "stem_bwd", "block_small_fwd", "block_small_bwd",
+                                                                  "block_fwd_fused", "block_bwd_fused", "dwblock_bwd", "dwln_fwd")]
+    out = {}
+    t_att = sum(b["avg_us"] * b["launches_per_step"] for b in att) * 1e-6
+    if t_att > 0:
+        fl = sum((b["tflops"] or 0) * 1e12 * b["avg_us"] * 1e-6 * b["launches_per_step"] for b in att if b["kernel"].count("+") == 0)
+        out["attention_mfma"] = {"achieved_tflops": round(fl / t_att / 1e12, 2), "peak_tflops": PEAK_BF16_TFLOPS,
+                                 "frac": round(fl / t_att / 1e12 / PEAK_BF16_TFLOPS, 5), "us_per_step": round(t_att * 1e6, 1)}
+    t_cnn = sum(b["avg_us"] * b["launches_per_step"] for b in cnn) * 1e-6
+    if t_cnn > 0:
+        by = B_PER_GPU * 23.94e6 * 3.0
+        out["conv_frontend_hbm"] = {"achieved_gbs": round(by / t_cnn / 1e9, 1), "peak_gbs": PEAK_HBM_GBS,
+                                    "frac": round(by / t_cnn / 1e9 / PEAK_HBM_GBS, 5), "us_per_step": round(t_cnn * 1e6, 1),
+                                    "algorithmic_bytes_per_step": by}
+    return out
+
+
+def main_infer(args):
+    """BASELINE configs[3]: 32 clips x 60 s, overlap 0.5 s -> 14 windows of 5 s per clip =
+    448 windows (448, 2, 80000), forward only (bf16), then stitch_probs per clip on the host (C++)."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    import audio_to_midi_amd as amt
+    from audio_to_midi_amd import infer as amt_infer, lib as amtlib
+    model = amt.OutputSequenceGenerator(amt.model_config, key=1234, dtype="bfloat16", device=dev)
+    clips, seconds, overlap = 32, 60.0, 0.5
+    rng = np.random.default_rng(0)
+    full = rng.standard_normal((2, int(seconds * 16000))).astype(np.float32)
+    windows, _ = amt_infer.slice_full_audio(amt_infer.normalize_audio(full), overlap)
+    n_win = windows.shape[0]
+    batch = torch.from_numpy(np.tile(windows, (clips, 1, 1))).to(dev, torch.bfloat16)     # resident in HBM
+    B = batch.shape[0]
+
+    def step():
+        return model.predict(None, batch)
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits, probs = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = 1e3 * elapsed / args.steps
+    # host part: stitch every clip (device -> host copy + C++ stitch), timed separately
+    t1 = time.perf_counter()
+    p = probs.float().cpu().numpy().reshape(clips, n_win, -1, probs.shape[-1])
+    stitched = [amt_infer.stitch_output_probs(p[i], 5.0 / p.shape[2], overlap) for i in range(clips)]
+    host_ms = 1e3 * (time.perf_counter() - t1)
+    breakdown = []
+    if args.profile_steps > 0:
+        amtlib.profile_begin()
+        for _ in range(args.profile_steps):
+            step()
+        ents = amtlib.profile_end()
+        tot = sum(e["total_ms"] for e in ents) or 1.0
+        ents.sort(key=lambda e: -e["total_ms"])
+        for e in ents:
+            avg_us = 1e3 * e["total_ms"] / e["launches"]
+            breakdown.append({"kernel": e["name"], "launches_per_step": e["launches"] // args.profile_steps,
+                              "avg_us": round(avg_us, 2), "share": round(e["total_ms"] / tot, 4),
+                              "tflops": round(e["flops"] / e["total_ms"] / 1e9, 2) if e["flops"] else None,
+                              "gbs": round(e["bytes"] / e["total_ms"] / 1e6, 1)})
+        log("kernel class breakdown (HIP events, eager), inference:")
+        for b in breakdown:
+            log(f"  {b['kernel']:32s} x{b['launches_per_step']:4d}  avg {b['avg_us']:9.2f} us  share {100*b['share']:5.1f}%"
+                f"  {b['tflops']} TFLOP/s  {b['gbs']} GB/s")
+    cnn = [b for b in breakdown if b["kernel"] in ("stem_fwd", "block_small_fwd", "block_fwd_fused", "dwln_fwd")]
+    t_cnn = sum(b["avg_us"] * b["launches_per_step"] for b in cnn) * 1e-6
+    conv = None
+    if t_cnn > 0:
+        by = B * 11.97e6        # SURVEY.md 8(d): 11.97 MB bf16 per 5-s clip forward
+        conv = {"achieved_gbs": round(by / t_cnn / 1e9, 1), "peak_gbs": PEAK_HBM_GBS, "frac": round(by / t_cnn / 1e9 / PEAK_HBM_GBS, 5),
+                "us_per_step": round(t_cnn * 1e6, 1), "algorithmic_bytes_per_step": by}
+    out = {"metric": "audio-sec/s (inference fwd, 5 s windows)", "value": round(clips * seconds / (elapsed / args.steps), 1),
+           "unit": "audio-sec/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "streaming inference (BASELINE configs[3]): 32 clips x 60 s -> 448 windows x 5 s, "
+                                  "forward (bf16) resident in HBM; stitch_probs on the host timed separately",
+                      "windows": int(B), "frames_per_window": int(probs.shape[1]), "stitched_frames_per_clip": int(stitched[0].shape[0])},
+           "model_tflops": round(B * 7.946e9 / (elapsed / args.steps) / 1e12, 2),
+           "host_copy_and_stitch_ms": round(host_ms, 1),
+           "rooflines": {"conv_frontend_hbm": conv}, "breakdown": breakdown[:12]}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,7 +191,12 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--workload", choices=["train", "infer"], default="train",
+                    help="train = BASELINE configs[1] (default, the headline metric); infer = configs[3]: streaming "
+                         "inference, 32 x 60 s clips -> 448 windows of 5 s, forward + stitch (reported, not the headline)")
     args = ap.parse_args()
+    if args.workload == "infer":
+        return main_infer(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -244,6 +346,7 @@ def main():
             "model_tflops": round(world * FLOPS_PER_STEP / (elapsed / args.steps) / 1e12, 2),
             "loss": round(loss_val, 3),
             "roofline": roofline,
+            "rooflines": named_rooflines(breakdown, args.profile_steps) if breakdown else None,
             "cpu_baseline": cpu,
             "breakdown": breakdown[:12],
         }
