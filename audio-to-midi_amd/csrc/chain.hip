@@ -858,12 +858,16 @@ void qkv_fwd_fused(hipStream_t s, DType dt, const QkvFwdArgs& a) {
 
 // ------------------------------------------------------------------ transformer layer backward chains
 template <typename T, int TT>
-__global__ __launch_bounds__(256) void qkv_bwd_fused_kernel(QkvBwdArgs a) {
+__global__ __launch_bounds__(256) void qkv_bwd_fused_kernel(QkvBwdArgs a, WgradGroup riders) {
   constexpr int H = 256, QC = 320, CK = 64, KV = 512, LDX = H + 8, LDQ = QC + 8, LDK = KV + 8;
   using SC = ChainSplit<CK, TT>;     // dc: 64 features
   using SX = ChainSplit<H, TT>;      // dxn: 256 features
   constexpr int KCC = ChainChunk<T, SC::RB, KV>::KC, KCX = ChainChunk<T, SX::RB, QC, 32>::KC;
   extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  if ((int)blockIdx.x >= a.n_chain) {   // weight gradients of the previous scope ride on this launch
+    wgrad_group_dispatch<T>(riders, (int)blockIdx.x - a.n_chain, chain_smem);
+    return;
+  }
   T* Ks = reinterpret_cast<T*>(chain_smem);   // [TT][LDK]  dkv
   T* Qs = Ks + TT * LDK;                      // [TT][LDQ]  dqc (dq | dc)
   T* Xs = Qs + TT * LDQ;                      // [TT][LDX]  dxn, then dx
@@ -954,11 +958,15 @@ __global__ __launch_bounds__(256) void qkv_bwd_fused_kernel(QkvBwdArgs a) {
 }
 
 template <typename T, int TT>
-__global__ __launch_bounds__(256) void lnout_bwd_fused_kernel(LnOutBwdArgs a) {
+__global__ __launch_bounds__(256) void lnout_bwd_fused_kernel(LnOutBwdArgs a, WgradGroup riders) {
   constexpr int H = 256, LDX = H + 8;
   using SO = ChainSplit<H, TT>;
-  constexpr int KCO = ChainChunk<T, SO::RB, H, 32>::KC;
+  constexpr int KCO = ChainChunk<T, SO::RB, H>::KC;   // 16 fragments per set: two waves per SIMD with the riders
   extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  if ((int)blockIdx.x >= a.n_chain) {
+    wgrad_group_dispatch<T>(riders, (int)blockIdx.x - a.n_chain, chain_smem);
+    return;
+  }
   T* Ds = reinterpret_cast<T*>(chain_smem);   // [TT][LDX]  dhn, then dh
   T* Os = Ds + TT * LDX;                      // [TT][LDX]  dao (staged for the copy-out)
   float* part = reinterpret_cast<float*>(Os); // [4][2 * 256] before Os is used
@@ -1018,22 +1026,24 @@ template <typename K> static void chain_set_lds(K kernel, size_t bytes) {
 }
 
 template <typename T>
-static void qkv_bwd_fused_launch(hipStream_t s, const QkvBwdArgs& a, int nb) {
+static void qkv_bwd_fused_launch(hipStream_t s, const QkvBwdArgs& a, const WgradGroup& rg, int n_rider_wgs) {
   constexpr int TT = FfnTile<T>::TT;
-  constexpr size_t lds = sizeof(T) * (size_t)TT * ((512 + 8) + (320 + 8) + (256 + 8));
+  constexpr size_t lds_chain = sizeof(T) * (size_t)TT * ((512 + 8) + (320 + 8) + (256 + 8));
+  constexpr size_t lds = lds_chain > TnLds<T>::BYTES ? lds_chain : TnLds<T>::BYTES;
   static_assert(lds <= 160 * 1024 && sizeof(T) * TT * (512 + 8) >= sizeof(float) * 8 * 256, "LDS budget");
   static bool once = (chain_set_lds(qkv_bwd_fused_kernel<T, TT>, lds), true);
   (void)once;
-  hipLaunchKernelGGL((qkv_bwd_fused_kernel<T, TT>), dim3(nb), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((qkv_bwd_fused_kernel<T, TT>), dim3(a.n_chain + n_rider_wgs), dim3(256), lds, s, a, rg);
 }
 template <typename T>
-static void lnout_bwd_fused_launch(hipStream_t s, const LnOutBwdArgs& a, int nb) {
+static void lnout_bwd_fused_launch(hipStream_t s, const LnOutBwdArgs& a, const WgradGroup& rg, int n_rider_wgs) {
   constexpr int TT = FfnTile<T>::TT;
-  constexpr size_t lds = sizeof(T) * (size_t)TT * 2 * (256 + 8);
+  constexpr size_t lds_chain = sizeof(T) * (size_t)TT * 2 * (256 + 8);
+  constexpr size_t lds = lds_chain > TnLds<T>::BYTES ? lds_chain : TnLds<T>::BYTES;
   static_assert(sizeof(T) * TT * (256 + 8) >= sizeof(float) * 8 * 256, "column-sum slices fit in one panel");
   static bool once = (chain_set_lds(lnout_bwd_fused_kernel<T, TT>, lds), true);
   (void)once;
-  hipLaunchKernelGGL((lnout_bwd_fused_kernel<T, TT>), dim3(nb), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((lnout_bwd_fused_kernel<T, TT>), dim3(a.n_chain + n_rider_wgs), dim3(256), lds, s, a, rg);
 }
 
 static int chain_ln_records(DType dt, int N, float* dlnw, float* dlnb, PartialSink* sink, float** rec) {
@@ -1045,26 +1055,36 @@ static int chain_ln_records(DType dt, int N, float* dlnw, float* dlnb, PartialSi
   return nb;
 }
 
-void qkv_bwd_fused(hipStream_t s, DType dt, const QkvBwdArgs& a_in, float* dlnw, float* dlnb, PartialSink* sink) {
+void qkv_bwd_fused(hipStream_t s, DType dt, const QkvBwdArgs& a_in, float* dlnw, float* dlnb, PartialSink* sink,
+                   const WgradArgs* riders, int n_riders) {
   QkvBwdArgs a = a_in;
-  const int nb = chain_ln_records(dt, a.N, dlnw, dlnb, sink, &a.rec);
+  a.n_chain = chain_ln_records(dt, a.N, dlnw, dlnb, sink, &a.rec);
+  WgradGroup rg;
+  double rfl = 0, rby = 0;
+  const int n_rider_wgs = wgrad_group_prepare(dt, riders, n_riders, sink, &rg, &rfl, &rby);
   if (sink->dry) return;
   a.rec_stride = 512;
   const double N = a.N, es = dt == DT_F32 ? 4 : 2;
-  ProfScope ps(s, "qkv_bwd_fused", 2.0 * N * (64.0 * 512 + 256.0 * 320), (N * (512 + 320 + 64 + 256 * 4.0) + 64.0 * 512 + 256.0 * 320) * es);
-  if (dt == DT_F32) qkv_bwd_fused_launch<float>(s, a, nb);
-  else qkv_bwd_fused_launch<bf16>(s, a, nb);
+  ProfScope ps(s, n_rider_wgs > 0 ? "qkv_bwd_fused+wgrad" : "qkv_bwd_fused", 2.0 * N * (64.0 * 512 + 256.0 * 320) + rfl,
+               (N * (512 + 320 + 64 + 256 * 4.0) + 64.0 * 512 + 256.0 * 320) * es + rby);
+  if (dt == DT_F32) qkv_bwd_fused_launch<float>(s, a, rg, n_rider_wgs);
+  else qkv_bwd_fused_launch<bf16>(s, a, rg, n_rider_wgs);
 }
 
-void lnout_bwd_fused(hipStream_t s, DType dt, const LnOutBwdArgs& a_in, float* dlnw, float* dlnb, PartialSink* sink) {
+void lnout_bwd_fused(hipStream_t s, DType dt, const LnOutBwdArgs& a_in, float* dlnw, float* dlnb, PartialSink* sink,
+                     const WgradArgs* riders, int n_riders) {
   LnOutBwdArgs a = a_in;
-  const int nb = chain_ln_records(dt, a.N, dlnw, dlnb, sink, &a.rec);
+  a.n_chain = chain_ln_records(dt, a.N, dlnw, dlnb, sink, &a.rec);
+  WgradGroup rg;
+  double rfl = 0, rby = 0;
+  const int n_rider_wgs = wgrad_group_prepare(dt, riders, n_riders, sink, &rg, &rfl, &rby);
   if (sink->dry) return;
   a.rec_stride = 512;
   const double N = a.N, es = dt == DT_F32 ? 4 : 2;
-  ProfScope ps(s, "lnout_bwd_fused", 2.0 * N * 256.0 * 256, (N * 256 * 5.0 + 256.0 * 256) * es);
-  if (dt == DT_F32) lnout_bwd_fused_launch<float>(s, a, nb);
-  else lnout_bwd_fused_launch<bf16>(s, a, nb);
+  ProfScope ps(s, n_rider_wgs > 0 ? "lnout_bwd_fused+wgrad" : "lnout_bwd_fused", 2.0 * N * 256.0 * 256 + rfl,
+               (N * 256 * 5.0 + 256.0 * 256) * es + rby);
+  if (dt == DT_F32) lnout_bwd_fused_launch<float>(s, a, rg, n_rider_wgs);
+  else lnout_bwd_fused_launch<bf16>(s, a, rg, n_rider_wgs);
 }
 
 }  // namespace amt

@@ -197,10 +197,12 @@ struct QkvBwdArgs {
   void* dX; void* dXD;
   float* rec; int rec_stride;                 // set by the launcher
   int N;
+  int n_chain;                                // workgroups of the chain; the rest run the riders (launcher)
   uint64_t seed; uint32_t stream; uint32_t drop_thresh24; float inv_keep;
   int dbg_slot;
 };
-void qkv_bwd_fused(hipStream_t s, DType dt, const QkvBwdArgs& a, float* dlnw, float* dlnb, PartialSink* sink);
+void qkv_bwd_fused(hipStream_t s, DType dt, const QkvBwdArgs& a, float* dlnw, float* dlnb, PartialSink* sink,
+                   const WgradArgs* riders = nullptr, int n_riders = 0);   // riders: see block_bwd_fused
 
 // Backward of the second half of a transformer layer below the FFN, in one launch (replaces
 // layernorm_bwd + gemm_nt (output-projection^T)):  dh = dy + LN2'(dhn) ; dao = dh . Wo ; dln2 w/b records.
@@ -211,9 +213,11 @@ struct LnOutBwdArgs {
   void* dH; void* dAO;
   float* rec; int rec_stride;
   int N;
+  int n_chain;
   int dbg_slot;
 };
-void lnout_bwd_fused(hipStream_t s, DType dt, const LnOutBwdArgs& a, float* dlnw, float* dlnb, PartialSink* sink);
+void lnout_bwd_fused(hipStream_t s, DType dt, const LnOutBwdArgs& a, float* dlnw, float* dlnb, PartialSink* sink,
+                     const WgradArgs* riders = nullptr, int n_riders = 0);
 
 // ----------------------------------------------------------------------------- attention
 struct AttnArgs {

@@ -684,7 +684,17 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     const LayerP& lp = L.layers[li];
     const LayerSave& ls = c->lsave[li];
     const bool local = (li % 2 == 0);
-    begin_scope();
+    const bool chain_ok = c->fuse && H == 256 && cfg.ffn_inter == 512 && cfg.n_heads * cfg.head_dim == 256 &&
+                          cfg.kv_compress == 64;
+    // the two backward chain launches of this layer carry the previous scope's weight gradients: the
+    // smaller problems ride on lnout_bwd_fused, the larger ones on qkv_bwd_fused
+    begin_scope(chain_ok && !side_on);
+    std::vector<WgradArgs> riders_a, riders_b;
+    for (const WgradArgs& w : deferred) {
+      const int tiles = ((w.M + 63) / 64) * ((w.Kp + 63) / 64);
+      (tiles < 24 ? riders_a : riders_b).push_back(w);
+    }
+    deferred.clear();
     const void* dy = dcur;
     const void* dyd = dy;
     if (dp.thr) {
@@ -711,8 +721,6 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       GemmArgs g = gargs(du, L.I2, c->WC(lp.c_w1t), L.I2, N, H, L.I2, nullptr, dhn2, H);
       RUN(gemm_nt(s, dt, EPI_STORE, g));
     }
-    const bool chain_ok = c->fuse && H == 256 && cfg.ffn_inter == 512 && cfg.n_heads * cfg.head_dim == 256 &&
-                          cfg.kv_compress == 64;
     void* dh = A.alloc((size_t)N * H * es);
     void* dao = A.alloc((size_t)N * H * es);
     if (chain_ok) {
@@ -720,7 +728,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       memset(&la, 0, sizeof(la));
       la.dHN = dhn2; la.Hres = ls.h; la.mean = ls.m2; la.rstd = ls.r2; la.ln_w = c->P(lp.ln2_w); la.dY = dy;
       la.Wot = c->WC(lp.c_wotp); la.dH = dh; la.dAO = dao; la.N = N; la.dbg_slot = 0;
-      lnout_bwd_fused(s, dt, la, G(lp.ln2_w), G(lp.ln2_b), &sink);
+      lnout_bwd_fused(s, dt, la, G(lp.ln2_w), G(lp.ln2_b), &sink, riders_a.data(), (int)riders_a.size());
       wgrad(dh, H, ls.ao, H, N, H, H, lp.wo, H, -1, 0);
     } else {
       layernorm_bwd(s, dt, dhn2, ls.h, ls.m2, ls.r2, c->P(lp.ln2_w), dy, dh, G(lp.ln2_w), G(lp.ln2_b), N, H, &sink);
@@ -753,7 +761,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
         qa.dXD = dxd; qa.seed = seed; qa.stream = stream_ffn(li - 1); qa.drop_thresh24 = dp.thr; qa.inv_keep = dp.inv_keep;
         pre_dropped = dxd;
       }
-      qkv_bwd_fused(s, dt, qa, G(lp.ln1_w), G(lp.ln1_b), &sink);
+      qkv_bwd_fused(s, dt, qa, G(lp.ln1_w), G(lp.ln1_b), &sink, riders_b.data(), (int)riders_b.size());
       wgrad(dkv, L.KVW, cptr, L.QC, N, L.KVW, ckv, lp.wkv, ckv, -1, 0);
       wgrad(dqc, L.QC, ls.xn, H, N, L.QC, H, lp.wqc, H, -1, 0);
     } else {
