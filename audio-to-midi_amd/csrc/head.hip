@@ -110,7 +110,26 @@ void grads_finalize(hipStream_t s, float* g, size_t n, float mul, int* valid_fla
 __global__ void fill_kernel(float* p, float v, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
+__global__ void fill4_kernel(f32x4* p, float v, size_t n4) {
+  const f32x4 vv = f32x4{v, v, v, v};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) p[i] = vv;
+}
+__global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void copy_f32(hipStream_t s, const float* src, float* dst, size_t n) {
+  int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(copy_f32_kernel, dim3(grid), dim3(256), 0, s, src, dst, n);
+}
 void fill_f32(hipStream_t s, float* p, float v, size_t n) {
+  if (n >= 65536 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {   // 16-byte stores for the big buffers
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(fill4_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<f32x4*>(p), v, n4);
+    p += 4 * n4;
+    n -= 4 * n4;
+    if (n == 0) return;
+  }
   int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(fill_kernel, dim3(grid), dim3(256), 0, s, p, v, n);

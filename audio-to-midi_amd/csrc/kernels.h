@@ -257,6 +257,7 @@ void convert_f32(hipStream_t s, DType dt, const float* src, void* dst, size_t n)
 // dst[c][r] = src[r][c]   (src [R x C] fp32 -> dst [C x R] T)
 void convert_transpose(hipStream_t s, DType dt, const float* src, void* dst, int R, int C);
 void fill_f32(hipStream_t s, float* p, float v, size_t n);
+void copy_f32(hipStream_t s, const float* src, float* dst, size_t n);
 
 // AdamW (optax.adamw) on the flat parameter vector with per-segment learning rates
 // pass 1: update m, v, write the (unclipped) update into upd, accumulate sum(upd^2) into norm2[0]

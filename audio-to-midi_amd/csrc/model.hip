@@ -279,6 +279,7 @@ struct amt_ctx {
   size_t scratch_max = 0;       // bytes of per-scope backward scratch (two alternating regions)
   bool use_side = false;
   bool fuse = true;             // chain kernels (chain.hip); AMT_FUSE=0 selects the unfused launch sequence
+  int nochain = 0;              // debugging: AMT_NOCHAIN bit mask disables individual chain kernels / riders
   bool fuse_ffn = false;        // AMT_FUSE_FFN=1: whole second half of a layer in one launch (measured slower)
 
   const float* P(size_t off) const { return params + off; }
@@ -426,7 +427,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
         cur = y;
         continue;
       }
-      if (c->fuse) {
+      if (c->fuse && !(c->nochain & 1)) {
         void* y = out_buf((size_t)N * C);
         BlockFwdArgs fa{cur, c->P(bp.dw_w), c->P(bp.dw_b), c->P(bp.ln_w), c->P(bp.ln_b), c->WC(bp.c_pw1p), c->P(bp.pw1_b),
                         c->WC(bp.c_pw2p), c->P(bp.pw2_b), c->P(bp.gamma), bs.ln, bs.mean, bs.rstd, bs.u, bs.h, bs.z, y,
@@ -480,7 +481,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
     ls.u = A.alloc((size_t)N * L.I2 * es);
     ls.g = A.alloc((size_t)N * (L.I2 / 2) * es);
     const bool chain_ok = c->fuse && H == 256 && cfg.ffn_inter == 512 && cfg.n_heads * cfg.head_dim == 256;
-    if (chain_ok) {
+    if (chain_ok && !(c->nochain & 4)) {
       QkvFwdArgs qa;
       memset(&qa, 0, sizeof(qa));
       qa.X = cur; qa.ln_w = c->P(lp.ln1_w); qa.ln_b = c->P(lp.ln1_b); qa.Wqc = c->WC(lp.c_wqcp); qa.Wkv = c->WC(lp.c_wkvp);
@@ -503,7 +504,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
     // h = x + attn . Wo^T ; out = h + FFN(LN2(h))
     ls.h = save ? A.alloc((size_t)N * H * es) : out_buf(0);
     void* y = save ? A.alloc((size_t)N * H * es) : out_buf(0);
-    if (chain_ok) {
+    if (chain_ok && !(c->nochain & 8)) {
       FfnFwdArgs fa;
       memset(&fa, 0, sizeof(fa));
       fa.AO = ls.ao; fa.X = cur; fa.Wo = c->WC(lp.c_wop); fa.ln_w = c->P(lp.ln2_w); fa.ln_b = c->P(lp.ln2_b);
@@ -651,13 +652,20 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   c->ev_used = 0;
   if (dry) c->ev_needed = 0;
 
-  RUN((void)hipMemsetAsync(grads, 0, L.n_params * sizeof(float), s));
-  RUN((void)hipMemsetAsync(c->loss_acc, 0, 2 * sizeof(float), s));
+  // Kernels, not hipMemsetAsync: under hipGraph replay (ROCm 7.2, MI355X) the captured memset nodes of
+  // this step did not take effect from the second replay on (gradients accumulated over replays;
+  // scratch/graph_dbg2.py), kernel nodes keep their stream order.
+  RUN(fill_f32(s, grads, 0.f, L.n_params));
+  RUN(fill_f32(s, c->loss_acc, 0.f, 2));
 
   // two ping-pong gradient buffers for the residual stream / CNN activations
   const size_t act_elems = (size_t)B * (T / 5) * 4;
   const size_t res_elems = act_elems > (size_t)N * H ? act_elems : (size_t)N * H;
   void* dbuf[3] = {A.alloc(res_elems * es), A.alloc(res_elems * es), A.alloc(res_elems * es)};
+  // dropout-masked copies of the transformer residual gradients rotate the same way: the copy written at
+  // the end of scope t is read by scope t + 1 and by its weight-gradient riders inside scope t + 2
+  void* dropbuf[3] = {nullptr, nullptr, nullptr};
+  if (dp.thr) for (int i = 0; i < 3; ++i) dropbuf[i] = A.alloc((size_t)N * H * es);
   int di = 0;
   mark = A.off;
   A.off = mark + 2 * c->scratch_max;     // both scratch regions are part of the plan
@@ -688,7 +696,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
                           cfg.kv_compress == 64;
     // the two backward chain launches of this layer carry the previous scope's weight gradients: the
     // smaller problems ride on lnout_bwd_fused, the larger ones on qkv_bwd_fused
-    begin_scope(chain_ok && !side_on);
+    begin_scope(chain_ok && !side_on && !(c->nochain & 128));
     std::vector<WgradArgs> riders_a, riders_b;
     for (const WgradArgs& w : deferred) {
       const int tiles = ((w.M + 63) / 64) * ((w.Kp + 63) / 64);
@@ -723,7 +731,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     }
     void* dh = A.alloc((size_t)N * H * es);
     void* dao = A.alloc((size_t)N * H * es);
-    if (chain_ok) {
+    if (chain_ok && !(c->nochain & 16)) {
       LnOutBwdArgs la;
       memset(&la, 0, sizeof(la));
       la.dHN = dhn2; la.Hres = ls.h; la.mean = ls.m2; la.rstd = ls.r2; la.ln_w = c->P(lp.ln2_w); la.dY = dy;
@@ -751,13 +759,13 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     const void* cptr = static_cast<const char*>(ls.qc) + (size_t)(L.QC - ckv) * es;
     di = (di + 1) % 3;
     void* dx = dbuf[di];
-    if (chain_ok) {
+    if (chain_ok && !(c->nochain & 32)) {
       QkvBwdArgs qa;
       memset(&qa, 0, sizeof(qa));
       qa.dKV = dkv; qa.dQC = dqc; qa.Wkvt = c->WC(lp.c_wkvtp); qa.Wqct = c->WC(lp.c_wqctp);
       qa.X = ls.x; qa.mean = ls.m1; qa.rstd = ls.r1; qa.ln_w = c->P(lp.ln1_w); qa.dH = dh; qa.dX = dx; qa.N = N;
-      if (dp.thr && li > 0) {   // the next scope's FFN-output dropout mask is applied here (saves its dropout_apply launch)
-        void* dxd = A.alloc((size_t)N * H * es);
+      if (dp.thr && li > 0 && !(c->nochain & 256)) {   // the next scope's FFN-output dropout mask is applied here (saves its dropout_apply launch)
+        void* dxd = dropbuf[di];
         qa.dXD = dxd; qa.seed = seed; qa.stream = stream_ffn(li - 1); qa.drop_thresh24 = dp.thr; qa.inv_keep = dp.inv_keep;
         pre_dropped = dxd;
       }
@@ -804,7 +812,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     for (int j = (int)st.blocks.size() - 1; j >= 0; --j) {
       const BlockP& bp = st.blocks[j];
       const BlockSave& bs = sv.blocks[j];
-      const bool carrier = c->fuse && C >= 16 && !side_on;
+      const bool carrier = c->fuse && C >= 16 && !side_on && !(c->nochain & 2) && !(c->nochain & 64);
       begin_scope(carrier);
       const void* dy = dcur;
       // layer scale folded away: dz = gamma * dy is never materialised.  The data-gradient GEMM uses a
@@ -812,7 +820,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       // and dgamma = sum dy * z is formed in the fused tail kernel.
       wgrad(dy, C, bs.h, 2 * C, Nn, C, 2 * C, bp.pw2_w, 2 * C, (long)bp.pw2_b, 0, c->P(bp.gamma));
       void* du = A.alloc((size_t)Nn * 2 * C * es);
-      if (c->fuse && C >= 16) {
+      if (c->fuse && C >= 16 && !(c->nochain & 2)) {
         wgrad(du, 2 * C, bs.ln, C, Nn, 2 * C, C, bp.pw1_w, C, (long)bp.pw1_b, 0);
         di = (di + 1) % 3;
         void* dx = dbuf[di];
@@ -959,8 +967,8 @@ int refresh(amt_ctx* c, hipStream_t s) {
   const Layout& L = c->L;
   convert_batch(s, c->dt, c->params, c->wc, c->conv_dev, c->conv_prefix_dev, (int)L.conv.size(), c->conv_tiles);
   // padded head bias
-  (void)hipMemsetAsync(c->head_bias, 0, L.VP * sizeof(float), s);
-  (void)hipMemcpyAsync(c->head_bias, c->params + L.hd_b, c->cfg.n_events * sizeof(float), hipMemcpyDeviceToDevice, s);
+  fill_f32(s, c->head_bias, 0.f, L.VP);
+  copy_f32(s, c->params + L.hd_b, c->head_bias, c->cfg.n_events);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { c->err = std::string("refresh_weights: ") + hipGetErrorString(e); return 1; }
   return 0;
@@ -1038,6 +1046,7 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   // every CU and slow down when sharing them.  Kept as an opt-in for larger per-GPU batches.
   c->use_side = getenv("AMT_SIDE_STREAM") != nullptr;
   c->fuse = !(getenv("AMT_FUSE") && atoi(getenv("AMT_FUSE")) == 0);
+  c->nochain = getenv("AMT_NOCHAIN") ? atoi(getenv("AMT_NOCHAIN")) : 0;
   c->fuse_ffn = getenv("AMT_FUSE_FFN") && atoi(getenv("AMT_FUSE_FFN")) != 0;
   const Layout& L = c->L;
   auto fail = [&](const char* what, hipError_t err) {
@@ -1121,7 +1130,7 @@ int32_t amt_forward_backward(amt_ctx* c, const void* audio, const float* labels,
   if (logits) head_probs(s, c->logits_pad, c->L.VP, logits, nullptr, B * (T / 320), c->cfg.n_events);
   if (run_backward(c, s, audio, labels, B, T, scale, train != 0, seed, grads_flat, grads_valid)) return 1;
   if (c->arena.overflow) { c->err = "internal error: workspace plan too small"; return 1; }
-  (void)hipMemcpyAsync(loss_out, c->loss_acc, 2 * sizeof(float), hipMemcpyDeviceToDevice, s);
+  copy_f32(s, c->loss_acc, loss_out, 2);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { c->err = std::string("amt_forward_backward: ") + hipGetErrorString(e); return 1; }
   return 0;
@@ -1195,7 +1204,7 @@ int32_t amt_adamw_step(amt_ctx* c, const float* grads_flat, float lr_base, float
   if (!c->adam_m || c->lr_scale_decay != layer_lr_decay) {
     if (amt_optimizer_init(c, layer_lr_decay)) return 1;
   }
-  HIPCHK(c, hipMemsetAsync(c->norm2, 0, sizeof(float), s));
+  fill_f32(s, c->norm2, 0.f, 1);
   adamw_compute(s, c->params, grads_flat, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, n, lr_base, b1, b2, eps,
                 weight_decay, step, c->norm2);
   adamw_apply(s, c->params, c->adam_upd, n, c->norm2, clip_norm);

@@ -21,3 +21,27 @@ for i in (1, 2):
         for r in rows:
             if r[1] > 0 and (r[2].startswith("tl.") and (".w" in r[2]) or "conv.weight" in r[2] or "decoder" in r[2] or r[2].endswith("point_conv_1.weight")):
                 print("   %-40s rel %.3g" % (r[2], r[0] / (r[1] + 1e-30)))
+
+# train mode (dropout, fixed seed), eager and under hipGraph replay
+dev = a.device
+for mode in ("eager", "graph"):
+    gbuf = torch.zeros(model.n_params, dtype=torch.float32, device="cuda")
+    ac, yc = a.to("cuda", torch.bfloat16), y.cuda()
+    def fb():
+        model.loss_and_grads(ac, yc, seed=77, train=True, grads_out=gbuf, sync=False)
+    fb(); torch.cuda.synchronize()
+    if mode == "graph":
+        side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fb()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fb()
+        run = g.replay
+    else:
+        run = fb
+    outs2 = []
+    for _ in range(3):
+        run(); torch.cuda.synchronize(); outs2.append(gbuf.clone())
+    print(mode, "train-mode rel", [float((o - outs2[0]).norm() / outs2[0].norm()) for o in outs2[1:]], "norms", [float(o.norm()) for o in outs2], "nonfinite", [int((~torch.isfinite(o)).sum()) for o in outs2])
