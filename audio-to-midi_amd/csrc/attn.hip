@@ -35,15 +35,19 @@ template <> AMT_DEV Frag<float> make_frag<float>(const float (&y)[8]) {
   return f;
 }
 
+// one interleaved pair, explicit rounding sequence (every site that rotates q / k must produce the same
+// bits: forward and backward stage the same tensors independently)
+AMT_DEV void rope_pair(float& x1, float& x2, float c, float s, float scale) {
+  const float a = __fmul_rn(__fmaf_rn(x1, c, -__fmul_rn(x2, s)), scale);
+  const float b = __fmul_rn(__fmaf_rn(x1, s, __fmul_rn(x2, c)), scale);
+  x1 = a; x2 = b;
+}
 // rotate 4 interleaved pairs starting at pair index pi for position pos, then scale
 AMT_DEV void rope8(float (&x)[8], const float* __restrict__ cs, const float* __restrict__ sn, int pos, int pi,
                    float scale) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    float c = cs[pos * 32 + pi + j], s = sn[pos * 32 + pi + j];
-    float x1 = x[2 * j], x2 = x[2 * j + 1];
-    x[2 * j] = (x1 * c - x2 * s) * scale;
-    x[2 * j + 1] = (x1 * s + x2 * c) * scale;
+    rope_pair(x[2 * j], x[2 * j + 1], cs[pos * 32 + pi + j], sn[pos * 32 + pi + j], scale);
   }
 }
 // transpose of the rotation (gradient w.r.t. the un-rotated input) for 2 pairs (4 features)
@@ -76,9 +80,13 @@ AMT_DEV void stage_row_chunk(T* dst, const T* src, bool valid, const float* cs, 
 // K/V tile staging split in two so that the global loads of tile t+1 are in flight while tile t is
 // being multiplied: kv_load issues this thread's four 16-byte loads (rows past the clip are read
 // from a clamped row), kv_store applies RoPE to K, zeroes invalid rows and writes LDS.
+// The RoPE table entries of the tile travel with it (RopeRegs): loaded inside kv_store they cost one more
+// dependent global round trip per key tile, after the barrier.
+struct RopeRegs { float c[2][4], s[2][4]; };
+
 template <typename T>
-AMT_DEV void kv_load(Chunk8<T> (&kc)[2], Chunk8<T> (&vc)[2], const T* KV, int ldkv, int b, int h, int S, int kt,
-                     int tid) {
+AMT_DEV void kv_load(Chunk8<T> (&kc)[2], Chunk8<T> (&vc)[2], RopeRegs& rr, const T* KV, int ldkv, int b, int h, int S,
+                     int kt, int tid, const float* __restrict__ cs, const float* __restrict__ sn) {
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     int id = tid + 256 * it, row = id >> 3, c = id & 7;
@@ -87,11 +95,13 @@ AMT_DEV void kv_load(Chunk8<T> (&kc)[2], Chunk8<T> (&vc)[2], const T* KV, int ld
     const T* kp = KV + (size_t)(b * S + keyc) * ldkv + h * 64 + 8 * c;
     kc[it] = chunk_load(kp);
     vc[it] = chunk_load(kp + 256);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { rr.c[it][j] = cs[keyc * 32 + 4 * c + j]; rr.s[it][j] = sn[keyc * 32 + 4 * c + j]; }
   }
 }
 template <typename T>
-AMT_DEV void kv_store(T* Ks, T* Vs, const Chunk8<T> (&kc)[2], const Chunk8<T> (&vc)[2], int S, int kt, int tid,
-                      const float* cs, const float* sn) {
+AMT_DEV void kv_store(T* Ks, T* Vs, const Chunk8<T> (&kc)[2], const Chunk8<T> (&vc)[2], const RopeRegs& rr, int S, int kt,
+                      int tid) {
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     int id = tid + 256 * it, row = id >> 3, c = id & 7;
@@ -100,7 +110,8 @@ AMT_DEV void kv_store(T* Ks, T* Vs, const Chunk8<T> (&kc)[2], const Chunk8<T> (&
 #pragma unroll
     for (int i = 0; i < 8; ++i) kx[i] = chunk_get(kc[it], i);
     if (key < S) {
-      rope8(kx, cs, sn, key, 4 * c, 1.f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rope_pair(kx[2 * j], kx[2 * j + 1], rr.c[it][j], rr.s[it][j], 1.f);   // = rope8
       store8f(Ks + row * ALD + 8 * c, kx);
       chunk_store(Vs + row * ALD + 8 * c, vc[it]);
     } else {
@@ -156,12 +167,13 @@ __global__ __launch_bounds__(256) void attn_global_fwd_kernel(AttnArgs a) {
 
   const int nkt = (S + 63) / 64;
   Chunk8<T> kc[2], vc[2];
-  kv_load<T>(kc, vc, KV, a.ldkv, b, h, S, 0, tid);
+  RopeRegs rr;
+  kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, 0, tid, a.cos, a.sin);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
-    kv_store<T>(Ks, Vs, kc, vc, S, kt, tid, a.cos, a.sin);
+    kv_store<T>(Ks, Vs, kc, vc, rr, S, kt, tid);
     __syncthreads();
-    if (kt + 1 < nkt) kv_load<T>(kc, vc, KV, a.ldkv, b, h, S, kt + 1, tid);
+    if (kt + 1 < nkt) kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, kt + 1, tid, a.cos, a.sin);
 
     f32x4 sacc[4];
 #pragma unroll
@@ -278,12 +290,13 @@ AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, int b, int
 
   const int nkt = (S + 63) / 64;
   Chunk8<T> kc[2], vc[2];
-  kv_load<T>(kc, vc, KV, a.ldkv, b, h, S, 0, tid);
+  RopeRegs rr;
+  kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, 0, tid, a.cos, a.sin);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
-    kv_store<T>(Ks, Vs, kc, vc, S, kt, tid, a.cos, a.sin);
+    kv_store<T>(Ks, Vs, kc, vc, rr, S, kt, tid);
     __syncthreads();
-    if (kt + 1 < nkt) kv_load<T>(kc, vc, KV, a.ldkv, b, h, S, kt + 1, tid);
+    if (kt + 1 < nkt) kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, kt + 1, tid, a.cos, a.sin);
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f}, dpacc = f32x4{0.f, 0.f, 0.f, 0.f};

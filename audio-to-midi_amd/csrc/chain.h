@@ -12,6 +12,7 @@
 // acc[rb][ti][i] = D[feature m0 + 16 rb + 4 g + i][token t0 + 16 ti + r],  r = lane & 15, g = lane >> 4.
 #pragma once
 #include "common.h"
+#include "rowops.h"
 
 namespace amt {
 
@@ -187,17 +188,11 @@ AMT_DEV void chain_ln_rows(const T* Xs, T* Ys, const float* __restrict__ w, cons
     const int p = pp * RPP + prow;
     float x[8];
     load8f(Xs + p * LD + sub * 8, x);
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += x[i];
-    const float mu = group_sum<LPR>(s) * (1.f / C);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { x[i] -= mu; q += x[i] * x[i]; }
-    const float rs = 1.f / sqrtf(group_sum<LPR>(q) * (1.f / C) + 1e-5f);
+    float mu, rs;
+    ln_stats<8, LPR>(x, mu, rs);
     float y[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = x[i] * rs * wv[i] + bv[i];
+    for (int i = 0; i < 8; ++i) y[i] = ln_apply(x[i], rs, wv[i], bv[i]);
     store8f(Ys + p * LD + sub * 8, y);
     if (sub == 0 && n0 + p < N) { mean[n0 + p] = mu; rstd[n0 + p] = rs; }
   }

@@ -139,17 +139,11 @@ __global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
         for (int i = 0; i < 8; ++i) d[i] += wk[k][i] * (x[k][i] * m);
       }
       store8f(Rs + p * LDX + sub * 8, x[3]);
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s += d[i];
-      const float mu = group_sum<LPR>(s) * (1.f / C);
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { d[i] -= mu; q += d[i] * d[i]; }
-      const float rs = 1.f / sqrtf(group_sum<LPR>(q) * (1.f / C) + kLnEps);
+      float mu, rs;
+      ln_stats<8, LPR>(d, mu, rs);
       float y[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) y[i] = d[i] * rs * wv[i] + lb[i];
+      for (int i = 0; i < 8; ++i) y[i] = ln_apply(d[i], rs, wv[i], lb[i]);
       store8f(Xs + p * LDX + sub * 8, y);
 #ifdef AMT_CHAIN_TIMING
       if (!(a.dbg_slot & 1024))

@@ -214,17 +214,11 @@ __global__ __launch_bounds__(256) void dwln_fwd_kernel(const T* __restrict__ X, 
     int b = (int)(row / L), l = (int)(row % L);
     float d[VEC];
     dwconv_row<T, VEC>(X, (long)b * L, l, L, C, sub, wk, bv, d);
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) s += d[i];
-    float mu = group_sum<LPR>(s) * (1.f / C);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) { d[i] -= mu; q += d[i] * d[i]; }
-    float rs = 1.f / sqrtf(group_sum<LPR>(q) * (1.f / C) + kLnEps);
+    float mu, rs;
+    ln_stats<VEC, LPR>(d, mu, rs);
     float y[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) y[i] = d[i] * rs * wv[i] + lb[i];
+    for (int i = 0; i < VEC; ++i) y[i] = ln_apply(d[i], rs, wv[i], lb[i]);
     storevf<VEC>(Y + row * C + sub * VEC, y);
     if (sub == 0) { mean[row] = mu; rstd[row] = rs; }
   }

@@ -739,6 +739,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       lnout_bwd_fused(s, dt, la, G(lp.ln2_w), G(lp.ln2_b), &sink, riders_a.data(), (int)riders_a.size());
       wgrad(dh, H, ls.ao, H, N, H, H, lp.wo, H, -1, 0);
     } else {
+      if (!riders_a.empty()) gemm_tn_wgrad_group(s, dt, riders_a.data(), (int)riders_a.size(), &sink);
       layernorm_bwd(s, dt, dhn2, ls.h, ls.m2, ls.r2, c->P(lp.ln2_w), dy, dh, G(lp.ln2_w), G(lp.ln2_b), N, H, &sink);
       // attention output projection
       wgrad(dh, H, ls.ao, H, N, H, H, lp.wo, H, -1, 0);
@@ -773,6 +774,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       wgrad(dkv, L.KVW, cptr, L.QC, N, L.KVW, ckv, lp.wkv, ckv, -1, 0);
       wgrad(dqc, L.QC, ls.xn, H, N, L.QC, H, lp.wqc, H, -1, 0);
     } else {
+      if (!riders_b.empty()) gemm_tn_wgrad_group(s, dt, riders_b.data(), (int)riders_b.size(), &sink);
       // k/v up-projection
       wgrad(dkv, L.KVW, cptr, L.QC, N, L.KVW, ckv, lp.wkv, ckv, -1, 0);
       {

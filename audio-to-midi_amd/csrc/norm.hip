@@ -21,18 +21,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, co
   for (long row = ((long)blockIdx.x * 4 + wave) * R::RPW + rw; row < N; row += (long)gridDim.x * R::RPB) {
     float x[VEC];
     loadvf<VEC>(X + row * C + sub * VEC, x);
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) s += x[i];
-    float mu = group_sum<LPR>(s) * (1.f / C);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) { x[i] -= mu; q += x[i] * x[i]; }
-    float var = group_sum<LPR>(q) * (1.f / C);
-    float rs = 1.f / sqrtf(var + kLnEps);
+    // explicit rounding sequence (rowops.h: ln_stats / ln_apply), shared with the chain kernels
+    float mu, rs;
+    ln_stats<VEC, LPR>(x, mu, rs);
     float y[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) y[i] = x[i] * rs * wv[i] + bv[i];
+    for (int i = 0; i < VEC; ++i) y[i] = ln_apply(x[i], rs, wv[i], bv[i]);
     storevf<VEC>(Y + row * C + sub * VEC, y);
     if (sub == 0 && mean != nullptr) { mean[row] = mu; rstd[row] = rs; }
   }

@@ -89,4 +89,23 @@ template <typename Sink> static inline int bwd_blocks(long N, int C, const Sink*
 
 constexpr float kLnEps = 1e-5f;   // eqx.nn.LayerNorm default eps
 
+// LayerNorm statistics of a row spread over LPR lanes (VEC features each) with an explicit rounding
+// sequence: the saved mean / rstd feed the backward pass in fp32, so the unfused kernels and the chain
+// kernels must produce the same bits (a compiler-chosen fma contraction differs between kernels).
+// On return x holds x - mean.
+template <int VEC, int LPR>
+AMT_DEV void ln_stats(float (&x)[VEC], float& mu, float& rs) {
+  constexpr int C = VEC * LPR;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s = __fadd_rn(s, x[i]);
+  mu = __fmul_rn(group_sum<LPR>(s), 1.f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { x[i] = __fsub_rn(x[i], mu); q = __fmaf_rn(x[i], x[i], q); }
+  rs = 1.f / sqrtf(__fadd_rn(__fmul_rn(group_sum<LPR>(q), 1.f / C), kLnEps));
+}
+// (x - mean) * rstd * w + b
+AMT_DEV float ln_apply(float d, float rs, float w, float b) { return __fmaf_rn(__fmul_rn(d, rs), w, b); }
+
 }  // namespace amt
