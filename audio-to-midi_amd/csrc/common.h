@@ -271,12 +271,15 @@ AMT_DEV uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
-AMT_DEV uint32_t rng_u32(uint64_t seed, uint32_t stream, uint32_t idx) {
+// (seed, stream) -> 32-bit key: wave-uniform, so it is computed once on the scalar unit; per element
+// one multiply + one mix32 (the three-round form cost 0.66 us per 64-key attention tile: 16 elements
+// per lane, profiles/r01_notes.md).
+AMT_DEV uint32_t rng_key(uint64_t seed, uint32_t stream) {
   uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
-  uint32_t h = mix32(idx ^ 0x9e3779b9U);
-  h = mix32(h ^ s0 ^ (stream * 0x85ebca6bU));
-  h = mix32(h + s1 + 0x165667b1U);
-  return h;
+  return mix32(mix32(s0 ^ (stream * 0x85ebca6bU)) + s1 + 0x165667b1U);
+}
+AMT_DEV uint32_t rng_u32(uint64_t seed, uint32_t stream, uint32_t idx) {
+  return mix32((idx * 0x9e3779b1U) ^ rng_key(seed, stream));
 }
 // keep with probability (1 - p): threshold on the top 24 bits
 AMT_DEV bool rng_keep(uint64_t seed, uint32_t stream, uint32_t idx, uint32_t drop_thresh24) {

@@ -141,9 +141,8 @@ int32_t amt_op_dropout(int32_t dtype, const void* X, void* Y, uint64_t n, uint64
 
 uint32_t amt_rng_u32(uint64_t seed, uint32_t stream_id, uint32_t idx) {
   uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
-  uint32_t h = h_mix32(idx ^ 0x9e3779b9U);
-  h = h_mix32(h ^ s0 ^ (stream_id * 0x85ebca6bU));
-  h = h_mix32(h + s1 + 0x165667b1U);
+  const uint32_t key = h_mix32(h_mix32(s0 ^ (stream_id * 0x85ebca6bU)) + s1 + 0x165667b1U);
+  uint32_t h = h_mix32((idx * 0x9e3779b1U) ^ key);
   return h;
 }
 uint32_t amt_drop_threshold24(float drop_p) { return thr24(drop_p); }

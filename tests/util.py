@@ -84,9 +84,8 @@ def rng_u32(seed, stream_id, idx):
     idx = np.asarray(idx, dtype=np.uint32)
     s0 = np.uint32(seed & 0xFFFFFFFF); s1 = np.uint32((seed >> 32) & 0xFFFFFFFF)
     with np.errstate(over="ignore"):
-        h = _mix32(idx ^ np.uint32(0x9e3779b9))
-        h = _mix32(h ^ s0 ^ np.uint32((stream_id * 0x85ebca6b) & 0xFFFFFFFF))
-        h = _mix32(h + s1 + np.uint32(0x165667b1))
+        key = _mix32(_mix32(np.asarray(s0 ^ np.uint32((stream_id * 0x85ebca6b) & 0xFFFFFFFF), dtype=np.uint32)) + s1 + np.uint32(0x165667b1))
+        h = _mix32((idx * np.uint32(0x9e3779b1)) ^ key)
     return h
 
 
