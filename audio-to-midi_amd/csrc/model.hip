@@ -271,6 +271,8 @@ struct amt_ctx {
   std::vector<PartDesc> part_descs;
   PartDesc* part_desc_dev = nullptr;
   int n_part_desc = 0;
+  int n_part_desc_half = 0;     // records registered by the first half of the backward pass (run_backward phases)
+  size_t fwd_end_off = 0;       // arena offset after the forward pass (start of the backward allocations)
   // side stream for weight-gradient launches (they only feed the gradient buffer, so they overlap
   // with the dependent data-gradient chain); events are created at plan time
   hipStream_t side = nullptr;
@@ -551,21 +553,27 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
 
 // ------------------------------------------------------------------------------------ backward
+// phase 0: the whole backward pass.  phase 1 / 2: its two halves for the overlapped data-parallel step —
+// 1 = loss, decoder, transformer and final CNN LayerNorm (their gradients = the flat range
+// [L.fn_w, n_params), complete and unscaled when the call returns), 2 = the CNN stages (range [0, L.fn_w)).
+// Both halves run the same host bookkeeping (buffer rotation, scratch regions, record offsets, riders)
+// and only launch inside their own half, so 1 followed by 2 issues exactly the launches of 0.
 int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labels, int B, int T, float scale,
-                 bool train, uint64_t seed, float* grads, int* grads_valid) {
+                 bool train, uint64_t seed, float* grads, int* grads_valid, int phase = 0) {
   const amt_config& cfg = c->cfg;
   const Layout& L = c->L;
   Arena& A = c->arena;
   const DType dt = c->dt;
   const size_t es = c->esz;
   const bool dry = A.dry;
-#define RUN(...) do { if (!dry) { __VA_ARGS__; } } while (0)
+  bool live = (phase != 2);            // launches enabled (first half active unless phase == 2)
+#define RUN(...) do { if (!dry && live) { __VA_ARGS__; } } while (0)
   const Drop dp = drop_params(c, train);
   const int S = T / 320, N = B * S, H = L.H;
   PartialSink sink;
   sink.ws = c->partials;
   sink.grads_base = grads;
-  sink.dry = dry;
+  sink.dry = dry || !live;             // launchers that take the sink account but do not launch when it is "dry"
   if (dry) { c->part_descs.clear(); sink.descs = &c->part_descs; }
 
   int dbg_bwd = 0;   // micro-benchmark builds only (AMT_CHAIN_TIMING)
@@ -652,6 +660,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   c->ev_used = 0;
   if (dry) c->ev_needed = 0;
 
+  RUN(hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, grads_valid, 1));
   // Kernels, not hipMemsetAsync: under hipGraph replay (ROCm 7.2, MI355X) the captured memset nodes of
   // this step did not take effect from the second replay on (gradients accumulated over replays;
   // scratch/graph_dbg2.py), kernel nodes keep their stream order.
@@ -804,6 +813,15 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     dcur = dx;
     end_scope();
   }
+  // ---- boundary between the two halves: every gradient of [L.fn_w, n_params) is complete here
+  if (dry) c->n_part_desc_half = (int)c->part_descs.size();
+  if (phase == 1) {
+    flush_deferred();   // (empty: the final-LayerNorm scope queues no weight gradient)
+    RUN(reduce_partials(s, c->part_desc_dev, c->n_part_desc_half, c->partials, grads));
+    RUN(grads_finalize(s, grads + L.fn_w, L.n_params - L.fn_w, 1.f / scale, grads_valid));
+    return 0;
+  }
+  if (phase == 2) { live = true; sink.dry = dry; }
   // CNN stages, last to first
   int Lcur = S;
   for (int si = cfg.n_stages - 1; si >= 0; --si) {
@@ -878,8 +896,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     }
   }
   flush_deferred();
-  // train.py:319-322: grads / grad_scale, all-finite flag
-  RUN(hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, grads_valid, 1));
+  // train.py:319-322: grads / grad_scale, all-finite flag (the flag was set to 1 when the pass began)
   // join: the main stream waits for the side work of the last two scopes (older ones were waited for
   // when their regions were reused)
   if (side_on) {
@@ -888,8 +905,13 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   }
   if (dry && scratch_used > c->scratch_max) c->scratch_max = scratch_used;
   c->part_total = sink.off;
-  RUN(reduce_partials(s, c->part_desc_dev, c->n_part_desc, c->partials, grads));
-  RUN(grads_finalize(s, grads, L.n_params, 1.f / scale, grads_valid));
+  if (phase == 2) {
+    RUN(reduce_partials(s, c->part_desc_dev + c->n_part_desc_half, c->n_part_desc - c->n_part_desc_half, c->partials, grads));
+    RUN(grads_finalize(s, grads, L.fn_w, 1.f / scale, grads_valid));
+  } else {
+    RUN(reduce_partials(s, c->part_desc_dev, c->n_part_desc, c->partials, grads));
+    RUN(grads_finalize(s, grads, L.n_params, 1.f / scale, grads_valid));
+  }
 #undef RUN
   return 0;
 }
@@ -1137,6 +1159,34 @@ int32_t amt_forward_backward(amt_ctx* c, const void* audio, const float* labels,
   if (e != hipSuccess) { c->err = std::string("amt_forward_backward: ") + hipGetErrorString(e); return 1; }
   return 0;
 }
+
+int32_t amt_forward_backward_phase(amt_ctx* c, const void* audio, const float* labels, int32_t B, int32_t T, float scale,
+                                   uint64_t seed, int32_t train, float* loss_out, float* grads_flat, int32_t* grads_valid,
+                                   float* logits, int32_t phase, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (phase != 1 && phase != 2) { c->err = "phase must be 1 or 2"; return 1; }
+  if (check_shape(c, B, T)) return 1;
+  if (!(scale > 0.f)) { c->err = "scale must be positive"; return 1; }
+  if (phase == 1) {
+    if (ensure_rope(c, T / 320)) return 1;
+    if (plan(c, B, T, 1, s)) return 1;
+    c->arena.off = 0;
+    if (run_forward(c, s, audio, B, T, true, train != 0, seed)) return 1;
+    c->fwd_end_off = c->arena.off;
+    if (logits) head_probs(s, c->logits_pad, c->L.VP, logits, nullptr, B * (T / 320), c->cfg.n_events);
+  } else {
+    if (c->plan_B != B || c->plan_T != T || c->plan_train != 1) { c->err = "phase 2 without a matching phase 1"; return 1; }
+    c->arena.off = c->fwd_end_off;
+  }
+  if (run_backward(c, s, audio, labels, B, T, scale, train != 0, seed, grads_flat, grads_valid, phase)) return 1;
+  if (c->arena.overflow) { c->err = "internal error: workspace plan too small"; return 1; }
+  if (phase == 1) copy_f32(s, c->loss_acc, loss_out, 2);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { c->err = std::string("amt_forward_backward_phase: ") + hipGetErrorString(e); return 1; }
+  return 0;
+}
+
+uint64_t amt_grad_bucket_split(const amt_ctx* c) { return c->L.fn_w; }
 
 uint64_t amt_workspace_bytes(const amt_ctx* c) { return c->arena.cap; }
 

@@ -90,6 +90,8 @@ SIGNATURES = {
     "amt_num_frames": (_i32, [C.POINTER(AmtConfig), _i32]),
     "amt_forward": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "amt_forward_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _u64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "amt_forward_backward_phase": (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _u64, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "amt_grad_bucket_split": (_u64, [_vp]),
     "amt_workspace_bytes": (_u64, [_vp]),
     "amt_adamw_step": (_i32, [_vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "amt_optimizer_init": (_i32, [_vp, _f32]),

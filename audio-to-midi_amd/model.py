@@ -211,6 +211,21 @@ class OutputSequenceGenerator:
         lv = loss.cpu().numpy()
         return StepOutput(float(lv[0]), float(lv[1]), grads, bool(int(valid.item())), logits)
 
+    # ------------------------------------------------------------------ the same step in two halves (DP overlap)
+    def grad_bucket_split(self) -> int:
+        """First flat index of the gradients completed by ``loss_and_grads_phase(1)`` (decoder, transformer,
+        final CNN norm); ``[0, split)`` (the CNN stages) is completed by phase 2."""
+        return int(self._L.amt_grad_bucket_split(self._h))
+
+    def loss_and_grads_phase(self, phase: int, audio, labels, grads_out: torch.Tensor, loss_out: torch.Tensor,
+                             valid_out: torch.Tensor, scale: float = 1.0, seed: int = 0, train: bool = True):
+        """Asynchronous half of ``loss_and_grads`` (include/amt.h: amt_forward_backward_phase).  All tensors are
+        caller-owned device tensors (audio in the activation dtype, labels fp32); nothing is synchronised."""
+        self._check(self._L.amt_forward_backward_phase(self._h, _lib.ptr(audio), _lib.ptr(labels), audio.shape[0],
+                                                       audio.shape[2], float(scale), int(seed), 1 if train else 0,
+                                                       _lib.ptr(loss_out), _lib.ptr(grads_out), _lib.ptr(valid_out), None,
+                                                       int(phase), self._stream()), "amt_forward_backward_phase")
+
     def init_optimizer(self, layer_lr_decay=0.7):
         """Allocate AdamW state (train.py:845 setup_optimizers).  Call before hipGraph capture."""
         self._check(self._L.amt_optimizer_init(self._h, float(layer_lr_decay)), "amt_optimizer_init")

@@ -191,6 +191,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: one all-reduce after the whole backward pass instead of the two-bucket overlap")
+    ap.add_argument("--force-overlap", action="store_true", help="use the two-phase step even at N = 1 (testing)")
     ap.add_argument("--workload", choices=["train", "infer"], default="train",
                     help="train = BASELINE configs[1] (default, the headline metric); infer = configs[3]: streaming "
                          "inference, 32 x 60 s clips -> 448 windows of 5 s, forward + stitch (reported, not the headline)")
@@ -232,31 +235,75 @@ def main():
         grads[model.n_params + 1] = valid[0].to(torch.float32)
         loss_buf.copy_(loss)
 
+    # N > 1: the step runs in two halves (include/amt.h: amt_forward_backward_phase).  The gradients of the
+    # decoder + transformer + final CNN norm (37 of the 46 MB) are complete after the first half and their
+    # all-reduce runs on a side stream while the CNN stages are still in their backward pass; the CNN
+    # bucket and the two scalars (loss, finite flag) follow.  Per-GPU work is identical to the one-call step.
+    overlap = (world > 1 and not args.no_overlap) or args.force_overlap
+    if overlap and dist is None:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    split = model.grad_bucket_split() if overlap else 0
+    valid_buf = torch.ones(1, dtype=torch.int32, device=dev)
+    tail = grads[model.n_params:]
+
+    def half(phase, seed):
+        model.loss_and_grads_phase(phase, audio, labels, gflat, loss_buf, valid_buf, scale=1.0, seed=seed, train=True)
+
     # every allocation happens before graph capture: optimizer state, then the workspace plan
     if not args.no_optimizer:
         model.init_optimizer()
     fwd_bwd(0)
     torch.cuda.synchronize()
-    graph = None
+    graph = graph_a = graph_b = None
+    side = torch.cuda.Stream(device=dev)
     if not args.no_graph:
-        side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             fwd_bwd(0)
+            if overlap:
+                half(1, 0); half(2, 0)
         torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            fwd_bwd(12345)
+        if overlap:
+            graph_a, graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_a):
+                half(1, 12345)
+            with torch.cuda.graph(graph_b, pool=graph_a.pool()):
+                half(2, 12345)
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                fwd_bwd(12345)
+    comm = torch.cuda.Stream(device=dev)
 
     def one_step():
         step_no[0] += 1
-        if graph is not None:
-            graph.replay()
+        if overlap:
+            main = torch.cuda.current_stream()
+            if graph_a is not None: graph_a.replay()
+            else: half(1, step_no[0])
+            comm.wait_stream(main)
+            with torch.cuda.stream(comm):
+                dist.all_reduce(grads[split:model.n_params], op=dist.ReduceOp.SUM)       # transformer + decoder bucket
+            if graph_b is not None: graph_b.replay()
+            else: half(2, step_no[0])
+            tail[0] = loss_buf[0]
+            tail[1] = valid_buf[0].to(torch.float32)
+            dist.all_reduce(grads[:split], op=dist.ReduceOp.SUM)                           # CNN bucket
+            dist.all_reduce(tail, op=dist.ReduceOp.SUM)                                    # loss, finite flag
+            main.wait_stream(comm)
+            if world > 1:
+                grads.mul_(1.0 / world)
         else:
-            fwd_bwd(step_no[0])
-        if world > 1:
-            dist.all_reduce(grads, op=dist.ReduceOp.SUM)        # ONE bucket: grads + loss + finite flag
-            grads.mul_(1.0 / world)                              # mean over the global batch (train.py:62)
+            if graph is not None:
+                graph.replay()
+            else:
+                fwd_bwd(step_no[0])
+            if world > 1:
+                dist.all_reduce(grads, op=dist.ReduceOp.SUM)        # ONE bucket: grads + loss + finite flag
+                grads.mul_(1.0 / world)                              # mean over the global batch (train.py:62)
         if not args.no_optimizer:
             model.adamw_step(gflat, lr_base=1e-4, step=step_no[0])
 
@@ -341,7 +388,8 @@ def main():
                                    "GPU, train mode (dropout 0.1)" + (", RCCL all-reduce of the fp32 grad bucket" if world > 1 else "")
                                    + ("" if args.no_optimizer else ", AdamW + global-norm clip + bf16 weight refresh"),
                        "global_batch": world * B_PER_GPU, "clip_seconds": CLIP_SECONDS, "frames": T_SAMPLES // 320,
-                       "parallelism": f"dp{world}", "hipgraph": graph is not None,
+                       "parallelism": f"dp{world}", "hipgraph": (graph is not None) or (graph_a is not None),
+                       "grad_allreduce": ("two buckets, first overlapped with the CNN backward" if overlap else "one bucket") if world > 1 or overlap else None,
                        "weights": "random init (Equinox distributions), 11606230 params"},
             "model_tflops": round(world * FLOPS_PER_STEP / (elapsed / args.steps) / 1e12, 2),
             "loss": round(loss_val, 3),
@@ -351,7 +399,7 @@ def main():
             "breakdown": breakdown[:12],
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None and dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -107,6 +107,18 @@ int32_t amt_forward_backward(amt_ctx* ctx, const void* audio, const float* label
                              float scale, uint64_t seed, int32_t train, float* loss_out, float* grads_flat,
                              int32_t* grads_valid, float* logits, void* stream);
 
+/* The same step in two calls, for a data-parallel host that overlaps the gradient all-reduce with the
+ * backward pass (the reference leaves that to XLA's GSPMD scheduler, train.py:238-244, 280):
+ *   phase 1 = forward, loss, backward of decoder + transformer + final CNN LayerNorm: on return (in
+ *             stream order) grads_flat[amt_grad_bucket_split(ctx) ..) is complete, unscaled and checked;
+ *   phase 2 = backward of the CNN stages: completes grads_flat[0 .. split).
+ * Same arguments in both calls; loss_out / logits are written by phase 1, grads_valid is AND-ed by both.
+ * Phase 1 followed by phase 2 issues exactly the launches of amt_forward_backward. */
+int32_t amt_forward_backward_phase(amt_ctx* ctx, const void* audio, const float* labels, int32_t B, int32_t T,
+                                   float scale, uint64_t seed, int32_t train, float* loss_out, float* grads_flat,
+                                   int32_t* grads_valid, float* logits, int32_t phase, void* stream);
+uint64_t amt_grad_bucket_split(const amt_ctx* ctx);
+
 /* Bytes of activation workspace currently held (diagnostics). */
 uint64_t amt_workspace_bytes(const amt_ctx* ctx);
 
