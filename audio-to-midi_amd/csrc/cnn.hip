@@ -157,7 +157,7 @@ void stem_fwd(hipStream_t s, DType dt, const void* audio, const float* w, const 
 void stem_bwd(hipStream_t s, DType dt, const void* audio, const void* dY, const float* w, const float* b,
               const float* lnw, float* dw, float* db, float* dlnw, float* dlnb, int B, int T_) {
   int L = T_ / 5, tiles = (L + STEM_POS - 1) / STEM_POS, total = B * tiles;
-  int grid = total < 512 ? total : 512;
+  int grid = total < 128 ? total : 128;   // 52 same-address atomics per block: few blocks, several tiles each
   ProfScope ps(s, "stem_bwd", 4.0 * B * L * 40, ((double)B * 2 * T_ + (double)B * L * 4) * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32)
     hipLaunchKernelGGL((stem_bwd_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)audio, (const float*)dY, w,

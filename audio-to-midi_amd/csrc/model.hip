@@ -61,10 +61,15 @@ struct Layout {
   size_t n_params = 0;
   size_t n_compute = 0;                    // elements of the compute-copy buffer
   std::vector<ConvDesc> conv;
+  std::vector<int> conv_need;              // per desc: which execution mode reads the copy (ConvNeed)
   int H = 0, QC = 0, KVW = 0, I2 = 0, VP = 0;   // hidden, q+c width, k+v width, 2*inter, padded events
 };
 
 size_t align8(size_t x) { return (x + 7) & ~(size_t)7; }
+
+// who reads a compute copy: amt_create drops the conversions nobody reads in the selected mode
+// (convert_batch runs after every optimizer step: 69 -> ~35 us with the default chains)
+enum ConvNeed { NEED_ALWAYS = 0, NEED_UNFUSED_BLOCK, NEED_FUSED_BLOCK, NEED_UNFUSED_TR, NEED_FUSED_TR, NEED_FFN_CHAIN };
 
 bool validate(const amt_config& c, std::string& err) {
   if (c.n_stages < 1 || c.n_stages > AMT_MAX_STAGES) { err = "n_stages out of range"; return false; }
@@ -95,15 +100,17 @@ Layout build_layout(const amt_config& c) {
     return o;
   };
   auto cbuf = [&](size_t n) { size_t o = coff; coff += align8(n); return o; };
+  int need_cur = NEED_ALWAYS;   // tag of the descriptors pushed next
+  auto push = [&](const ConvDesc& d) { L.conv.push_back(d); L.conv_need.push_back(need_cur); };
   auto cpair = [&](size_t src, int rows, int cols, size_t& cw, size_t& cwt) {
     cw = cbuf((size_t)rows * cols);
     cwt = cbuf((size_t)rows * cols);
-    L.conv.push_back(ConvDesc{src, cw, rows, cols, rows, 0, -1, 0});
-    L.conv.push_back(ConvDesc{src, cwt, cols, rows, rows, 1, -1, 0});
+    push(ConvDesc{src, cw, rows, cols, rows, 0, -1, 0});
+    push(ConvDesc{src, cwt, cols, rows, rows, 1, -1, 0});
   };
   auto cpacked = [&](size_t src, int rows, int cols) {
     size_t o = cbuf(chain_packed_elems(rows, cols));
-    L.conv.push_back(ConvDesc{src, o, rows, cols, rows, 0, -1, 1});
+    push(ConvDesc{src, o, rows, cols, rows, 0, -1, 1});
     return o;
   };
   int depth_base = 0;
@@ -141,19 +148,22 @@ Layout build_layout(const amt_config& c) {
       b.pw2_w = seg(q + "point_conv_2.weight", C, 2 * C, d);
       b.pw2_b = seg(q + "point_conv_2.bias", C, 1, d);
       b.gamma = seg(q + "gamma", C, 1, d);
+      need_cur = C >= 16 ? NEED_UNFUSED_BLOCK : NEED_ALWAYS;   // C <= 8: the per-position kernels read these
       cpair(b.pw1_w, 2 * C, C, b.c_pw1, b.c_pw1t);
       cpair(b.pw2_w, C, 2 * C, b.c_pw2, b.c_pw2t);
       b.c_pw2tg = cbuf((size_t)2 * C * C);
-      L.conv.push_back(ConvDesc{b.pw2_w, b.c_pw2tg, 2 * C, C, C, 1, (long long)b.gamma, 0});
+      push(ConvDesc{b.pw2_w, b.c_pw2tg, 2 * C, C, C, 1, (long long)b.gamma, 0});
+      need_cur = NEED_FUSED_BLOCK;
       b.c_pw1p = b.c_pw2p = b.c_pw2tgp = b.c_pw1tp = 0;
       if (C >= 16) {
         b.c_pw1p = cpacked(b.pw1_w, 2 * C, C);
         b.c_pw2p = cpacked(b.pw2_w, C, 2 * C);
         b.c_pw2tgp = cbuf(chain_packed_elems(2 * C, C));
-        L.conv.push_back(ConvDesc{b.pw2_w, b.c_pw2tgp, 2 * C, C, C, 1, (long long)b.gamma, 1});
+        push(ConvDesc{b.pw2_w, b.c_pw2tgp, 2 * C, C, C, 1, (long long)b.gamma, 1});
         b.c_pw1tp = cbuf(chain_packed_elems(C, 2 * C));
-        L.conv.push_back(ConvDesc{b.pw1_w, b.c_pw1tp, C, 2 * C, 2 * C, 1, -1, 1});
+        push(ConvDesc{b.pw1_w, b.c_pw1tp, C, 2 * C, 2 * C, 1, -1, 1});
       }
+      need_cur = NEED_ALWAYS;
       st.blocks.push_back(b);
     }
     depth_base += st.depth;
@@ -182,24 +192,29 @@ Layout build_layout(const amt_config& c) {
     l.b1 = seg(t + "b1", L.I2, 1, -1);
     l.w2 = seg(t + "w2", H, c.ffn_inter, -1);
     l.b2 = seg(t + "b2", H, 1, -1);
+    need_cur = NEED_UNFUSED_TR;
     cpair(l.wqc, L.QC, H, l.c_wqc, l.c_wqct);
     cpair(l.wkv, L.KVW, c.kv_compress, l.c_wkv, l.c_wkvt);
     cpair(l.wo, H, HD, l.c_wo, l.c_wot);
+    need_cur = NEED_ALWAYS;
     cpair(l.w1, L.I2, H, l.c_w1, l.c_w1t);
     cpair(l.w2, H, c.ffn_inter, l.c_w2, l.c_w2t);
+    need_cur = NEED_FUSED_TR;
     l.c_wop = cpacked(l.wo, H, HD);
     l.c_wqcp = cpacked(l.wqc, L.QC, H);
     l.c_wkvp = cpacked(l.wkv, L.KVW, c.kv_compress);
     auto cpacked_t = [&](size_t src, int rows, int cols) {   // packed copy of src^T: dst [rows][cols], src [cols][rows]
       size_t o = cbuf(chain_packed_elems(rows, cols));
-      L.conv.push_back(ConvDesc{src, o, rows, cols, cols, 1, -1, 1});
+      push(ConvDesc{src, o, rows, cols, cols, 1, -1, 1});
       return o;
     };
     l.c_wotp = cpacked_t(l.wo, HD, H);
     l.c_wqctp = cpacked_t(l.wqc, H, L.QC);
     l.c_wkvtp = cpacked_t(l.wkv, c.kv_compress, L.KVW);
+    need_cur = NEED_FFN_CHAIN;
     l.c_w1p = cpacked(l.w1, L.I2, H);
     l.c_w2p = cpacked(l.w2, H, c.ffn_inter);
+    need_cur = NEED_ALWAYS;
     L.layers.push_back(l);
   }
   L.hd_lnw = seg("decoder.norm.weight", H, 1, -1);
@@ -209,8 +224,9 @@ Layout build_layout(const amt_config& c) {
   // head: padded to VP rows so that every GEMM has M % 4 == 0 and K % 8 == 0
   L.c_hw = cbuf((size_t)L.VP * H);
   L.c_hwt = cbuf((size_t)L.VP * H);
-  L.conv.push_back(ConvDesc{L.hd_w, L.c_hw, L.VP, H, c.n_events, 0, -1, 0});
-  L.conv.push_back(ConvDesc{L.hd_w, L.c_hwt, H, L.VP, c.n_events, 1, -1, 0});
+  need_cur = NEED_ALWAYS;
+  push(ConvDesc{L.hd_w, L.c_hw, L.VP, H, c.n_events, 0, -1, 0});
+  push(ConvDesc{L.hd_w, L.c_hwt, H, L.VP, c.n_events, 1, -1, 0});
   L.n_params = off;
   L.n_compute = coff;
   return L;
@@ -1072,6 +1088,19 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   c->fuse = !(getenv("AMT_FUSE") && atoi(getenv("AMT_FUSE")) == 0);
   c->nochain = getenv("AMT_NOCHAIN") ? atoi(getenv("AMT_NOCHAIN")) : 0;
   c->fuse_ffn = getenv("AMT_FUSE_FFN") && atoi(getenv("AMT_FUSE_FFN")) != 0;
+  if (c->nochain == 0) {   // keep only the conversions the selected execution mode reads (debug mask: keep all)
+    const bool chain_tr = c->fuse && cfg->dims[cfg->n_stages - 1] == 256 && cfg->ffn_inter == 512 &&
+                          cfg->n_heads * cfg->head_dim == 256 && cfg->kv_compress == 64;
+    std::vector<ConvDesc> kept;
+    for (size_t i = 0; i < c->L.conv.size(); ++i) {
+      const int need = c->L.conv_need[i];
+      const bool use = need == NEED_ALWAYS || (need == NEED_UNFUSED_BLOCK && !c->fuse) || (need == NEED_FUSED_BLOCK && c->fuse) ||
+                       (need == NEED_UNFUSED_TR && !chain_tr) || (need == NEED_FUSED_TR && chain_tr) ||
+                       (need == NEED_FFN_CHAIN && chain_tr && c->fuse_ffn);
+      if (use) kept.push_back(c->L.conv[i]);
+    }
+    c->L.conv.swap(kept);
+  }
   const Layout& L = c->L;
   auto fail = [&](const char* what, hipError_t err) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(err);
