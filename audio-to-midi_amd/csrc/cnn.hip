@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const T* __restrict__ aud
                                                        const float* __restrict__ lnw, float* __restrict__ dw,
                                                        float* __restrict__ db, float* __restrict__ dlnw,
                                                        float* __restrict__ dlnb, int B, int T_, int L,
-                                                       int tiles_per_clip, int total_tiles) {
+                                                       int tiles_per_clip, int total_tiles, float* __restrict__ rec) {
   __shared__ float xs[2][STEM_SAMP];
   __shared__ float red[52];
   float acc[52];   // 40 dw, 4 db, 4 dlnw, 4 dlnb
@@ -136,6 +136,10 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const T* __restrict__ aud
     if ((threadIdx.x & 63) == 0) atomicAdd(&red[i], v);
   }
   __syncthreads();
+  if (rec != nullptr) {   // one record [dw 40 | db 4 | dlnw 4 | dlnb 4] per block, summed by reduce_partials
+    if (threadIdx.x < 52) rec[(size_t)blockIdx.x * 52 + threadIdx.x] = red[threadIdx.x];
+    return;
+  }
   if (threadIdx.x < 40) atomicAdd(&dw[threadIdx.x], red[threadIdx.x]);
   else if (threadIdx.x < 44) atomicAdd(&db[threadIdx.x - 40], red[threadIdx.x]);
   else if (threadIdx.x < 48) atomicAdd(&dlnw[threadIdx.x - 44], red[threadIdx.x]);
@@ -155,16 +159,28 @@ void stem_fwd(hipStream_t s, DType dt, const void* audio, const float* w, const 
 }
 
 void stem_bwd(hipStream_t s, DType dt, const void* audio, const void* dY, const float* w, const float* b,
-              const float* lnw, float* dw, float* db, float* dlnw, float* dlnb, int B, int T_) {
+              const float* lnw, float* dw, float* db, float* dlnw, float* dlnb, int B, int T_, PartialSink* sink) {
   int L = T_ / 5, tiles = (L + STEM_POS - 1) / STEM_POS, total = B * tiles;
-  int grid = total < 128 ? total : 128;   // 52 same-address atomics per block: few blocks, several tiles each
+  // with per-block records: one 256-position tile per block (the blocks' memory round trips overlap);
+  // with atomics: 52 same-address adds per block, so few blocks with several tiles each
+  int grid = sink ? (total < 2048 ? total : 2048) : (total < 128 ? total : 128);
+  float* rec = nullptr;
+  if (sink) {
+    size_t o = sink->take((size_t)grid * 52);
+    sink->add(o, grid, 52, 40, dw);
+    sink->add(o + 40, grid, 52, 4, db);
+    sink->add(o + 44, grid, 52, 4, dlnw);
+    sink->add(o + 48, grid, 52, 4, dlnb);
+    if (sink->dry) return;
+    rec = sink->ws + o;
+  }
   ProfScope ps(s, "stem_bwd", 4.0 * B * L * 40, ((double)B * 2 * T_ + (double)B * L * 4) * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32)
     hipLaunchKernelGGL((stem_bwd_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)audio, (const float*)dY, w,
-                       b, lnw, dw, db, dlnw, dlnb, B, T_, L, tiles, total);
+                       b, lnw, dw, db, dlnw, dlnb, B, T_, L, tiles, total, rec);
   else
     hipLaunchKernelGGL((stem_bwd_kernel<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)audio, (const bf16*)dY, w, b,
-                       lnw, dw, db, dlnw, dlnb, B, T_, L, tiles, total);
+                       lnw, dw, db, dlnw, dlnb, B, T_, L, tiles, total, rec);
 }
 
 // ------------------------------------------------------------------ depthwise conv k7 (+ LayerNorm)

@@ -34,16 +34,19 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ lp, 
                                                   float inv_b) {
   __shared__ float red[4];
   float acc = 0.f;
-  const long total = N * ldd;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    long n = i / ldd;
-    int v = (int)(i % ldd);
+  const unsigned total = (unsigned)(N * ldd);          // < 2^31 (checked by the launcher): 32-bit index math
+#pragma unroll 4
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned n = i / (unsigned)ldd;
+    const int v = (int)(i - n * (unsigned)ldd);
     float d = 0.f;
     if (v < V) {
-      float z = lp[n * ldl + v], y = labels[n * V + v];
+      float z = lp[(size_t)n * ldl + v], y = labels[(size_t)n * V + v];
       // -y log_sigmoid(z) - (1-y) log_sigmoid(-z) = max(z,0) - z y + log1p(exp(-|z|))
-      acc += fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)));
-      d = (1.f / (1.f + expf(-z)) - y) * scale * inv_b;
+      const float t = __expf(-fabsf(z));                 // in (0, 1]
+      acc += fmaxf(z, 0.f) - z * y + log1pf(t);
+      const float sg = z >= 0.f ? 1.f / (1.f + t) : t / (1.f + t);   // sigmoid(z) from the same exponential
+      d = (sg - y) * scale * inv_b;
     }
     dl[i] = from_f<T>(d);
   }
@@ -60,9 +63,10 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ lp, 
 void bce_loss(hipStream_t s, DType dt, const float* logits_pad, int ldl, const float* labels, float* loss_acc,
               void* dlogits, int ldd, int N, int V, float scale, int B) {
   long total = (long)N * ldd;
-  // <= 96 blocks: every block ends with two atomics on the SAME two addresses (1024 contending adders cost
-  // most of the former 29 us)
-  int grid = (int)((total + 4095) / 4096 < 96 ? (total + 4095) / 4096 : 96);
+  if (total >= (1L << 31)) return;   // (N x 96 logits: 2^31 would be 22 million frames per call)
+  // <= 256 blocks, loads of 4 iterations in flight: every block ends with two atomics on the SAME two
+  // addresses (1024 contending adders cost a third of the former 29 us, the serial load loop the rest)
+  int grid = (int)((total + 1023) / 1024 < 256 ? (total + 1023) / 1024 : 256);
   if (grid < 1) grid = 1;
   ProfScope ps(s, "bce_loss", 0, (double)N * V * 8 + (double)N * ldd * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32)

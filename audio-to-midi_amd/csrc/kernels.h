@@ -94,7 +94,7 @@ void layernorm_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const
 void stem_fwd(hipStream_t s, DType dt, const void* audio, const float* w /*[4][2][5]*/, const float* b,
               const float* lnw, const float* lnb, void* Y, int B, int T);
 void stem_bwd(hipStream_t s, DType dt, const void* audio, const void* dY, const float* w, const float* b,
-              const float* lnw, float* dw, float* db, float* dlnw, float* dlnb, int B, int T);
+              const float* lnw, float* dw, float* db, float* dlnw, float* dlnb, int B, int T, PartialSink* sink = nullptr);
 // Y = LN(dwconv7(X) + bdw) ; X,Y [B][L][C]; saves mean/rstd [B*L]
 void dwln_fwd(hipStream_t s, DType dt, const void* X, const float* wdw /*[7][C]*/, const float* bdw,
               const float* lnw, const float* lnb, void* Y, float* mean, float* rstd, int B, int L, int C);

@@ -907,8 +907,8 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       Lcur = Lin;
       end_scope();
     } else {
-      RUN(stem_bwd(s, dt, audio, dcur, c->P(st.conv_w), c->P(st.conv_b), c->P(st.ln_w), G(st.conv_w), G(st.conv_b),
-                   G(st.ln_w), G(st.ln_b), B, T));
+      stem_bwd(s, dt, audio, dcur, c->P(st.conv_w), c->P(st.conv_b), c->P(st.ln_w), G(st.conv_w), G(st.conv_b),
+               G(st.ln_w), G(st.ln_b), B, T, &sink);
     }
   }
   flush_deferred();
