@@ -292,3 +292,23 @@ def test_two_phase_step_equals_one_call(small_conf):
     assert int(valid.item()) == 1
     with pytest.raises(RuntimeError):
         model.loss_and_grads_phase(3, a, y, g, loss, valid)
+
+
+def test_streaming_inference_windows_are_independent():
+    """cfg4 shape (448 windows x 5 s in one call): every window's logits equal the logits of the same window
+    predicted in a small batch (the reference vmaps the model over windows, infer.py:40), and the stitched
+    track of a clip has n * 250 - 25 * (n - 1) frames (common.rs:20-22)."""
+    from audio_to_midi_amd import infer
+    model = amt.OutputSequenceGenerator(np_model.MODEL_CONFIG, key=1234, dtype="bfloat16", gamma=1.0)
+    rng = np.random.default_rng(3)
+    full = rng.standard_normal((2, 60 * 16000)).astype(np.float32)
+    windows, dur = infer.slice_full_audio(infer.normalize_audio(full), 0.5)
+    assert windows.shape == (14, 2, 80000)
+    batch = torch.from_numpy(np.tile(windows, (32, 1, 1)))
+    logits, probs = model.predict(None, batch)
+    assert logits.shape == (448, 250, 90)
+    small, _ = model.predict(None, batch[[0, 13, 447]])
+    assert torch.equal(logits[[0, 13, 447]], small)
+    assert torch.equal(logits[:14], logits[14:28])                 # identical clips -> identical windows
+    stitched = infer.stitch_output_probs(probs[:14].cpu().numpy(), dur / 250, 0.5)
+    assert stitched.shape == (14 * 250 - 25 * 13, 90)
