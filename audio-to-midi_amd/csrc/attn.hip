@@ -240,6 +240,192 @@ __global__ __launch_bounds__(256) void attn_global_fwd_kernel(AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ global forward, fp8 (e4m3) QK^T and PV
+// BASELINE configs[4] ("fp8 MFMA attention + bf16 everything else").  q (rotated, / sqrt(64)), k (rotated) and
+// v are scaled per tensor and converted to OCP e4m3 while they are staged; S = QK^T and O = PV run on
+// v_mfma_f32_16x16x32_fp8_fp8 with fp32 accumulation; the softmax stays fp32; P is scaled by 384 (dropout
+// can raise a probability to 1.11) before its conversion.  Delayed scaling: the scales come from the
+// per-tensor |max| observed in the PREVIOUS call of this layer (amax_prev; 0 -> a default of 16), this call
+// records its own into amax_cur (atomic max).  V is written to LDS transposed so that both PV operands
+// are plain 8-byte row reads.  The backward pass is the bf16 one (it recomputes S from the saved bf16
+// q / k and the log-sum-exp of this kernel).
+constexpr int F8LD = 72;                     // bytes per LDS row of the 64-wide fp8 tiles
+constexpr float F8_MAX = 448.f, F8_P_SCALE = 384.f;
+
+AMT_DEV long pack_fp8x8(const float (&x)[8], float scale) {
+  int lo = __builtin_amdgcn_cvt_pk_fp8_f32(x[0] * scale, x[1] * scale, 0, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(x[2] * scale, x[3] * scale, lo, true);
+  int hi = __builtin_amdgcn_cvt_pk_fp8_f32(x[4] * scale, x[5] * scale, 0, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(x[6] * scale, x[7] * scale, hi, true);
+  return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
+}
+AMT_DEV float fp8_scale_from_amax(float amax) { return (F8_MAX * 0.9f) / (amax > 0.f ? amax : 16.f); }
+
+__global__ __launch_bounds__(256) void attn_global_fwd_fp8_kernel(AttnArgs a, const float* __restrict__ amax_prev,
+                                                                  float* __restrict__ amax_cur) {
+  typedef bf16 T;
+  __shared__ __attribute__((aligned(16))) unsigned char Ks8[64 * F8LD];   // [key][d]
+  __shared__ __attribute__((aligned(16))) unsigned char Vt8[64 * F8LD];   // [d][key]
+  __shared__ __attribute__((aligned(16))) unsigned char Ps8[4 * 16 * F8LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int S = a.S, ntile = (S + 63) / 64;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int bh = (jj / ntile) * 8 + xcd, qtile = jj % ntile;
+  if (bh >= a.B * a.H) return;
+  const int h = bh % a.H, b = bh / a.H;
+  const int qrow = qtile * 64 + wave * 16 + r;
+  const T* QC = reinterpret_cast<const T*>(a.QC);
+  const T* KV = reinterpret_cast<const T*>(a.KV);
+  unsigned char* Pw = Ps8 + wave * 16 * F8LD;
+  const float sq = fp8_scale_from_amax(amax_prev[0]), sk = fp8_scale_from_amax(amax_prev[1]),
+              sv = fp8_scale_from_amax(amax_prev[2]);
+  const float s_deq = 1.f / (sq * sk), o_deq = 1.f / (F8_P_SCALE * sv);
+  float mq = 0.f, mk = 0.f, mv = 0.f;
+
+  long qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = 0.f;
+    if (qrow < S) {
+      load8f(QC + (size_t)(b * S + qrow) * a.ldqc + h * 64 + 32 * ks + 8 * g, x);
+      rope8(x, a.cos, a.sin, qrow, 16 * ks + 4 * g, 1.f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { x[i] = to_f(from_f<T>(x[i])) * 0.125f; mq = fmaxf(mq, fabsf(x[i])); }
+    }
+    qf[ks] = pack_fp8x8(x, sq);
+  }
+
+  float m_run = -1e30f, l_run = 0.f;
+  f32x4 oacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (S + 63) / 64;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    // stage K (rotated) and V^T of this key tile as fp8
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int id = tid + 256 * it, row = id >> 3, c = id & 7;
+      const int key = kt * 64 + row;
+      float kx[8], vx[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { kx[i] = 0.f; vx[i] = 0.f; }
+      if (key < S) {
+        const T* kp = KV + (size_t)(b * S + key) * a.ldkv + h * 64 + 8 * c;
+        load8f(kp, kx);
+        load8f(kp + 256, vx);
+        rope8(kx, a.cos, a.sin, key, 4 * c, 1.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { kx[i] = to_f(from_f<T>(kx[i])); mk = fmaxf(mk, fabsf(kx[i])); mv = fmaxf(mv, fabsf(vx[i])); }
+      }
+      *reinterpret_cast<long*>(Ks8 + row * F8LD + 8 * c) = pack_fp8x8(kx, sk);
+      const long vp = pack_fp8x8(vx, sv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) Vt8[(8 * c + i) * F8LD + row] = (unsigned char)((unsigned long)vp >> (8 * i));
+    }
+    __syncthreads();
+
+    f32x4 sacc[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      sacc[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const long kf = *reinterpret_cast<const long*>(Ks8 + (16 * st + r) * F8LD + 32 * ks + 8 * g);
+        sacc[st] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(kf, qf[ks], sacc[st], 0, 0, 0);
+      }
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = kt * 64 + 16 * st + 4 * g + e;
+        sacc[st][e] = key < S ? sacc[st][e] * s_deq : -1e30f;
+        mx = fmaxf(mx, sacc[st][e]);
+      }
+    mx = max_xor32(max_xor16(mx));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      float pv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float p = __expf(sacc[st][e] - m_new);
+        psum += p;
+        if (a.drop_thresh24) {
+          const int key = kt * 64 + 16 * st + 4 * g + e;
+          const bool keep = rng_keep(a.seed, a.stream, gdrop_idx(b, a.H, h, S, qrow, key), a.drop_thresh24);
+          p = keep ? p * a.inv_keep : 0.f;
+        }
+        pv[e] = p * F8_P_SCALE;
+      }
+      int pk = __builtin_amdgcn_cvt_pk_fp8_f32(pv[0], pv[1], 0, false);
+      pk = __builtin_amdgcn_cvt_pk_fp8_f32(pv[2], pv[3], pk, true);
+      *reinterpret_cast<int*>(Pw + r * F8LD + 16 * st + 4 * g) = pk;
+    }
+    psum = sum_xor32(sum_xor16(psum));
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
+    __syncthreads();
+    // O^T[d][q] += V^T[d][key] P^T[key][q]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const long pf = *reinterpret_cast<const long*>(Pw + r * F8LD + 32 * ks + 8 * g);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const long vf = *reinterpret_cast<const long*>(Vt8 + (16 * dt + r) * F8LD + 32 * ks + 8 * g);
+        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(vf, pf, oacc[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (qrow < S) {
+    const float inv = o_deq / l_run;
+    T* op = reinterpret_cast<T*>(a.O) + (size_t)(b * S + qrow) * a.ldo + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = oacc[dt][e] * inv;
+      store4f(op + 16 * dt + 4 * g, o);
+    }
+    if (g == 0 && a.LSE != nullptr) a.LSE[(size_t)(b * a.H + h) * S + qrow] = m_run + logf(l_run);
+  }
+  // per-tensor |max| of this call (non-negative floats order like their bit patterns)
+  mq = group_max<64>(mq); mk = group_max<64>(mk); mv = group_max<64>(mv);
+  if (lane == 0) {
+    atomicMax(reinterpret_cast<unsigned int*>(amax_cur) + 0, __float_as_uint(mq));
+    atomicMax(reinterpret_cast<unsigned int*>(amax_cur) + 1, __float_as_uint(mk));
+    atomicMax(reinterpret_cast<unsigned int*>(amax_cur) + 2, __float_as_uint(mv));
+  }
+}
+
+__global__ void attn_fp8_roll_kernel(float* amax, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * 4) {
+    const int l = i >> 2, j = i & 3;
+    const float cur = amax[8 * l + 4 + j];
+    if (cur > 0.f) amax[8 * l + j] = cur;     // a layer that did not run keeps its last scale
+    amax[8 * l + 4 + j] = 0.f;
+  }
+}
+void attn_fp8_roll(hipStream_t s, float* amax, int n_layers) {
+  hipLaunchKernelGGL(attn_fp8_roll_kernel, dim3((n_layers * 4 + 63) / 64), dim3(64), 0, s, amax, n_layers);
+}
+
+void attn_global_fwd_fp8(hipStream_t s, const AttnArgs& a, const float* amax_prev, float* amax_cur) {
+  dim3 grid(((a.B * a.H + 7) / 8 * 8) * ((a.S + 63) / 64));
+  ProfScope ps(s, "attn_global_fwd_fp8", 4.0 * a.B * a.H * (double)a.S * a.S * 64, 4.0 * a.B * a.S * a.H * 64 * 2);
+  hipLaunchKernelGGL(attn_global_fwd_fp8_kernel, grid, dim3(256), 0, s, a, amax_prev, amax_cur);
+}
+
 // ------------------------------------------------------------------ global backward: dQ (and delta)
 template <typename T>
 AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, int b, int h, unsigned char* smem_raw) {

@@ -238,6 +238,11 @@ struct AttnBwdArgs {
 };
 void attn_global_fwd(hipStream_t s, DType dt, const AttnArgs& a);
 void attn_global_bwd(hipStream_t s, DType dt, const AttnBwdArgs& a);
+// bf16 activations, fp8 (e4m3) QK^T / PV with per-tensor delayed scaling: amax_prev[3] (|q|, |k|, |v| maxima of the
+// previous call of this layer; 0 = none yet) gives the scales, amax_cur[3] (zeroed by the caller) receives this call's
+void attn_global_fwd_fp8(hipStream_t s, const AttnArgs& a, const float* amax_prev, float* amax_cur);
+// start of a forward pass: per layer, prev <- cur, cur <- 0 (amax laid out [layers][prev[4] | cur[4]])
+void attn_fp8_roll(hipStream_t s, float* amax, int n_layers);
 void attn_local_fwd(hipStream_t s, DType dt, const AttnArgs& a);
 void attn_local_bwd(hipStream_t s, DType dt, const AttnBwdArgs& a);
 

@@ -298,6 +298,8 @@ struct amt_ctx {
   bool use_side = false;
   bool fuse = true;             // chain kernels (chain.hip); AMT_FUSE=0 selects the unfused launch sequence
   int nochain = 0;              // debugging: AMT_NOCHAIN bit mask disables individual chain kernels / riders
+  bool attn_fp8 = false;        // amt_set_attn_fp8: global-attention forward on fp8 MFMA (bf16 contexts only)
+  float* amax = nullptr;        // [layers][prev q,k,v,- | cur q,k,v,-]: delayed per-tensor scaling state
   bool fuse_ffn = false;        // AMT_FUSE_FFN=1: whole second half of a layer in one launch (measured slower)
 
   const float* P(size_t off) const { return params + off; }
@@ -388,6 +390,8 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
 
   c->ssave.assign(cfg.n_stages, StageSave());
   c->lsave.assign(L.layers.size(), LayerSave());
+  const bool fp8 = c->attn_fp8 && dt == DT_BF16;
+  if (fp8) RUN(attn_fp8_roll(s, c->amax, (int)L.layers.size()));
 
   int Lcur = T / 5;
   const size_t act_elems = (size_t)B * Lcur * 4;   // B * C * L is constant over stages
@@ -518,7 +522,9 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
     aa.QC = ls.qc; aa.ldqc = L.QC; aa.KV = ls.kv; aa.ldkv = L.KVW; aa.O = ls.ao; aa.ldo = H; aa.LSE = ls.lse;
     aa.cos = c->rope_cos; aa.sin = c->rope_sin; aa.B = B; aa.S = S; aa.H = cfg.n_heads;
     aa.seed = seed; aa.stream = stream_attn((int)li); aa.drop_thresh24 = dp.thr; aa.inv_keep = dp.inv_keep;
-    if (local) RUN(attn_local_fwd(s, dt, aa)); else RUN(attn_global_fwd(s, dt, aa));
+    if (local) RUN(attn_local_fwd(s, dt, aa));
+    else if (fp8) RUN(attn_global_fwd_fp8(s, aa, c->amax + 8 * li, c->amax + 8 * li + 4));
+    else RUN(attn_global_fwd(s, dt, aa));
     // h = x + attn . Wo^T ; out = h + FFN(LN2(h))
     ls.h = save ? A.alloc((size_t)N * H * es) : out_buf(0);
     void* y = save ? A.alloc((size_t)N * H * es) : out_buf(0);
@@ -1130,7 +1136,7 @@ void amt_destroy(amt_ctx* c) {
   (void)hipSetDevice(c->device);
   void* ptrs[] = {c->params, c->wc, c->head_bias, c->conv_dev, c->conv_prefix_dev, c->rope_cos, c->rope_sin,
                   c->arena.base, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, c->norm2, c->loss_acc,
-                  c->partials, c->part_desc_dev};
+                  c->partials, c->part_desc_dev, c->amax};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1154,6 +1160,17 @@ int32_t amt_set_rope(amt_ctx* c, const float* cos_table, const float* sin_table,
   if (n_pos <= 0) { c->err = "amt_set_rope: n_pos must be positive"; return 1; }
   c->rope_user = true;
   return upload_rope(c, cos_table, sin_table, n_pos);
+}
+
+int32_t amt_set_attn_fp8(amt_ctx* c, int32_t enable) {
+  if (enable && c->dt != DT_BF16) { c->err = "amt_set_attn_fp8: fp8 attention needs a bf16 context"; return 1; }
+  if (enable && c->amax == nullptr) {
+    const size_t bytes = c->L.layers.size() * 8 * sizeof(float);
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->amax), bytes));
+    HIPCHK(c, hipMemset(c->amax, 0, bytes));
+  }
+  c->attn_fp8 = enable != 0;
+  return 0;
 }
 
 int32_t amt_forward(amt_ctx* c, const void* audio, int32_t B, int32_t T, float* logits, float* probs, void* stream) {

@@ -112,6 +112,19 @@ int32_t amt_op_attn_fwd(int32_t dtype, int32_t local, const void* QC, int32_t ld
   return done();
 }
 
+int32_t amt_op_attn_global_fwd_fp8(const void* QC, int32_t ldqc, const void* KV, int32_t ldkv, void* O, int32_t ldo,
+                                   float* LSE, const float* cos_t, const float* sin_t, int32_t B, int32_t S, int32_t H,
+                                   uint64_t seed, uint32_t stream_id, float drop_p, float* amax, void* stream) {
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.QC = QC; a.ldqc = ldqc; a.KV = KV; a.ldkv = ldkv; a.O = O; a.ldo = ldo; a.LSE = LSE; a.cos = cos_t; a.sin = sin_t;
+  a.B = B; a.S = S; a.H = H; a.seed = seed; a.stream = stream_id; a.drop_thresh24 = thr24(drop_p);
+  a.inv_keep = inv_keep(drop_p);
+  attn_fp8_roll(st(stream), amax, 1);
+  attn_global_fwd_fp8(st(stream), a, amax, amax + 4);
+  return done();
+}
+
 int32_t amt_op_attn_bwd(int32_t dtype, int32_t local, const void* QC, int32_t ldqc, const void* KV, int32_t ldkv,
                         const void* O, int32_t ldo, const float* LSE, const float* cos_t, const float* sin_t, int32_t B,
                         int32_t S, int32_t H, uint64_t seed, uint32_t stream_id, float drop_p, const void* dO,

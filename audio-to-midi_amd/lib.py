@@ -87,6 +87,7 @@ SIGNATURES = {
     "amt_weights_ptr": (_vp, [_vp]),
     "amt_refresh_weights": (_i32, [_vp, _vp]),
     "amt_set_rope": (_i32, [_vp, _vp, _vp, _i32]),
+    "amt_set_attn_fp8": (_i32, [_vp, _i32]),
     "amt_num_frames": (_i32, [C.POINTER(AmtConfig), _i32]),
     "amt_forward": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "amt_forward_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _u64, _i32, _vp, _vp, _vp, _vp, _vp]),
@@ -112,6 +113,8 @@ SIGNATURES = {
     "amt_op_scale_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "amt_op_attn_fwd": (_i32, [_i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _u64,
                                _u32, _f32, _vp]),
+    "amt_op_attn_global_fwd_fp8": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _u64, _u32,
+                                          _f32, _vp, _vp]),
     "amt_op_attn_bwd": (_i32, [_i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _u64,
                                _u32, _f32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp]),
     "amt_op_bce_loss": (_i32, [_i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),

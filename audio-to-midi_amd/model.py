@@ -146,6 +146,12 @@ class OutputSequenceGenerator:
                                          cos.shape[0]), "amt_set_rope")
         self._rope_key = key
 
+    def set_attn_fp8(self, enable: bool = True):
+        """Global-attention forward on fp8 (e4m3) MFMA with delayed per-tensor scaling (include/amt.h:
+        amt_set_attn_fp8; BASELINE configs[4]).  bf16 models only; not part of the reference (model.py:333-386
+        computes attention in the activation dtype), so it is off unless asked for."""
+        self._check(self._L.amt_set_attn_fp8(self._h, 1 if enable else 0), "amt_set_attn_fp8")
+
     # ------------------------------------------------------------------ shape checks
     def _prep_audio(self, samples):
         if not torch.is_tensor(samples):

@@ -87,6 +87,13 @@ int32_t amt_refresh_weights(amt_ctx* ctx, void* stream);
  * arithmetic. */
 int32_t amt_set_rope(amt_ctx* ctx, const float* cos_table, const float* sin_table, int32_t n_pos);
 
+/* BASELINE configs[4] (the reference has no fp8 path; its attention is model.py:333-386): run S = QK^T and
+ * O = PV of the GLOBAL-attention forward on fp8 (e4m3) MFMA with per-tensor delayed scaling (the scales of a
+ * call come from the |max| of q, k, v seen in the context's previous forward; the first call assumes 16).
+ * bf16 contexts only; softmax, backward and everything else are unchanged.  Off by default: results differ
+ * from the bf16 path by fp8 rounding (tests/test_model_gpu.py states the bound). */
+int32_t amt_set_attn_fp8(amt_ctx* ctx, int32_t enable);
+
 /* frames produced for T samples (T must be a multiple of 320) */
 int32_t amt_num_frames(const amt_config* cfg, int32_t T);
 

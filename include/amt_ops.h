@@ -54,6 +54,11 @@ int32_t amt_op_scale_bwd(int32_t dtype, const void* dY, const void* Z, const flo
 int32_t amt_op_attn_fwd(int32_t dtype, int32_t local, const void* QC, int32_t ldqc, const void* KV, int32_t ldkv,
                         void* O, int32_t ldo, float* LSE, const float* cos_t, const float* sin_t, int32_t B, int32_t S,
                         int32_t H, uint64_t seed, uint32_t stream_id, float drop_p, void* stream);
+/* bf16 global attention forward with fp8 (e4m3) QK^T / PV (amt.h: amt_set_attn_fp8).  amax: device float[8],
+ * {previous |q|,|k|,|v| maxima, -, this call's, -}; the call first rolls cur -> prev (zeros = no history). */
+int32_t amt_op_attn_global_fwd_fp8(const void* QC, int32_t ldqc, const void* KV, int32_t ldkv, void* O, int32_t ldo,
+                                   float* LSE, const float* cos_t, const float* sin_t, int32_t B, int32_t S, int32_t H,
+                                   uint64_t seed, uint32_t stream_id, float drop_p, float* amax, void* stream);
 int32_t amt_op_attn_bwd(int32_t dtype, int32_t local, const void* QC, int32_t ldqc, const void* KV, int32_t ldkv,
                         const void* O, int32_t ldo, const float* LSE, const float* cos_t, const float* sin_t,
                         int32_t B, int32_t S, int32_t H, uint64_t seed, uint32_t stream_id, float drop_p,
