@@ -261,12 +261,70 @@ AMT_DEV long pack_fp8x8(const float (&x)[8], float scale) {
 }
 AMT_DEV float fp8_scale_from_amax(float amax) { return (F8_MAX * 0.9f) / (amax > 0.f ? amax : 16.f); }
 
+// key tile in flight: K as two 8-element chunks per thread (+ their RoPE entries), V as 2 x 4 keys x one
+// feature pair per thread (the transposed LDS tile takes four keys of one feature as one dword)
+struct Fp8Stage { Chunk8<bf16> kc[2]; RopeRegs rr; uint32_t v[2][4]; };
+
+AMT_DEV void fp8_kv_load(Fp8Stage& st, const bf16* KV, int ldkv, int b, int h, int S, int kt, int tid,
+                         const float* __restrict__ cs, const float* __restrict__ sn) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int id = tid + 256 * it, row = id >> 3, c = id & 7;
+    const int key = kt * 64 + row, keyc = key < S ? key : S - 1;
+    st.kc[it] = chunk_load(KV + (size_t)(b * S + keyc) * ldkv + h * 64 + 8 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { st.rr.c[it][j] = cs[keyc * 32 + 4 * c + j]; st.rr.s[it][j] = sn[keyc * 32 + 4 * c + j]; }
+    const int dp = tid & 31, kg = (tid >> 5) + 8 * it;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int vk = kt * 64 + 4 * kg + j, vkc = vk < S ? vk : S - 1;
+      st.v[it][j] = *reinterpret_cast<const uint32_t*>(KV + (size_t)(b * S + vkc) * ldkv + 256 + h * 64 + 2 * dp);
+    }
+  }
+}
+
+AMT_DEV void fp8_kv_store(unsigned char* Ks8, unsigned char* Vt8, const Fp8Stage& st, int S, int kt, int tid, float sk,
+                          float sv, float& mk, float& mv) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int id = tid + 256 * it, row = id >> 3, c = id & 7;
+    const int key = kt * 64 + row;
+    float kx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kx[i] = chunk_get(st.kc[it], i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rope_pair(kx[2 * j], kx[2 * j + 1], st.rr.c[it][j], st.rr.s[it][j], 1.f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      kx[i] = key < S ? to_f(from_f<bf16>(kx[i])) : 0.f;
+      mk = fmaxf(mk, fabsf(kx[i]));
+    }
+    *reinterpret_cast<long*>(Ks8 + row * F8LD + 8 * c) = pack_fp8x8(kx, sk);
+    const int dp = tid & 31, kg = (tid >> 5) + 8 * it;
+    float lo[4], hi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = kt * 64 + 4 * kg + j < S;
+      lo[j] = ok ? __uint_as_float(st.v[it][j] << 16) : 0.f;
+      hi[j] = ok ? __uint_as_float(st.v[it][j] & 0xffff0000u) : 0.f;
+      mv = fmaxf(mv, fmaxf(fabsf(lo[j]), fabsf(hi[j])));
+    }
+    int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0] * sv, lo[1] * sv, 0, false);
+    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2] * sv, lo[3] * sv, p0, true);
+    int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(hi[0] * sv, hi[1] * sv, 0, false);
+    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(hi[2] * sv, hi[3] * sv, p1, true);
+    *reinterpret_cast<int*>(Vt8 + (2 * dp) * F8LD + 4 * kg) = p0;
+    *reinterpret_cast<int*>(Vt8 + (2 * dp + 1) * F8LD + 4 * kg) = p1;
+  }
+}
+
 __global__ __launch_bounds__(256) void attn_global_fwd_fp8_kernel(AttnArgs a, const float* __restrict__ amax_prev,
                                                                   float* __restrict__ amax_cur) {
   typedef bf16 T;
   __shared__ __attribute__((aligned(16))) unsigned char Ks8[64 * F8LD];   // [key][d]
   __shared__ __attribute__((aligned(16))) unsigned char Vt8[64 * F8LD];   // [d][key]
   __shared__ __attribute__((aligned(16))) unsigned char Ps8[4 * 16 * F8LD];
+  __shared__ float wmax[4][3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
   const int S = a.S, ntile = (S + 63) / 64;
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
@@ -277,6 +335,8 @@ __global__ __launch_bounds__(256) void attn_global_fwd_fp8_kernel(AttnArgs a, co
   const T* QC = reinterpret_cast<const T*>(a.QC);
   const T* KV = reinterpret_cast<const T*>(a.KV);
   unsigned char* Pw = Ps8 + wave * 16 * F8LD;
+  Fp8Stage stg;
+  fp8_kv_load(stg, KV, a.ldkv, b, h, S, 0, tid, a.cos, a.sin);
   const float sq = fp8_scale_from_amax(amax_prev[0]), sk = fp8_scale_from_amax(amax_prev[1]),
               sv = fp8_scale_from_amax(amax_prev[2]);
   const float s_deq = 1.f / (sq * sk), o_deq = 1.f / (F8_P_SCALE * sv);
@@ -305,28 +365,9 @@ __global__ __launch_bounds__(256) void attn_global_fwd_fp8_kernel(AttnArgs a, co
   const int nkt = (S + 63) / 64;
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
-    // stage K (rotated) and V^T of this key tile as fp8
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int id = tid + 256 * it, row = id >> 3, c = id & 7;
-      const int key = kt * 64 + row;
-      float kx[8], vx[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { kx[i] = 0.f; vx[i] = 0.f; }
-      if (key < S) {
-        const T* kp = KV + (size_t)(b * S + key) * a.ldkv + h * 64 + 8 * c;
-        load8f(kp, kx);
-        load8f(kp + 256, vx);
-        rope8(kx, a.cos, a.sin, key, 4 * c, 1.f);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { kx[i] = to_f(from_f<T>(kx[i])); mk = fmaxf(mk, fabsf(kx[i])); mv = fmaxf(mv, fabsf(vx[i])); }
-      }
-      *reinterpret_cast<long*>(Ks8 + row * F8LD + 8 * c) = pack_fp8x8(kx, sk);
-      const long vp = pack_fp8x8(vx, sv);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) Vt8[(8 * c + i) * F8LD + row] = (unsigned char)((unsigned long)vp >> (8 * i));
-    }
+    fp8_kv_store(Ks8, Vt8, stg, S, kt, tid, sk, sv, mk, mv);
     __syncthreads();
+    if (kt + 1 < nkt) fp8_kv_load(stg, KV, a.ldkv, b, h, S, kt + 1, tid, a.cos, a.sin);
 
     f32x4 sacc[4];
 #pragma unroll
@@ -398,12 +439,15 @@ __global__ __launch_bounds__(256) void attn_global_fwd_fp8_kernel(AttnArgs a, co
     }
     if (g == 0 && a.LSE != nullptr) a.LSE[(size_t)(b * a.H + h) * S + qrow] = m_run + logf(l_run);
   }
-  // per-tensor |max| of this call (non-negative floats order like their bit patterns)
+  // per-tensor |max| of this call: one atomic per workgroup and tensor, and only if it raises the value
+  // (non-negative floats order like their bit patterns)
   mq = group_max<64>(mq); mk = group_max<64>(mk); mv = group_max<64>(mv);
-  if (lane == 0) {
-    atomicMax(reinterpret_cast<unsigned int*>(amax_cur) + 0, __float_as_uint(mq));
-    atomicMax(reinterpret_cast<unsigned int*>(amax_cur) + 1, __float_as_uint(mk));
-    atomicMax(reinterpret_cast<unsigned int*>(amax_cur) + 2, __float_as_uint(mv));
+  if (lane == 0) { wmax[wave][0] = mq; wmax[wave][1] = mk; wmax[wave][2] = mv; }
+  __syncthreads();
+  if (tid < 3) {
+    const float m = fmaxf(fmaxf(wmax[0][tid], wmax[1][tid]), fmaxf(wmax[2][tid], wmax[3][tid]));
+    if (m > __builtin_nontemporal_load(amax_cur + tid))
+      atomicMax(reinterpret_cast<unsigned int*>(amax_cur) + tid, __float_as_uint(m));
   }
 }
 

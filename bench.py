@@ -172,7 +172,8 @@ def main_infer(args):
                 "us_per_step": round(t_cnn * 1e6, 1), "algorithmic_bytes_per_step": by}
     out = {"metric": "audio-sec/s (inference fwd, 5 s windows)", "value": round(clips * seconds / (elapsed / args.steps), 1),
            "unit": "audio-sec/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 (fp8 e4m3 QK^T / PV in the global-attention forward)" if args.attn_fp8 else "bf16", "data": "synthetic",
            "config": {"workload": "streaming inference (BASELINE configs[3]): 32 clips x 60 s -> 448 windows x 5 s, "
                                   "forward (bf16) resident in HBM; stitch_probs on the host timed separately",
                       "windows": int(B), "frames_per_window": int(probs.shape[1]), "stitched_frames_per_clip": int(stitched[0].shape[0])},
@@ -197,9 +198,16 @@ def main():
     ap.add_argument("--workload", choices=["train", "infer"], default="train",
                     help="train = BASELINE configs[1] (default, the headline metric); infer = configs[3]: streaming "
                          "inference, 32 x 60 s clips -> 448 windows of 5 s, forward + stitch (reported, not the headline)")
+    ap.add_argument("--clips-per-gpu", type=int, default=8,
+                    help="10 s clips per GPU and step (default 8 = configs[1]; 32 = configs[4]'s 256 over 8 GPUs)")
+    ap.add_argument("--attn-fp8", action="store_true",
+                    help="configs[4]: global-attention forward on fp8 MFMA (amt_set_attn_fp8); reported, not the headline")
     args = ap.parse_args()
     if args.workload == "infer":
         return main_infer(args)
+    global B_PER_GPU, FLOPS_PER_STEP
+    B_PER_GPU = args.clips_per_gpu
+    FLOPS_PER_STEP = B_PER_GPU * 50.75e9
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -220,6 +228,8 @@ def main():
     from audio_to_midi_amd import lib as amtlib
 
     model = amt.OutputSequenceGenerator(amt.model_config, key=1234, dtype="bfloat16", device=dev)
+    if args.attn_fp8:
+        model.set_attn_fp8(True)
     audio_np, labels_np = amt.synth.make_batch_fast(B_PER_GPU, T_SAMPLES, seed=100 + rank)
     audio = torch.from_numpy(audio_np).to(dev, torch.bfloat16)       # inputs resident in HBM
     labels = torch.from_numpy(labels_np).to(dev)
@@ -384,8 +394,8 @@ def main():
             "metric": "audio-sec/s (fwd+bwd, 10 s clips)", "value": round(value, 1), "unit": "audio-sec/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "train.py step: fwd + BCE + bwd of the full model, 8 clips x 10 s @ 16 kHz stereo per "
-                                   "GPU, train mode (dropout 0.1)" + (", RCCL all-reduce of the fp32 grad bucket" if world > 1 else "")
+            "config": {"workload": f"train.py step: fwd + BCE + bwd of the full model, {B_PER_GPU} clips x 10 s @ 16 kHz stereo per "
+                                   "GPU, train mode (dropout 0.1)" + (", global-attention forward on fp8 MFMA" if args.attn_fp8 else "") + (", RCCL all-reduce of the fp32 grad bucket" if world > 1 else "")
                                    + ("" if args.no_optimizer else ", AdamW + global-norm clip + bf16 weight refresh"),
                        "global_batch": world * B_PER_GPU, "clip_seconds": CLIP_SECONDS, "frames": T_SAMPLES // 320,
                        "parallelism": f"dp{world}", "hipgraph": (graph is not None) or (graph_a is not None),
