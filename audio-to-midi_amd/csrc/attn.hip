@@ -757,9 +757,15 @@ void attn_global_bwd(hipStream_t s, DType dt, const AttnBwdArgs& a) {
 // ------------------------------------------------------------------ local (windowed) attention
 // One wave per (stripe of 8 output positions, head, clip).  Output position j = 8 s + i is covered
 // by window A = s - 1 (its rows 8..15) and window B = s (its rows 0..7); both windows are
-// evaluated in LDS and averaged, which reproduces model.py:451-469 without atomics.  Everything is
-// fp32 VALU work on LDS-resident data (8 MFLOP per clip-layer: latency-, not throughput-bound).
-constexpr int LLD = 65;
+// evaluated by the same wave and averaged, which reproduces model.py:451-469 without atomics.
+// A 16 x 16 x 64 window is exactly MFMA-shaped: the 24 tokens the stripe touches are staged once in
+// LDS (q / k rotated per window, as the reference rotates inside every window), scores and dP come out
+// of MFMAs with the query on the lane axis (softmax = a reduction over 4 registers and the 4 lane
+// groups), and the second GEMMs take both windows in ONE 32-deep step: their operand tiles hold
+// window A in k = 0..15 and window B in k = 16..31 (rows 0..7 / 8..15 where the two results must stay
+// apart because their rotations differ).  (The first version of these kernels did the same sums as
+// fp32 VALU dot products over LDS: 13.9 / 37.8 us per launch at 8 clips.)
+constexpr int OLD = 40;   // row stride (elements) of the 16 x 32 operand tiles
 
 struct LocalGeom { int padL, nW, Lp; };
 static LocalGeom local_geom(int S, int W) {
@@ -795,22 +801,25 @@ AMT_DEV void mask8(float (&x)[8], bool ok) {
   }
 }
 
+// rotate chunk c of a token for window-relative position pos, round to the activation dtype (as the
+// reference does), scale (a power of two: exact), store as 8 elements of an LDS tile row
 template <typename T>
-AMT_DEV void store_roped(float (*dst)[LLD], int row, int c, const float (&x)[8], const float* cs, const float* sn,
-                         int pos, float scale) {
+AMT_DEV void store_roped(T* row, int c, const float (&x)[8], const float* cs, const float* sn, int pos, float scale) {
   float y[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) y[i] = x[i];
   rope8(y, cs, sn, pos, 4 * c, 1.f);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) dst[row][8 * c + i] = to_f(from_f<T>(y[i])) * scale;
+  for (int i = 0; i < 8; ++i) y[i] = to_f(from_f<T>(y[i])) * scale;
+  store8f(row + 8 * c, y);
 }
 
 template <typename T>
 __global__ __launch_bounds__(64) void attn_local_fwd_kernel(AttnArgs a, int padL, int nW) {
-  __shared__ float qA[8][LLD], qB[8][LLD], kA[16][LLD], kB[16][LLD], vs[24][LLD];
-  __shared__ float P[2][8][17];
-  const int lane = threadIdx.x, s = blockIdx.x, h = blockIdx.y, b = blockIdx.z, S = a.S;
+  // qs: the stripe's 8 queries twice: row i rotated as row i of window B, row 8 + i as row 8 + i of window A
+  __shared__ __attribute__((aligned(16))) T qs[16][ALD], kA[16][ALD], kB[16][ALD], vs[24][ALD], Pt[8][OLD];
+  const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+  const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z, S = a.S;
   const bool validA = (s >= 1) && (s - 1 < nW), validB = (s < nW);
   const T* QC = reinterpret_cast<const T*>(a.QC);
   const T* KV = reinterpret_cast<const T*>(a.KV);
@@ -828,63 +837,65 @@ __global__ __launch_bounds__(64) void attn_local_fwd_kernel(AttnArgs a, int padL
       load_tok_chunk(KV, a.ldkv, b, S, p, padL, 256 + h * 64 + 8 * c, vx[it]);
     }
     mask8(qx, okq);
-    store_roped<T>(qA, qi, qc, qx, a.cos, a.sin, 8 + qi, 0.125f);
-    store_roped<T>(qB, qi, qc, qx, a.cos, a.sin, qi, 0.125f);
+    store_roped<T>(qs[8 + qi], qc, qx, a.cos, a.sin, 8 + qi, 0.125f);
+    store_roped<T>(qs[qi], qc, qx, a.cos, a.sin, qi, 0.125f);
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
       int id = lane + 64 * it, jp = id >> 3, c = id & 7;
       mask8(kx[it], okk[it]);
       mask8(vx[it], okk[it]);
-      if (jp < 16) store_roped<T>(kA, jp, c, kx[it], a.cos, a.sin, jp, 1.f);
-      if (jp >= 8) store_roped<T>(kB, jp - 8, c, kx[it], a.cos, a.sin, jp - 8, 1.f);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) vs[jp][8 * c + i] = vx[it][i];
+      if (jp < 16) store_roped<T>(kA[jp], c, kx[it], a.cos, a.sin, jp, 1.f);
+      if (jp >= 8) store_roped<T>(kB[jp - 8], c, kx[it], a.cos, a.sin, jp - 8, 1.f);
+      store8f(&vs[jp][8 * c], vx[it]);
     }
   }
   __syncthreads();
-  {
-    const int w = lane >> 5, i = (lane >> 2) & 7, kg = lane & 3;
-    float (*qw)[LLD] = w ? qB : qA;
-    float (*kw)[LLD] = w ? kB : kA;
-    float sc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int d = 0; d < 64; ++d) {
-      float qv = qw[i][d];
+  // scores, transposed: lane (r, g) holds keys 4 g + e of query row r; rows >= 8 belong to window A
+  f32x4 sA = f32x4{0.f, 0.f, 0.f, 0.f}, sB = sA;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) sc[kk] += qv * kw[4 * kg + kk][d];
-    }
-    float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-    mx = group_max<4>(mx);
-    float sum = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) { sc[kk] = __expf(sc[kk] - mx); sum += sc[kk]; }
-    sum = group_sum<4>(sum);
-    float inv = 1.f / sum;
-    const int win = s - 1 + w, iw = w ? i : 8 + i;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      float p = sc[kk] * inv;
-      if (a.drop_thresh24) {
-        bool keep = rng_keep(a.seed, a.stream, ldrop_idx(b, a.H, h, nW, win, iw, 4 * kg + kk), a.drop_thresh24);
-        p = keep ? p * a.inv_keep : 0.f;
-      }
-      P[w][i][4 * kg + kk] = p;
-    }
+  for (int ks = 0; ks < 2; ++ks) {
+    const Frag<T> qf = frag_row(&qs[r][32 * ks + 8 * g]);
+    mma(sA, frag_row(&kA[r][32 * ks + 8 * g]), qf);
+    mma(sB, frag_row(&kB[r][32 * ks + 8 * g]), qf);
   }
-  __syncthreads();
-  {
-    const int d = lane;
-    const float fa = validA ? 1.f : 0.f, fb = validB ? 1.f : 0.f;
-    const float icnt = 1.f / (fa + fb);
-    T* O = reinterpret_cast<T*>(a.O);
-    for (int i = 0; i < 8; ++i) {
-      float oA = 0.f, oB = 0.f;
+  const bool isA = r >= 8;
+  float sc[4];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        oA += P[0][i][j] * vs[j][d];
-        oB += P[1][i][j] * vs[8 + j][d];
-      }
-      int jo = 8 * s + i;
-      if (jo < S) O[(size_t)(b * S + jo) * a.ldo + h * 64 + d] = from_f<T>((fa * oA + fb * oB) * icnt);
+  for (int e = 0; e < 4; ++e) sc[e] = isA ? sA[e] : sB[e];
+  float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+  mx = max_xor32(max_xor16(mx));
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { sc[e] = __expf(sc[e] - mx); sum += sc[e]; }
+  sum = sum_xor32(sum_xor16(sum));
+  const float fa = validA ? 1.f : 0.f, fb = validB ? 1.f : 0.f;
+  const float wgt = (isA ? fa : fb) / (fa + fb) / sum;      // window average folded into P (0, 1/2 or 1: exact)
+  const int win = isA ? s - 1 : s;
+  float pv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float p = sc[e] * wgt;
+    if (a.drop_thresh24) {
+      bool keep = rng_keep(a.seed, a.stream, ldrop_idx(b, a.H, h, nW, win, r, 4 * g + e), a.drop_thresh24);
+      p = keep ? p * a.inv_keep : 0.f;
+    }
+    pv[e] = p;
+  }
+  // Pt[i][0..15] = P_A[8 + i][keys], Pt[i][16..31] = P_B[i][keys]
+  store4f(&Pt[r & 7][(isA ? 0 : 16) + 4 * g], pv);
+  __syncthreads();
+  // O^T[d][i] = sum_k V^T[d][k] Pt[i][k]; k = 8 g + j is token row {0, 8, 8, 16}[g] + j of the stripe's 24
+  const Frag<T> pf = frag_row(&Pt[r & 7][8 * g]);
+  const int vrow = g == 0 ? 0 : (g == 3 ? 16 : 8);
+  T* O = reinterpret_cast<T*>(a.O);
+  const int jo = 8 * s + r;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma(o, frag_col16(&vs[vrow][16 * dt], ALD, r), pf);
+    if (r < 8 && jo < S) {
+      float ov[4] = {o[0], o[1], o[2], o[3]};
+      store4f(O + (size_t)(b * S + jo) * a.ldo + h * 64 + 16 * dt + 4 * g, ov);
     }
   }
 }
@@ -901,10 +912,16 @@ AMT_DEV float local_cnt(int p, int nW) {
 template <typename T>
 __global__ __launch_bounds__(64) void attn_local_bwd_kernel(AttnBwdArgs ba, int padL, int nW) {
   const AttnArgs& a = ba.f;
-  __shared__ float qA[16][LLD], qB[16][LLD], kA[16][LLD], kB[16][LLD], vs[24][LLD], dOs[24][LLD];
-  __shared__ float Pd[2][16][17], dS[2][16][17];
-  const int lane = threadIdx.x, s = blockIdx.x, h = blockIdx.y, b = blockIdx.z, S = a.S;
+  __shared__ __attribute__((aligned(16))) T qA[16][ALD], qB[16][ALD], kA[16][ALD], kB[16][ALD], vs[24][ALD], dOs[24][ALD];
+  // operand tiles of the second GEMMs, k = 0..15 window A, k = 16..31 window B:
+  //   opq rows 0..7  = dS_A[8 + m][key k]       rows 8..15 = dS_B[m - 8][key k - 16]    (other halves zero)
+  //   opk rows 0..7  = dS_A[query k][8 + m]      rows 8..15 = dS_B[query k - 16][m - 8]
+  //   opv rows 0..7  = Pd_A[query k][8 + m] | Pd_B[query k - 16][m]                      rows 8..15 zero
+  __shared__ __attribute__((aligned(16))) T ops[3][16][OLD];
+  const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+  const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z, S = a.S;
   const bool validA = (s >= 1) && (s - 1 < nW), validB = (s < nW);
+  const float fa = validA ? 1.f : 0.f, fb = validB ? 1.f : 0.f;
   const T* QC = reinterpret_cast<const T*>(a.QC);
   const T* KV = reinterpret_cast<const T*>(a.KV);
   const T* dO = reinterpret_cast<const T*>(ba.dO);
@@ -922,6 +939,8 @@ __global__ __launch_bounds__(64) void attn_local_bwd_kernel(AttnBwdArgs ba, int 
       int pc = p < 0 ? 0 : (p >= S ? S - 1 : p);   // dO lives at OUTPUT coordinate p (no pad shift)
       load8f(dO + (size_t)(b * S + pc) * ba.lddo + h * 64 + 8 * c, dx[it]);
     }
+    T* opz = &ops[0][0][0];
+    for (int i = lane; i < 3 * 16 * OLD / 8; i += 64) chunk_store(opz + 8 * i, chunk_zero<T>());
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
       int id = lane + 64 * it, jp = id >> 3, c = id & 7;
@@ -929,101 +948,138 @@ __global__ __launch_bounds__(64) void attn_local_bwd_kernel(AttnBwdArgs ba, int 
       mask8(qx[it], okt[it]);
       mask8(kx[it], okt[it]);
       mask8(vx[it], okt[it]);
-      if (jp < 16) store_roped<T>(qA, jp, c, qx[it], a.cos, a.sin, jp, 0.125f);
-      if (jp >= 8) store_roped<T>(qB, jp - 8, c, qx[it], a.cos, a.sin, jp - 8, 0.125f);
-      if (jp < 16) store_roped<T>(kA, jp, c, kx[it], a.cos, a.sin, jp, 1.f);
-      if (jp >= 8) store_roped<T>(kB, jp - 8, c, kx[it], a.cos, a.sin, jp - 8, 1.f);
-      // window-output gradient divided by the cover count; zero outside [0, S)
+      if (jp < 16) store_roped<T>(qA[jp], c, qx[it], a.cos, a.sin, jp, 0.125f);
+      if (jp >= 8) store_roped<T>(qB[jp - 8], c, qx[it], a.cos, a.sin, jp - 8, 0.125f);
+      if (jp < 16) store_roped<T>(kA[jp], c, kx[it], a.cos, a.sin, jp, 1.f);
+      if (jp >= 8) store_roped<T>(kB[jp - 8], c, kx[it], a.cos, a.sin, jp - 8, 1.f);
+      // window-output gradient divided by the cover count (1 or 2: exact); zero outside [0, S)
       const bool okp = (p >= 0) && (p < S);
       const float ic = okp ? 1.f / local_cnt(okp ? p : 0, nW) : 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        vs[jp][8 * c + i] = vx[it][i];
-        dOs[jp][8 * c + i] = dx[it][i] * ic;
-      }
+      for (int i = 0; i < 8; ++i) dx[it][i] *= ic;
+      store8f(&vs[jp][8 * c], vx[it]);
+      store8f(&dOs[jp][8 * c], dx[it]);
     }
   }
-  __syncthreads();
-  {
-    const int w = lane >> 5, i = (lane >> 1) & 15, hf = lane & 1;
-    float (*qw)[LLD] = w ? qB : qA;
-    float (*kw)[LLD] = w ? kB : kA;
-    float sc[8], dp[8];
+  // rotation entries of the output phase: this lane un-rotates rows 4 g + e of the result tiles, i.e.
+  // window position 8 + 4 g + e (window A, lane groups 0-1) or 4 (g - 2) + e (window B), feature 16 dt + r
+  float ucs[4][4], usn[4][4];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) { sc[kk] = 0.f; dp[kk] = 0.f; }
-    for (int d = 0; d < 64; ++d) {
-      float qv = qw[i][d], dv = dOs[8 * w + i][d];
+  for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        sc[kk] += qv * kw[8 * hf + kk][d];
-        dp[kk] += dv * vs[8 * w + 8 * hf + kk][d];
-      }
+    for (int e = 0; e < 4; ++e) {
+      const int pos = g < 2 ? 8 + 4 * g + e : 4 * (g - 2) + e;
+      ucs[dt][e] = a.cos[pos * 32 + 8 * dt + (r >> 1)];
+      usn[dt][e] = a.sin[pos * 32 + 8 * dt + (r >> 1)];
     }
-    float mx = sc[0];
+  __syncthreads();
 #pragma unroll
-    for (int kk = 1; kk < 8; ++kk) mx = fmaxf(mx, sc[kk]);
-    mx = group_max<2>(mx);
-    float sum = 0.f;
+  for (int w = 0; w < 2; ++w) {
+    T (*qw)[ALD] = w ? qB : qA;
+    T (*kw)[ALD] = w ? kB : kA;
+    const int off = 8 * w;
+    // transposed scores and dP: lane (r, g) holds keys 4 g + e of query r
+    f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = sc;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) { sc[kk] = __expf(sc[kk] - mx); sum += sc[kk]; }
-    sum = group_sum<2>(sum);
-    float inv = 1.f / sum;
+    for (int ks = 0; ks < 2; ++ks) {
+      mma(sc, frag_row(&kw[r][32 * ks + 8 * g]), frag_row(&qw[r][32 * ks + 8 * g]));
+      mma(dp, frag_row(&vs[off + r][32 * ks + 8 * g]), frag_row(&dOs[off + r][32 * ks + 8 * g]));
+    }
+    float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+    mx = max_xor32(max_xor16(mx));
+    float p[4], sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { p[e] = __expf(sc[e] - mx); sum += p[e]; }
+    sum = sum_xor32(sum_xor16(sum));
+    const float inv = 1.f / sum;
     const int win = s - 1 + w;
-    float dl = 0.f, pdv[8];
+    float dl = 0.f, pd[4], dpm[4];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      float p = sc[kk] * inv;
-      float pd = p, dpm = dp[kk];
+    for (int e = 0; e < 4; ++e) {
+      p[e] *= inv;
+      pd[e] = p[e];
+      dpm[e] = dp[e];
       if (a.drop_thresh24) {
-        bool keep = rng_keep(a.seed, a.stream, ldrop_idx(b, a.H, h, nW, win, i, 8 * hf + kk), a.drop_thresh24);
-        pd = keep ? p * a.inv_keep : 0.f;
-        dpm = keep ? dpm * a.inv_keep : 0.f;
+        bool keep = rng_keep(a.seed, a.stream, ldrop_idx(b, a.H, h, nW, win, r, 4 * g + e), a.drop_thresh24);
+        pd[e] = keep ? p[e] * a.inv_keep : 0.f;
+        dpm[e] = keep ? dpm[e] * a.inv_keep : 0.f;
       }
-      sc[kk] = p;
-      dp[kk] = dpm;
-      pdv[kk] = pd;
-      dl += p * dpm;
+      dl += p[e] * dpm[e];
     }
-    dl = group_sum<2>(dl);
+    dl = sum_xor32(sum_xor16(dl));
+    float ds[4];
+    const float fw = w ? fb : fa;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      Pd[w][i][8 * hf + kk] = pdv[kk];
-      dS[w][i][8 * hf + kk] = sc[kk] * (dp[kk] - dl);
+    for (int e = 0; e < 4; ++e) { ds[e] = p[e] * (dpm[e] - dl); pd[e] *= fw; }
+    if (w == 0) {
+      if (r >= 8) store4f(&ops[0][r - 8][4 * g], ds);
+      if (g >= 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ops[1][4 * g + e - 8][r] = from_f<T>(ds[e]);
+          ops[2][4 * g + e - 8][r] = from_f<T>(pd[e]);
+        }
+      }
+    } else {
+      if (r < 8) store4f(&ops[0][8 + r][16 + 4 * g], ds);
+      if (g < 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ops[1][8 + 4 * g + e][16 + r] = from_f<T>(ds[e]);
+          ops[2][4 * g + e][16 + r] = from_f<T>(pd[e]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // vs is dead: its 24 rows become the three [8][64] output tiles (dq, dk, dv of the stripe)
+  T (*outq)[ALD] = vs;
+  T (*outk)[ALD] = vs + 8;
+  T (*outv)[ALD] = vs + 16;
+  {
+    const Frag<T> fq = frag_row(&ops[0][r][8 * g]), fk = frag_row(&ops[1][r][8 * g]), fv = frag_row(&ops[2][r][8 * g]);
+    const T* kp = g < 2 ? &kA[8 * g][0] : &kB[8 * (g - 2)][0];
+    const T* qp = g < 2 ? &qA[8 * g][0] : &qB[8 * (g - 2)][0];
+    const T* dop = &dOs[g == 0 ? 0 : (g == 3 ? 16 : 8)][0];
+    const float fw = g < 2 ? fa : fb;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 aq = f32x4{0.f, 0.f, 0.f, 0.f}, ak = aq, av = aq;
+      mma(aq, fq, frag_col16(kp + 16 * dt, ALD, r));
+      mma(ak, fk, frag_col16(qp + 16 * dt, ALD, r));
+      mma(av, fv, frag_col16(dop + 16 * dt, ALD, r));
+      // acc[e] = result row 4 g + e (rows 0..7: window A part of position i = row, rows 8..15: window B part
+      // of position i = row - 8), feature d = 16 dt + r.  Transpose of the rotation: the partner feature
+      // sits in the neighbouring lane.
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float c = ucs[dt][e], sn = usn[dt][e];
+        const float oq = dpp_mov<DPP_XOR1>(aq[e]), ok = dpp_mov<DPP_XOR1>(ak[e]);
+        float x = ((r & 1) ? (-oq * sn + aq[e] * c) : (aq[e] * c + oq * sn)) * (fw * 0.125f);
+        float y = ((r & 1) ? (-ok * sn + ak[e] * c) : (ak[e] * c + ok * sn)) * fw;
+        swap32(x, y);        // lanes 0..31: x = dq parts A, y = dq part B;  lanes 32..63: dk part A, dk part B
+        const float tot = x + y;
+        const int i = 4 * (g & 1) + e;
+        if (g < 2) {
+          outq[i][16 * dt + r] = from_f<T>(tot);
+          outv[i][16 * dt + r] = from_f<T>(av[e]);
+        } else {
+          outk[i][16 * dt + r] = from_f<T>(tot);
+        }
+      }
     }
   }
   __syncthreads();
   {
-    const int d = lane;
-    const float fa = validA ? 1.f : 0.f, fb = validB ? 1.f : 0.f;
-    T* dQC = reinterpret_cast<T*>(ba.dQC);
-    T* dKV = reinterpret_cast<T*>(ba.dKV);
-    for (int ip = 0; ip < 8; ++ip) {
-      float dvA = 0.f, dvB = 0.f, dqA = 0.f, dqB = 0.f, dkA = 0.f, dkB = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        dvA += Pd[0][i][8 + ip] * dOs[i][d];
-        dvB += Pd[1][i][ip] * dOs[8 + i][d];
-        dqA += dS[0][8 + ip][i] * kA[i][d];
-        dqB += dS[1][ip][i] * kB[i][d];
-        dkA += dS[0][i][8 + ip] * qA[i][d];
-        dkB += dS[1][i][ip] * qB[i][d];
-      }
-      // transpose of the rotation: partner feature sits in the neighbouring lane
-      auto unrope = [&](float v, int pos) {
-        float o = dpp_mov<DPP_XOR1>(v);
-        float c = a.cos[pos * 32 + (d >> 1)], sn = a.sin[pos * 32 + (d >> 1)];
-        return (d & 1) ? (-o * sn + v * c) : (v * c + o * sn);
-      };
-      float dq = (fa * unrope(dqA, 8 + ip) + fb * unrope(dqB, ip)) * 0.125f;
-      float dk = fa * unrope(dkA, 8 + ip) + fb * unrope(dkB, ip);
-      float dv = fa * dvA + fb * dvB;
-      int t = 8 * s + ip - padL;
-      if (t >= 0 && t < S) {
-        size_t row = (size_t)(b * S + t);
-        dQC[row * ba.lddqc + h * 64 + d] = from_f<T>(dq);
-        dKV[row * ba.lddkv + h * 64 + d] = from_f<T>(dk);
-        dKV[row * ba.lddkv + 256 + h * 64 + d] = from_f<T>(dv);
-      }
+    const int i = lane >> 3, c = lane & 7;
+    const int t = 8 * s + i - padL;
+    if (t >= 0 && t < S) {
+      const size_t row = (size_t)(b * S + t);
+      T* dQC = reinterpret_cast<T*>(ba.dQC);
+      T* dKV = reinterpret_cast<T*>(ba.dKV);
+      chunk_store(dQC + row * ba.lddqc + h * 64 + 8 * c, chunk_load(&outq[i][8 * c]));
+      chunk_store(dKV + row * ba.lddkv + h * 64 + 8 * c, chunk_load(&outk[i][8 * c]));
+      chunk_store(dKV + row * ba.lddkv + 256 + h * 64 + 8 * c, chunk_load(&outv[i][8 * c]));
     }
   }
 }
