@@ -611,47 +611,61 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
   for (int i = 0; i < 4; ++i) { dkacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const int nqt = (S + 63) / 64;
+  // the next query tile (q, dO, O chunks, RoPE entries, log-sum-exp) is in flight while this one is consumed
+  Chunk8<T> qc_[2], dc_[2], oc_[2];
+  RopeRegs rr;
+  float lse_next = 0.f;
+  auto q_load = [&](int qt) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      int id = tid + 256 * it, row = id >> 3, c = id & 7;
+      int q = qt * 64 + row;
+      int qc = q < S ? q : S - 1;
+      qc_[it] = chunk_load(QC + (size_t)(b * S + qc) * a.ldqc + h * 64 + 8 * c);
+      dc_[it] = chunk_load(dO + (size_t)(b * S + qc) * ba.lddo + h * 64 + 8 * c);
+      oc_[it] = chunk_load(O + (size_t)(b * S + qc) * a.ldo + h * 64 + 8 * c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { rr.c[it][j] = a.cos[qc * 32 + 4 * c + j]; rr.s[it][j] = a.sin[qc * 32 + 4 * c + j]; }
+    }
+    if (tid < 64) {
+      int q = qt * 64 + tid;
+      lse_next = (q < S) ? a.LSE[(size_t)(b * a.H + h) * S + q] : 0.f;
+    }
+  };
+  q_load(0);
   for (int qt = 0; qt < nqt; ++qt) {
     __syncthreads();
     {
-      float qx[2][8], dch[2][8], och[2][8];
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         int id = tid + 256 * it, row = id >> 3, c = id & 7;
         int q = qt * 64 + row;
-        int qc = q < S ? q : S - 1;
-        load8f(QC + (size_t)(b * S + qc) * a.ldqc + h * 64 + 8 * c, qx[it]);
-        load8f(dO + (size_t)(b * S + qc) * ba.lddo + h * 64 + 8 * c, dch[it]);
-        load8f(O + (size_t)(b * S + qc) * a.ldo + h * 64 + 8 * c, och[it]);
-      }
+        float qx[8], dch[8], och[8];
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        int id = tid + 256 * it, row = id >> 3, c = id & 7;
-        int q = qt * 64 + row;
+        for (int i = 0; i < 8; ++i) { qx[i] = chunk_get(qc_[it], i); dch[i] = chunk_get(dc_[it], i); och[i] = chunk_get(oc_[it], i); }
         if (q < S) {
-          rope8(qx[it], a.cos, a.sin, q, 4 * c, 1.f);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) qx[it][i] = to_f(from_f<T>(qx[it][i])) * 0.125f;
+          for (int j = 0; j < 4; ++j) rope_pair(qx[2 * j], qx[2 * j + 1], rr.c[it][j], rr.s[it][j], 1.f);   // = rope8
+#pragma unroll
+          for (int i = 0; i < 8; ++i) qx[i] = to_f(from_f<T>(qx[i])) * 0.125f;
         } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) { qx[it][i] = 0.f; dch[it][i] = 0.f; och[it][i] = 0.f; }
+          for (int i = 0; i < 8; ++i) { qx[i] = 0.f; dch[i] = 0.f; och[i] = 0.f; }
         }
-        store8f(Qs + row * ALD + 8 * c, qx[it]);
-        store8f(dOs + row * ALD + 8 * c, dch[it]);
+        store8f(Qs + row * ALD + 8 * c, qx);
+        store8f(dOs + row * ALD + 8 * c, dch);
         // delta[q] = sum_d dO[q][d] O[q][d] (8 lanes share a row), so this role does not depend on
         // the dQ role and both run in one launch
         float part = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) part += dch[it][i] * och[it][i];
+        for (int i = 0; i < 8; ++i) part += dch[i] * och[i];
         part = group_sum<8>(part);
         if (c == 0) delta_s[row] = part;
       }
     }
-    if (tid < 64) {
-      int q = qt * 64 + tid;
-      lse_s[tid] = (q < S) ? a.LSE[(size_t)(b * a.H + h) * S + q] : 0.f;
-    }
+    if (tid < 64) lse_s[tid] = lse_next;
     __syncthreads();
+    if (qt + 1 < nqt) q_load(qt + 1);
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f}, dpacc = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -124,6 +124,14 @@ __global__ void fill4_kernel(f32x4* p, float v, size_t n4) {
 __global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
+__global__ void copy_pad_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n, size_t n_pad) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = i < n ? src[i] : 0.f;
+}
+void copy_pad_f32(hipStream_t s, const float* src, float* dst, size_t n, size_t n_pad) {
+  int grid = (int)((n_pad + 255) / 256 < 2048 ? (n_pad + 255) / 256 : 2048);
+  hipLaunchKernelGGL(copy_pad_f32_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, s, src, dst, n, n_pad);
+}
 void copy_f32(hipStream_t s, const float* src, float* dst, size_t n) {
   int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   if (grid < 1) grid = 1;

@@ -263,6 +263,8 @@ void convert_f32(hipStream_t s, DType dt, const float* src, void* dst, size_t n)
 void convert_transpose(hipStream_t s, DType dt, const float* src, void* dst, int R, int C);
 void fill_f32(hipStream_t s, float* p, float v, size_t n);
 void copy_f32(hipStream_t s, const float* src, float* dst, size_t n);
+// dst[0..n) = src, dst[n..n_pad) = 0 in one launch
+void copy_pad_f32(hipStream_t s, const float* src, float* dst, size_t n, size_t n_pad);
 
 // AdamW (optax.adamw) on the flat parameter vector with per-segment learning rates
 // pass 1: update m, v, write the (unclipped) update into upd, accumulate sum(upd^2) into norm2[0]

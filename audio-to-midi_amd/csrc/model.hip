@@ -1013,8 +1013,7 @@ int refresh(amt_ctx* c, hipStream_t s) {
   const Layout& L = c->L;
   convert_batch(s, c->dt, c->params, c->wc, c->conv_dev, c->conv_prefix_dev, (int)L.conv.size(), c->conv_tiles);
   // padded head bias
-  fill_f32(s, c->head_bias, 0.f, L.VP);
-  copy_f32(s, c->params + L.hd_b, c->head_bias, c->cfg.n_events);
+  copy_pad_f32(s, c->params + L.hd_b, c->head_bias, c->cfg.n_events, L.VP);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { c->err = std::string("refresh_weights: ") + hipGetErrorString(e); return 1; }
   return 0;
