@@ -684,6 +684,252 @@ __global__ __launch_bounds__(256) void block_small_bwd_kernel(const T* __restric
   }
 }
 
+// ------------------------------------------------------------------ whole Block backward per position, C <= 8
+// One launch per Block instead of three (block_small_bwd + dwblock_bwd + a grouped weight-gradient GEMM with
+// 1000-2000 workgroups for 4..16-wide outputs: 54-56 us per Block at 8 clips).  One thread owns one position of
+// a 256-row tile (250 interior rows + 3 halo rows each side):
+//   phase 1  du = (pw2^T gamma . dy) gelu'(u), dln = pw1^T . du, LayerNorm', dD -> LDS; du, h, LN output and dy of
+//            the interior rows are staged in LDS as [position][16] tiles
+//   phase 2  dX = dY + dwconv^T(dD), depthwise tap / bias sums; the two 1x1-conv weight gradients are
+//            [16 x 16] x 256-position MFMA products of the staged tiles read column-wise (a ones column in the
+//            LN tile yields the pw1 bias gradient)
+// Every parameter gradient leaves the kernel as one record per workgroup (reduce_partials sums them).
+template <int C> struct SmallBwd {
+  static constexpr int H2 = 2 * C, ROWS = 256, TL = ROWS - 6, FW = 16;
+  static constexpr int O_W1 = 0, O_B1 = H2 * C, O_W2 = O_B1 + H2, O_B2 = O_W2 + C * H2, O_LNW = O_B2 + C,
+                       O_LNB = O_LNW + C, O_TAPS = O_LNB + C, O_DWB = O_TAPS + 7 * C, O_G = O_DWB + C, REC = O_G + C;
+};
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void block_small_bwd_full_kernel(
+    const T* __restrict__ dY, const T* __restrict__ X, const T* __restrict__ U, const T* __restrict__ Hh,
+    const T* __restrict__ Z, const T* __restrict__ LNs, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const T* __restrict__ w2tg, const T* __restrict__ w1t, const float* __restrict__ wdw, const float* __restrict__ bdw,
+    const float* __restrict__ lnw, const float* __restrict__ gamma, T* __restrict__ dX, float* __restrict__ rec, int B,
+    int L, int tiles_per_clip, int total_tiles) {
+  using P = SmallBwd<C>;
+  constexpr int H2 = P::H2, TL = P::TL, FW = P::FW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T (*du_t)[FW] = reinterpret_cast<T (*)[FW]>(smem_raw);
+  T (*h_t)[FW] = du_t + 256;
+  T (*ln_t)[FW] = h_t + 256;
+  T (*dy_t)[FW] = ln_t + 256;
+  T (*dDs)[C] = reinterpret_cast<T (*)[C]>(dy_t + 256);
+  __shared__ float s2[H2 * C], s1[C * H2], sdw[7 * C], sbd[C], slw[C], sg[C];
+  for (int t = threadIdx.x; t < H2 * C; t += 256) { s2[t] = to_f(w2tg[t]); s1[t] = to_f(w1t[t]); }
+  for (int t = threadIdx.x; t < 7 * C; t += 256) sdw[t] = wdw[t];
+  if (threadIdx.x < C) { sbd[threadIdx.x] = bdw[threadIdx.x]; slw[threadIdx.x] = lnw[threadIdx.x]; sg[threadIdx.x] = gamma[threadIdx.x]; }
+  const int p = threadIdx.x, lane = p & 63, wave = p >> 6, r = lane & 15, g = lane >> 4;
+  float alw[C], alb[C], ab[C], aw[7][C], ag[C], adb2[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    alw[c] = 0.f; alb[c] = 0.f; ab[c] = 0.f; ag[c] = 0.f; adb2[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) aw[k][c] = 0.f;
+  }
+  f32x4 aw1 = f32x4{0.f, 0.f, 0.f, 0.f}, aw2 = aw1;
+  for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    const int b = t / tiles_per_clip, l0 = (t % tiles_per_clip) * TL;
+    const long rb = (long)b * L;
+    const int l = l0 - 3 + p;
+    const bool valid = (l >= 0) && (l < L);
+    const bool inner = valid && p >= 3 && p < TL + 3;
+    const int lcl = l < 0 ? 0 : (l >= L ? L - 1 : l);
+    const long row = rb + lcl;
+    __syncthreads();   // weights staged / previous tile's tiles consumed
+    float dy[C];
+    {
+      float u[H2], hh[H2], z[C], ln[C], x[7][C];
+      loadvf<C>(dY + row * C, dy);
+      loadvf<C>(Z + row * C, z);
+      loadvf<C>(LNs + row * C, ln);
+      if constexpr (H2 == 8) {
+        loadvf<8>(U + row * H2, u);
+        loadvf<8>(Hh + row * H2, hh);
+      } else {
+        float t0[8], t1[8];
+        loadvf<8>(U + row * H2, t0); loadvf<8>(U + row * H2 + 8, t1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { u[i] = t0[i]; u[8 + i] = t1[i]; }
+        loadvf<8>(Hh + row * H2, t0); loadvf<8>(Hh + row * H2 + 8, t1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { hh[i] = t0[i]; hh[8 + i] = t1[i]; }
+      }
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int ll = lcl + k - 3;
+        const int lc = ll < 0 ? 0 : (ll >= L ? L - 1 : ll);
+        loadvf<C>(X + (rb + lc) * C, x[k]);
+      }
+      const float mu = mean[row], rs = rstd[row];
+      const float fin = inner ? 1.f : 0.f, fv = valid ? 1.f : 0.f;
+      float du[H2], dl[C];
+#pragma unroll
+      for (int j = 0; j < H2; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) a += s2[j * C + c] * dy[c];
+        du[j] = to_f(from_f<T>(a * gelu_tanh_grad(u[j])));
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < H2; ++j) a += s1[c * H2 + j] * du[j];
+        dl[c] = to_f(from_f<T>(a));
+      }
+      float d[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) d[c] = sbd[c];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int ll = lcl + k - 3;
+        const float m = (ll >= 0 && ll < L) ? 1.f : 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) d[c] += sdw[k * C + c] * (x[k][c] * m);
+      }
+      float q1 = 0.f, q2 = 0.f, gy[C], o[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        d[c] = (d[c] - mu) * rs;
+        gy[c] = dl[c] * slw[c];
+        q1 += gy[c];
+        q2 += gy[c] * d[c];
+        alw[c] += fin * dl[c] * d[c];
+        alb[c] += fin * dl[c];
+        adb2[c] += fin * dy[c];
+        ag[c] += fin * dy[c] * z[c];
+      }
+      q1 *= (1.f / C);
+      q2 *= (1.f / C);
+#pragma unroll
+      for (int c = 0; c < C; ++c) o[c] = fv * rs * (gy[c] - q1 - d[c] * q2);
+      storevf<C>(&dDs[p][0], o);
+      // operand tiles of the two weight-gradient products (halo / out-of-clip rows contribute nothing)
+      float t0[8], t1[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { t0[i] = i < H2 ? fin * du[i] : 0.f; t1[i] = (8 + i) < H2 ? fin * du[(8 + i) < H2 ? 8 + i : 0] : 0.f; }
+      storevf<8>(&du_t[p][0], t0); storevf<8>(&du_t[p][8], t1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { t0[i] = i < H2 ? hh[i] : 0.f; t1[i] = (8 + i) < H2 ? hh[(8 + i) < H2 ? 8 + i : 0] : 0.f; }
+      storevf<8>(&h_t[p][0], t0); storevf<8>(&h_t[p][8], t1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { t0[i] = i < C ? ln[i < C ? i : 0] : (i == C ? 1.f : 0.f); t1[i] = (8 + i) == C ? 1.f : 0.f; }
+      storevf<8>(&ln_t[p][0], t0); storevf<8>(&ln_t[p][8], t1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { t0[i] = i < C ? fin * dy[i < C ? i : 0] : 0.f; t1[i] = 0.f; }
+      storevf<8>(&dy_t[p][0], t0); storevf<8>(&dy_t[p][8], t1);
+    }
+    __syncthreads();
+    {
+      const float fi = inner ? 1.f : 0.f;
+      const int pc = p < 3 ? 3 : (p >= TL + 3 ? TL + 2 : p);     // clamp so that halo threads read inside the tile
+      float o[C], dd[C];
+      loadvf<C>(&dDs[pc][0], dd);
+#pragma unroll
+      for (int c = 0; c < C; ++c) { o[c] = dy[c]; dd[c] *= fi; ab[c] += dd[c]; }
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        float tq[C], x[C];
+        loadvf<C>(&dDs[pc + 3 - k][0], tq);      // dD[l - k + 3] (zero outside the clip)
+        const int lx = lcl + k - 3;
+        const int lxc = lx < 0 ? 0 : (lx >= L ? L - 1 : lx);
+        const float mx = (lx >= 0 && lx < L) ? 1.f : 0.f;
+        loadvf<C>(X + (rb + lxc) * C, x);
+#pragma unroll
+        for (int c = 0; c < C; ++c) { o[c] += sdw[k * C + c] * tq[c]; aw[k][c] += dd[c] * (x[c] * mx); }
+      }
+      if (inner) storevf<C>(dX + row * C, o);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ks = 2 * wave + kk;
+        mma(aw1, frag_col16(&du_t[32 * ks + 8 * g][0], FW, r), frag_col16(&ln_t[32 * ks + 8 * g][0], FW, r));
+        mma(aw2, frag_col16(&h_t[32 * ks + 8 * g][0], FW, r), frag_col16(&dy_t[32 * ks + 8 * g][0], FW, r));
+      }
+    }
+  }
+  // ---- one record per workgroup
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem_raw);     // [4 waves][2][16][16] MFMA sums, then [4][12 C] row sums
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[wave * 512 + (4 * g + e) * 16 + r] = aw1[e];         // [j][n]: n < C pw1 weight, n == C pw1 bias
+    red[wave * 512 + 256 + (4 * g + e) * 16 + r] = aw2[e];   // [j][c] = sum h[j] dy[c]
+  }
+  auto fold = [&](const float (&acc)[C], int slot) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float v = group_sum<64>(acc[c]);
+      if (lane == 0) red[2048 + wave * 12 * C + slot * C + c] = v;
+    }
+  };
+  fold(alw, 0);
+  fold(alb, 1);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) fold(aw[k], 2 + k);
+  fold(ab, 9);
+  fold(ag, 10);
+  fold(adb2, 11);
+  __syncthreads();
+  float* R = rec + (size_t)blockIdx.x * P::REC;
+  {
+    const int j = p >> 4, n = p & 15;
+    const float v1 = red[p] + red[512 + p] + red[1024 + p] + red[1536 + p];
+    const float v2 = red[256 + p] + red[768 + p] + red[1280 + p] + red[1792 + p];
+    if (j < H2) {
+      if (n < C) { R[P::O_W1 + j * C + n] = v1; R[P::O_W2 + n * H2 + j] = v2 * sg[n]; }
+      else if (n == C) R[P::O_B1 + j] = v1;
+    }
+  }
+  if (p < 12 * C) {
+    const float v = red[2048 + p] + red[2048 + 12 * C + p] + red[2048 + 24 * C + p] + red[2048 + 36 * C + p];
+    if (p < 11 * C) R[P::O_LNW + p] = v;                       // lnw | lnb | taps 7C | dw bias | gamma
+    else R[P::O_B2 + (p - 11 * C)] = v * sg[p - 11 * C];        // pw2 bias (layer scale folded in, like the weight)
+  }
+}
+
+template <typename T, int C>
+static void block_small_bwd_full_t(hipStream_t s, const SmallBwdArgs& a, float* rec, int nb, int tiles_per_clip, int total) {
+  const size_t lds = (size_t)(4 * 256 * 16 + 256 * C) * sizeof(T);
+  if (lds > 48 * 1024) {
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(block_small_bwd_full_kernel<T, C>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), true);
+    (void)once;
+  }
+  hipLaunchKernelGGL((block_small_bwd_full_kernel<T, C>), dim3(nb), dim3(256), lds, s, (const T*)a.dY, (const T*)a.X,
+                     (const T*)a.U, (const T*)a.Hh, (const T*)a.Z, (const T*)a.LN, a.mean, a.rstd, (const T*)a.w2tg,
+                     (const T*)a.w1t, a.wdw, a.bdw, a.lnw, a.gamma, (T*)a.dX, rec, a.B, a.L, tiles_per_clip, total);
+}
+
+void block_small_bwd_full(hipStream_t s, DType dt, const SmallBwdArgs& a, PartialSink* sink) {
+  const int C = a.C, H2 = 2 * C, TL = 250;
+  const int tiles_per_clip = (a.L + TL - 1) / TL, total = a.B * tiles_per_clip;
+  const int nb = total < 512 ? total : 512;
+  const int REC = 4 * C * C + 14 * C;
+  const size_t o = sink->take((size_t)nb * REC);
+  size_t q = o;
+  sink->add(q, nb, REC, H2 * C, a.dW1); q += H2 * C;
+  sink->add(q, nb, REC, H2, a.db1); q += H2;
+  sink->add(q, nb, REC, C * H2, a.dW2); q += C * H2;
+  sink->add(q, nb, REC, C, a.db2); q += C;
+  sink->add(q, nb, REC, C, a.dlnw); q += C;
+  sink->add(q, nb, REC, C, a.dlnb); q += C;
+  sink->add(q, nb, REC, 7 * C, a.dwdw); q += 7 * C;
+  sink->add(q, nb, REC, C, a.dbdw); q += C;
+  sink->add(q, nb, REC, C, a.dgamma);
+  if (sink->dry) return;
+  float* rec = sink->ws + o;
+  const long N = (long)a.B * a.L;
+  ProfScope ps(s, "block_small_bwd_full", 2.0 * N * (7 * C * 2 + 12 * C * C), 9.0 * N * C * (dt == DT_F32 ? 4 : 2));
+  if (dt == DT_F32) {
+    if (C == 4) block_small_bwd_full_t<float, 4>(s, a, rec, nb, tiles_per_clip, total);
+    else block_small_bwd_full_t<float, 8>(s, a, rec, nb, tiles_per_clip, total);
+  } else {
+    if (C == 4) block_small_bwd_full_t<bf16, 4>(s, a, rec, nb, tiles_per_clip, total);
+    else block_small_bwd_full_t<bf16, 8>(s, a, rec, nb, tiles_per_clip, total);
+  }
+}
+
 void block_small_fwd(hipStream_t s, DType dt, const void* X, const float* wdw, const float* bdw, const float* lnw,
                      const float* lnb, const void* w1, const float* b1, const void* w2, const float* b2,
                      const float* gamma, void* LN, float* mean, float* rstd, void* U, void* Hh, void* Z, void* Y, int B,

@@ -95,6 +95,19 @@ void stem_fwd(hipStream_t s, DType dt, const void* audio, const float* w /*[4][2
               const float* lnw, const float* lnb, void* Y, int B, int T);
 void stem_bwd(hipStream_t s, DType dt, const void* audio, const void* dY, const float* w, const float* b,
               const float* lnw, float* dw, float* db, float* dlnw, float* dlnb, int B, int T, PartialSink* sink = nullptr);
+// whole Block backward for C <= 8 in one launch (cnn.hip): data gradient dX and, as per-workgroup records in
+// `sink`, every parameter gradient of the Block (pw1 / pw2 weights + biases with the layer scale folded into pw2's,
+// LayerNorm, depthwise taps + bias, gamma).  Pointers d* are the destinations inside the gradient buffer.
+struct SmallBwdArgs {
+  const void *dY, *X, *U, *Hh, *Z, *LN;
+  const float *mean, *rstd;
+  const void *w2tg, *w1t;
+  const float *wdw, *bdw, *lnw, *gamma;
+  void* dX;
+  float *dW1, *db1, *dW2, *db2, *dlnw, *dlnb, *dwdw, *dbdw, *dgamma;
+  int B, L, C;
+};
+void block_small_bwd_full(hipStream_t s, DType dt, const SmallBwdArgs& a, PartialSink* sink);
 // Y = LN(dwconv7(X) + bdw) ; X,Y [B][L][C]; saves mean/rstd [B*L]
 void dwln_fwd(hipStream_t s, DType dt, const void* X, const float* wdw /*[7][C]*/, const float* bdw,
               const float* lnw, const float* lnb, void* Y, float* mean, float* rstd, int B, int L, int C);

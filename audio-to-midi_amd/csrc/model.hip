@@ -857,6 +857,23 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       const bool carrier = c->fuse && C >= 16 && !side_on && !(c->nochain & 2) && !(c->nochain & 64);
       begin_scope(carrier);
       const void* dy = dcur;
+      if (C <= 8 && c->fuse && !(c->nochain & 512)) {
+        // stages 0 / 1: the whole Block backward, weight gradients included, in one launch
+        di = (di + 1) % 3;
+        void* dx = dbuf[di];
+        SmallBwdArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.dY = dy; sa.X = bs.x; sa.U = bs.u; sa.Hh = bs.h; sa.Z = bs.z; sa.LN = bs.ln; sa.mean = bs.mean; sa.rstd = bs.rstd;
+        sa.w2tg = c->WC(bp.c_pw2tg); sa.w1t = c->WC(bp.c_pw1t); sa.wdw = c->P(bp.dw_w); sa.bdw = c->P(bp.dw_b);
+        sa.lnw = c->P(bp.ln_w); sa.gamma = c->P(bp.gamma); sa.dX = dx;
+        sa.dW1 = G(bp.pw1_w); sa.db1 = G(bp.pw1_b); sa.dW2 = G(bp.pw2_w); sa.db2 = G(bp.pw2_b); sa.dlnw = G(bp.ln_w);
+        sa.dlnb = G(bp.ln_b); sa.dwdw = G(bp.dw_w); sa.dbdw = G(bp.dw_b); sa.dgamma = G(bp.gamma);
+        sa.B = B; sa.L = Lcur; sa.C = C;
+        block_small_bwd_full(s, dt, sa, &sink);
+        dcur = dx;
+        end_scope();
+        continue;
+      }
       // layer scale folded away: dz = gamma * dy is never materialised.  The data-gradient GEMM uses a
       // gamma-scaled copy of pw2^T, the pw2 weight/bias gradients are row-scaled in their epilogue
       // and dgamma = sum dy * z is formed in the fused tail kernel.
