@@ -173,7 +173,7 @@ def main_infer(args):
     out = {"metric": "audio-sec/s (inference fwd, 5 s windows)", "value": round(clips * seconds / (elapsed / args.steps), 1),
            "unit": "audio-sec/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 (fp8 e4m3 QK^T / PV in the global-attention forward)" if args.attn_fp8 else "bf16", "data": "synthetic",
+            "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "streaming inference (BASELINE configs[3]): 32 clips x 60 s -> 448 windows x 5 s, "
                                   "forward (bf16) resident in HBM; stitch_probs on the host timed separately",
                       "windows": int(B), "frames_per_window": int(probs.shape[1]), "stitched_frames_per_clip": int(stitched[0].shape[0])},
@@ -396,7 +396,8 @@ def main():
         out = {
             "metric": "audio-sec/s (fwd+bwd, 10 s clips)", "value": round(value, 1), "unit": "audio-sec/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 (fp8 e4m3 QK^T / PV in the global-attention forward)" if args.attn_fp8 else "bf16", "data": "synthetic",
             "config": {"workload": f"train.py step: fwd + BCE + bwd of the full model, {B_PER_GPU} clips x 10 s @ 16 kHz stereo per "
                                    "GPU, train mode (dropout 0.1)" + (", global-attention forward on fp8 MFMA" if args.attn_fp8 else "") + (", RCCL all-reduce of the fp32 grad bucket" if world > 1 else "")
                                    + ("" if args.no_optimizer else ", AdamW + global-norm clip + bf16 weight refresh"),

@@ -27,7 +27,8 @@ def classify(name):
                      ("block_fwd_fused_kernel", "block_fwd_fused"), ("block_bwd_fused_kernel", "block_bwd_fused+wgrad"),
                      ("qkv_fwd_fused_kernel", "qkv_fwd_fused"), ("qkv_bwd_fused_kernel", "qkv_bwd_fused"),
                      ("lnout_bwd_fused_kernel", "lnout_bwd_fused"), ("block_small_fwd_kernel", "block_small_fwd"),
-                     ("block_small_bwd_kernel", "block_small_bwd"),
+                     ("block_small_bwd_kernel", "block_small_bwd"), ("block_small_bwd_full_kernel", "block_small_bwd_full"),
+                     ("attn_global_fwd_fp8_kernel", "attn_global_fwd_fp8"),
                      ("attn_global_bwd_kernel", "attn_global_bwd"), ("attn_global_fwd_kernel", "attn_global_fwd"),
                      ("attn_local_bwd_kernel", "attn_local_bwd"), ("attn_local_fwd_kernel", "attn_local_fwd"),
                      ("ln_bwd_kernel", "layernorm_bwd"), ("ln_fwd_kernel", "layernorm_fwd"),
