@@ -632,7 +632,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   // carry them (block_bwd_fused), they run in extra workgroups of that launch, off the dependent
   // chain and without a launch of their own; otherwise they are launched when the next scope begins.
   // The buffers they read stay valid for exactly one more scope (two alternating scratch regions,
-  // three rotating residual-gradient buffers), which is all either form needs.
+  // four rotating residual-gradient buffers; "pass" scopes below stretch it by one short scope).
   std::vector<WgradArgs> deferred;
   auto flush_deferred = [&]() {
     for (size_t i = 0; i < deferred.size(); i += 8) {
@@ -679,6 +679,26 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     }
     side_done.push_back(done);
   };
+  // "Pass" scopes (final CNN LayerNorm, Downsample backward: two small launches, no chain kernel that could carry
+  // riders): they do not flush the deferred weight gradients, so those ride on the first Block-backward chain of
+  // the NEXT stage together with the pass scope's own.  A pass scope works in the scratch region of the scope
+  // that follows it (it does not advance the region parity), so the deferred problems' scratch operands stay
+  // intact until that scope's launch has run them; the residual-gradient buffers rotate over FOUR for the same
+  // reason.  The weight gradients a pass scope queues must not read its own scratch (they read the
+  // residual-gradient buffer and saved forward tensors only).
+  auto begin_pass_scope = [&]() {
+    if (side_on) { begin_scope(); return; }
+    A.off = mark + (side_done.size() & 1) * c->scratch_max;
+  };
+  auto end_pass_scope = [&]() {
+    if (side_on) { end_scope(); return; }
+    const size_t base = mark + (side_done.size() & 1) * c->scratch_max;
+    if (A.off > base && A.off - base > scratch_used) scratch_used = A.off - base;
+    deferred.insert(deferred.end(), pending_skinny.begin(), pending_skinny.end());
+    deferred.insert(deferred.end(), pending.begin(), pending.end());
+    pending.clear();
+    pending_skinny.clear();
+  };
   c->ev_used = 0;
   if (dry) c->ev_needed = 0;
 
@@ -692,11 +712,11 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   // two ping-pong gradient buffers for the residual stream / CNN activations
   const size_t act_elems = (size_t)B * (T / 5) * 4;
   const size_t res_elems = act_elems > (size_t)N * H ? act_elems : (size_t)N * H;
-  void* dbuf[3] = {A.alloc(res_elems * es), A.alloc(res_elems * es), A.alloc(res_elems * es)};
+  void* dbuf[4] = {A.alloc(res_elems * es), A.alloc(res_elems * es), A.alloc(res_elems * es), A.alloc(res_elems * es)};
   // dropout-masked copies of the transformer residual gradients rotate the same way: the copy written at
   // the end of scope t is read by scope t + 1 and by its weight-gradient riders inside scope t + 2
-  void* dropbuf[3] = {nullptr, nullptr, nullptr};
-  if (dp.thr) for (int i = 0; i < 3; ++i) dropbuf[i] = A.alloc((size_t)N * H * es);
+  void* dropbuf[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (dp.thr) for (int i = 0; i < 4; ++i) dropbuf[i] = A.alloc((size_t)N * H * es);
   int di = 0;
   mark = A.off;
   A.off = mark + 2 * c->scratch_max;     // both scratch regions are part of the plan
@@ -789,7 +809,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     if (local) RUN(attn_local_bwd(s, dt, ab)); else RUN(attn_global_bwd(s, dt, ab));
     const int ckv = cfg.kv_compress;
     const void* cptr = static_cast<const char*>(ls.qc) + (size_t)(L.QC - ckv) * es;
-    di = (di + 1) % 3;
+    di = (di + 1) % 4;
     void* dx = dbuf[di];
     if (chain_ok && !(c->nochain & 32)) {
       QkvBwdArgs qa;
@@ -827,23 +847,23 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   }
   // final CNN LayerNorm
   {
-    begin_scope();
-    di = (di + 1) % 3;
+    begin_pass_scope();
+    di = (di + 1) % 4;
     void* dx = dbuf[di];
     layernorm_bwd(s, dt, dcur, c->fn_x, c->fn_mean, c->fn_rstd, c->P(L.fn_w), nullptr, dx, G(L.fn_w), G(L.fn_b), N,
                       H, &sink);
     dcur = dx;
-    end_scope();
+    end_pass_scope();
   }
   // ---- boundary between the two halves: every gradient of [L.fn_w, n_params) is complete here
   if (dry) c->n_part_desc_half = (int)c->part_descs.size();
   if (phase == 1) {
-    flush_deferred();   // (empty: the final-LayerNorm scope queues no weight gradient)
+    flush_deferred();   // the first transformer layer's weight gradients (in the one-call step they ride on stage 6)
     RUN(reduce_partials(s, c->part_desc_dev, c->n_part_desc_half, c->partials, grads));
     RUN(grads_finalize(s, grads + L.fn_w, L.n_params - L.fn_w, 1.f / scale, grads_valid));
     return 0;
   }
-  if (phase == 2) { live = true; sink.dry = dry; }
+  if (phase == 2) { live = true; sink.dry = dry; deferred.clear(); }   // phase 1 ran the deferred problems itself (none of them takes sink records)
   // CNN stages, last to first
   int Lcur = S;
   for (int si = cfg.n_stages - 1; si >= 0; --si) {
@@ -859,7 +879,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       const void* dy = dcur;
       if (C <= 8 && c->fuse && !(c->nochain & 512)) {
         // stages 0 / 1: the whole Block backward, weight gradients included, in one launch
-        di = (di + 1) % 3;
+        di = (di + 1) % 4;
         void* dx = dbuf[di];
         SmallBwdArgs sa;
         memset(&sa, 0, sizeof(sa));
@@ -881,7 +901,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       void* du = A.alloc((size_t)Nn * 2 * C * es);
       if (c->fuse && C >= 16 && !(c->nochain & 2)) {
         wgrad(du, 2 * C, bs.ln, C, Nn, 2 * C, C, bp.pw1_w, C, (long)bp.pw1_b, 0);
-        di = (di + 1) % 3;
+        di = (di + 1) % 4;
         void* dx = dbuf[di];
         BlockBwdArgs ba;
         memset(&ba, 0, sizeof(ba));
@@ -906,7 +926,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
         RUN(gemm_nt(s, dt, EPI_STORE, g2));
       }
       wgrad(du, 2 * C, bs.ln, C, Nn, 2 * C, C, bp.pw1_w, C, (long)bp.pw1_b, 0);
-      di = (di + 1) % 3;
+      di = (di + 1) % 4;
       void* dx = dbuf[di];
       dwblock_bwd(s, dt, dln, bs.x, dy, bs.z, c->P(bp.dw_w), c->P(bp.dw_b), bs.mean, bs.rstd, c->P(bp.ln_w), dx,
                   G(bp.ln_w), G(bp.ln_b), G(bp.dw_w), G(bp.dw_b), G(bp.gamma), B, Lcur, C, &sink);
@@ -914,7 +934,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       end_scope();
     }
     if (si > 0) {
-      begin_scope();
+      begin_pass_scope();
       const int Cin = st.Cin, Lin = Lcur * 2;
       wgrad(dcur, C, sv.ln, 2 * Cin, Nn, C, 2 * Cin, st.conv_w, 2 * Cin, (long)st.conv_b, 0);
       void* dln = A.alloc((size_t)Nn * 2 * Cin * es);
@@ -922,13 +942,13 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
         GemmArgs g = gargs(dcur, C, c->WC(st.c_wt), C, Nn, 2 * Cin, C, nullptr, dln, 2 * Cin);
         RUN(gemm_nt(s, dt, EPI_STORE, g));
       }
-      di = (di + 1) % 3;
+      di = (di + 1) % 4;
       void* dx = dbuf[di];
       layernorm_bwd(s, dt, dln, sv.x, sv.mean, sv.rstd, c->P(st.ln_w), nullptr, dx, G(st.ln_w), G(st.ln_b), B * Lin,
                         Cin, &sink);
       dcur = dx;
       Lcur = Lin;
-      end_scope();
+      end_pass_scope();
     } else {
       stem_bwd(s, dt, audio, dcur, c->P(st.conv_w), c->P(st.conv_b), c->P(st.ln_w), G(st.conv_w), G(st.conv_b),
                G(st.ln_w), G(st.ln_b), B, T, &sink);
