@@ -126,13 +126,19 @@ AMT_DEV uint32_t gdrop_idx(int b, int H, int h, int S, int q, int key) {
 }
 
 // ------------------------------------------------------------------ global forward
-template <typename T>
-__global__ __launch_bounds__(256) void attn_global_fwd_kernel(AttnArgs a) {
+// NG = 2 groups of four waves share the 64 queries of the workgroup and split the key tiles
+// round-robin, each with its own K/V/P tiles in LDS, and merge their (max, sum, O) triples once at the end.  With one
+// group (= one wave per SIMD at 8 clips: 256 workgroups) the loop was bound by its own dependency chain
+// (MFMA -> softmax -> LDS round trip -> MFMA, three barriers per tile): 2.1 us per 64-key tile for ~1600
+// cycles of VALU issue.
+template <typename T, int NG>
+__global__ __launch_bounds__(256 * NG) void attn_global_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* Ks = reinterpret_cast<T*>(smem_raw);
+  const int tid_all = threadIdx.x, half = tid_all >> 8, tid = tid_all & 255;   // half = key-tile group 0 .. NG-1
+  T* Ks = reinterpret_cast<T*>(smem_raw) + half * (3 * 64 * ALD);
   T* Vs = Ks + 64 * ALD;
   T* Ps = Vs + 64 * ALD;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
   // XCD-aware order: the query tiles of one (clip, head) share K/V, so they get the same id % 8
   const int S = a.S, ntile = (S + 63) / 64;
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
@@ -165,69 +171,105 @@ __global__ __launch_bounds__(256) void attn_global_fwd_kernel(AttnArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nkt = (S + 63) / 64;
+  const int nkt = (S + 63) / 64, niter = (nkt + NG - 1) / NG;
   Chunk8<T> kc[2], vc[2];
   RopeRegs rr;
-  kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, 0, tid, a.cos, a.sin);
-  for (int kt = 0; kt < nkt; ++kt) {
+  if (half < nkt) kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, half, tid, a.cos, a.sin);
+  for (int it = 0; it < niter; ++it) {
+    const int kt = NG * it + half;
+    const bool active = kt < nkt;            // uniform over the group; barriers are taken by all 512 threads
     __syncthreads();
-    kv_store<T>(Ks, Vs, kc, vc, rr, S, kt, tid);
+    if (active) kv_store<T>(Ks, Vs, kc, vc, rr, S, kt, tid);
     __syncthreads();
-    if (kt + 1 < nkt) kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, kt + 1, tid, a.cos, a.sin);
+    if (kt + NG < nkt) kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, kt + NG, tid, a.cos, a.sin);
 
-    f32x4 sacc[4];
+    if (active) {
+      f32x4 sacc[4];
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      sacc[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int st = 0; st < 4; ++st) {
+        sacc[st] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) mma(sacc[st], frag_row(Ks + (16 * st + r) * ALD + 32 * ks + 8 * g), qf[ks]);
-    }
-    // sacc[st][e] = score[key = kt*64 + 16 st + 4 g + e][query = this lane's]
-    float mx = -1e30f;
-#pragma unroll
-    for (int st = 0; st < 4; ++st)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int key = kt * 64 + 16 * st + 4 * g + e;
-        if (key >= S) sacc[st][e] = -1e30f;
-        mx = fmaxf(mx, sacc[st][e]);
+        for (int ks = 0; ks < 2; ++ks) mma(sacc[st], frag_row(Ks + (16 * st + r) * ALD + 32 * ks + 8 * g), qf[ks]);
       }
-    mx = max_xor32(max_xor16(mx));
-    float m_new = fmaxf(m_run, mx);
-    float alpha = __expf(m_run - m_new);
-    float psum = 0.f;
+      // sacc[st][e] = score[key = kt*64 + 16 st + 4 g + e][query = this lane's]
+      float mx = -1e30f;
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      float pv[4];
+      for (int st = 0; st < 4; ++st)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float p = __expf(sacc[st][e] - m_new);
-        psum += p;
-        if (a.drop_thresh24) {
+        for (int e = 0; e < 4; ++e) {
           int key = kt * 64 + 16 * st + 4 * g + e;
-          bool keep = rng_keep(a.seed, a.stream, gdrop_idx(b, a.H, h, S, qrow, key), a.drop_thresh24);
-          p = keep ? p * a.inv_keep : 0.f;
+          if (key >= S) sacc[st][e] = -1e30f;
+          mx = fmaxf(mx, sacc[st][e]);
         }
-        pv[e] = p;
+      mx = max_xor32(max_xor16(mx));
+      float m_new = fmaxf(m_run, mx);
+      float alpha = __expf(m_run - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        float pv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float p = __expf(sacc[st][e] - m_new);
+          psum += p;
+          if (a.drop_thresh24) {
+            int key = kt * 64 + 16 * st + 4 * g + e;
+            bool keep = rng_keep(a.seed, a.stream, gdrop_idx(b, a.H, h, S, qrow, key), a.drop_thresh24);
+            p = keep ? p * a.inv_keep : 0.f;
+          }
+          pv[e] = p;
+        }
+        store4f(Pw + r * ALD + 16 * st + 4 * g, pv);
       }
-      store4f(Pw + r * ALD + 16 * st + 4 * g, pv);
+      psum = sum_xor32(sum_xor16(psum));
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
     }
-    psum = sum_xor32(sum_xor16(psum));
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
     __syncthreads();
-    // O^T[d][q] += V^T[d][key] P^T[key][q]
+    if (active) {
+      // O^T[d][q] += V^T[d][key] P^T[key][q]
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      Frag<T> pf = frag_row(Pw + r * ALD + 32 * ks + 8 * g);
+      for (int ks = 0; ks < 2; ++ks) {
+        Frag<T> pf = frag_row(Pw + r * ALD + 32 * ks + 8 * g);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) mma(oacc[dt], frag_col16(Vs + (32 * ks + 8 * g) * ALD + 16 * dt, ALD, r), pf);
+        for (int dt = 0; dt < 4; ++dt) mma(oacc[dt], frag_col16(Vs + (32 * ks + 8 * g) * ALD + 16 * dt, ALD, r), pf);
+      }
     }
   }
-  if (qrow < S) {
-    float inv = 1.f / l_run;
+  // merge: groups 1 .. NG-1 hand their (m, l, O) to group 0 through LDS
+  __syncthreads();
+  float* mg = reinterpret_cast<float*>(smem_raw) + (size_t)(wave * 64 + lane) * 18;
+  constexpr int MGS = 256 * 18;     // floats per group
+  if (half > 0) {
+    float* w = mg + (half - 1) * MGS;
+    w[0] = m_run; w[1] = l_run;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[2 + 4 * dt + e] = oacc[dt][e];
+  }
+  __syncthreads();
+  if (half == 0 && qrow < S) {
+    float m = m_run;
+#pragma unroll
+    for (int k = 0; k < NG - 1; ++k) m = fmaxf(m, mg[k * MGS]);
+    const float a0 = __expf(m_run - m);
+    float l = l_run * a0;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] *= a0;
+#pragma unroll
+    for (int k = 0; k < NG - 1; ++k) {
+      const float* w = mg + k * MGS;
+      const float ak = __expf(w[0] - m);
+      l += w[1] * ak;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) oacc[dt][e] += w[2 + 4 * dt + e] * ak;
+    }
+    const float inv = 1.f / l;
     T* op = reinterpret_cast<T*>(a.O) + (size_t)(b * S + qrow) * a.ldo + h * 64;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -236,7 +278,7 @@ __global__ __launch_bounds__(256) void attn_global_fwd_kernel(AttnArgs a) {
       for (int e = 0; e < 4; ++e) o[e] = oacc[dt][e] * inv;
       store4f(op + 16 * dt + 4 * g, o);
     }
-    if (g == 0 && a.LSE != nullptr) a.LSE[(size_t)(b * a.H + h) * S + qrow] = m_run + logf(l_run);
+    if (g == 0 && a.LSE != nullptr) a.LSE[(size_t)(b * a.H + h) * S + qrow] = m + logf(l);
   }
 }
 
@@ -742,13 +784,15 @@ void attn_global_fwd(hipStream_t s, DType dt, const AttnArgs& a) {
   ProfScope ps(s, "attn_global_fwd", 4.0 * a.B * a.H * (double)a.S * a.S * 64,
                4.0 * a.B * a.S * a.H * 64 * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) {
-    size_t lds = (size_t)(64 * 2 + 64) * ALD * sizeof(float);
-    static bool once = (set_max_lds(attn_global_fwd_kernel<float>, 96 * 1024), true);
+    size_t lds = (size_t)2 * (64 * 2 + 64) * ALD * sizeof(float);
+    static bool once = (set_max_lds(attn_global_fwd_kernel<float, 2>, 128 * 1024), true);
     (void)once;
-    hipLaunchKernelGGL((attn_global_fwd_kernel<float>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((attn_global_fwd_kernel<float, 2>), grid, dim3(512), lds, s, a);
   } else {
-    size_t lds = (size_t)(64 * 2 + 64) * ALD * sizeof(bf16);
-    hipLaunchKernelGGL((attn_global_fwd_kernel<bf16>), grid, dim3(256), lds, s, a);
+    // (four groups of two tiles each measured the same 13.9 us as two groups of four: what is left is the
+    // first-tile latency, the merge and the launch itself)
+    size_t lds = (size_t)2 * (64 * 2 + 64) * ALD * sizeof(bf16);
+    hipLaunchKernelGGL((attn_global_fwd_kernel<bf16, 2>), grid, dim3(512), lds, s, a);
   }
 }
 
