@@ -741,11 +741,13 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
           mma(dpacc, frag_row(dOs + (16 * st + r) * ALD + 32 * ks + 8 * g), vf[ks]);   // dP[q][key]
         }
         float pd[4], ds[4];
+        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * st + 4 * g);
+        const f32x4 del4 = *reinterpret_cast<const f32x4*>(delta_s + 16 * st + 4 * g);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           int ql = 16 * st + 4 * g + e, q = qt * 64 + ql;
           bool valid = (q < S) && (key < S);
-          float p = valid ? __expf(sacc[e] - lse_s[ql]) : 0.f;
+          float p = valid ? __expf(sacc[e] - lse4[e]) : 0.f;
           float dp = dpacc[e], pdrop = p;
           if (a.drop_thresh24) {
             bool keep = rng_keep(a.seed, a.stream, gdrop_idx(b, a.H, h, S, q, key), a.drop_thresh24);
@@ -753,7 +755,7 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
             pdrop = keep ? p * a.inv_keep : 0.f;
           }
           pd[e] = pdrop;
-          ds[e] = p * (dp - delta_s[ql]);
+          ds[e] = p * (dp - del4[e]);
         }
         store4f(PTw + r * ALD + 16 * st + 4 * g, pd);
         store4f(dSTw + r * ALD + 16 * st + 4 * g, ds);
