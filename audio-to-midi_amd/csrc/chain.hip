@@ -534,7 +534,11 @@ void block_bwd_fused(hipStream_t s, DType dt, const BlockBwdArgs& a_in, float* d
   if (dgamma) sink->add(o + 10 * C, nb, rec, C, dgamma);
   WgradGroup rg;
   double rfl = 0, rby = 0;
-  const int n_rider_wgs = wgrad_group_prepare(dt, riders, n_riders, sink, &rg, &rfl, &rby);
+  // Rider workgroups per Block-chain launch.  Measured (ms/step at cfg2): 48: 4.70, 96: 4.35, 144: 4.21, 224: 4.18,
+  // 336: 4.23, 448: 4.25, 640: 4.43; sizing them to the compute units the chain leaves free (256 - nb) gave 4.52: a
+  // rider workgroup is bound by its own load -> LDS -> MFMA stage latency, so fewer, longer riders end later.
+  static const int rider_target = getenv("AMT_RIDER_TARGET") ? atoi(getenv("AMT_RIDER_TARGET")) : 224;
+  const int n_rider_wgs = wgrad_group_prepare(dt, riders, n_riders, sink, &rg, &rfl, &rby, rider_target);
   if (sink->dry) return;
   a.rec = sink->ws + o;
   a.rec_stride = rec;

@@ -345,7 +345,7 @@ void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a_in, PartialSink* 
 // while planning).  One-tile problems with a very long token axis ("skinny", C <= 32 blocks) get many
 // short splits that write per-split records into the sink instead of atomics.
 int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* sink, WgradGroup* gp, double* flops,
-                        double* bytes) {
+                        double* bytes, int target_override) {
   WgradGroup& g = *gp;
   memset(&g, 0, sizeof(g));
   if (n <= 0) return 0;
@@ -383,7 +383,8 @@ int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* si
     // few token splits: every split adds M*Kp*4 bytes of fp32 atomics and the chip-wide atomic rate
     // (~1.3 TB/s) was the bound at 1536 workgroups (38 us per layer group vs 24 us at ~224)
     static const int target_wgs = getenv("AMT_WGRAD_TARGET_WGS") ? atoi(getenv("AMT_WGRAD_TARGET_WGS")) : 336;
-    int splits = (target_wgs + total_tiles - 1) / total_tiles;
+    const int tgt = target_override > 0 ? target_override : target_wgs;
+    int splits = (tgt + total_tiles - 1) / total_tiles;
     int max_splits = (a.N + 127) / 128;
     if (splits > max_splits) splits = max_splits;
     if (splits > 48) splits = 48;

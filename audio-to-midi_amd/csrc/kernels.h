@@ -59,8 +59,10 @@ void gemm_tn_wgrad_group(hipStream_t s, DType dt, const WgradArgs* probs, int n,
 // fills the group (one-tile / long-N problems get per-split records from `sink`); returns the number of
 // workgroups, 0 while planning.  Used by gemm_tn_wgrad_group and by chain kernels that carry the
 // previous scope's weight gradients in extra workgroups of their own launch.
+// target_override > 0: aim for about that many workgroups instead of the default (a carrier whose own workgroups
+// leave compute units free asks for as many riders as there are free units).
 int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* sink, WgradGroup* g, double* flops = nullptr,
-                        double* bytes = nullptr);
+                        double* bytes = nullptr, int target_override = 0);
 
 // ----------------------------------------------------------------------------- per-block partial sums
 // Row kernels that produce parameter gradients (LayerNorm w/b, depthwise conv w/b, gamma) can write
