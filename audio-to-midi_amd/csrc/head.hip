@@ -98,20 +98,21 @@ void dropout_apply(hipStream_t s, DType dt, const void* X, void* Y, size_t n, ui
                        thr, inv_keep);
 }
 
-__global__ void grads_finalize_kernel(float* __restrict__ g, size_t n, float mul, int* __restrict__ flag) {
+__global__ void grads_finalize_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n, float mul,
+                                      int* __restrict__ flag) {
   bool bad = false;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    float v = g[i] * mul;
-    g[i] = v;
+    float v = src[i] * mul;
+    dst[i] = v;
     bad |= !isfinite(v);
   }
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicAnd(flag, 0);
 }
 
-void grads_finalize(hipStream_t s, float* g, size_t n, float mul, int* valid_flag) {
+void grads_finalize(hipStream_t s, const float* src, float* dst, size_t n, float mul, int* valid_flag) {
   int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   ProfScope ps(s, "grads_finalize", 0, 8.0 * n);
-  hipLaunchKernelGGL(grads_finalize_kernel, dim3(grid), dim3(256), 0, s, g, n, mul, valid_flag);
+  hipLaunchKernelGGL(grads_finalize_kernel, dim3(grid), dim3(256), 0, s, src, dst, n, mul, valid_flag);
 }
 
 __global__ void fill_kernel(float* p, float v, size_t n) {

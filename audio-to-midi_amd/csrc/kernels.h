@@ -272,7 +272,8 @@ void bce_loss(hipStream_t s, DType dt, const float* logits_pad, int ldl, const f
 void dropout_apply(hipStream_t s, DType dt, const void* X, void* Y, size_t n, uint64_t seed, uint32_t stream,
                    uint32_t drop_thresh24, float inv_keep);
 // g[i] *= mul ; flag[0] = 0 if any non-finite
-void grads_finalize(hipStream_t s, float* g, size_t n, float mul, int* valid_flag);
+// dst[i] = src[i] * mul, AND-ing `valid_flag` with "all finite" (src == dst allowed)
+void grads_finalize(hipStream_t s, const float* src, float* dst, size_t n, float mul, int* valid_flag);
 void convert_f32(hipStream_t s, DType dt, const float* src, void* dst, size_t n);
 // dst[c][r] = src[r][c]   (src [R x C] fp32 -> dst [C x R] T)
 void convert_transpose(hipStream_t s, DType dt, const float* src, void* dst, int R, int C);

@@ -233,8 +233,14 @@ def main():
     audio_np, labels_np = amt.synth.make_batch_fast(B_PER_GPU, T_SAMPLES, seed=100 + rank)
     audio = torch.from_numpy(audio_np).to(dev, torch.bfloat16)       # inputs resident in HBM
     labels = torch.from_numpy(labels_np).to(dev)
-    grads = torch.zeros(model.n_params + 2, dtype=torch.float32, device=dev)   # tail: loss, valid flag
-    gflat = grads[: model.n_params]
+    # One flat fp32 bucket: [finite flag of the whole step, 3 pad | gradients (amt layout) | loss, finite flag of the
+    # first half].  The four head floats keep the gradient range 16-byte aligned.  With N > 1 the bucket is
+    # all-reduced with ReduceOp.AVG (mean over the global batch, train.py:62; a flag stays 1.0 iff every rank's is 1).
+    HEAD = 4
+    n = model.n_params
+    bucket = torch.zeros(HEAD + n + 2, dtype=torch.float32, device=dev)
+    gflat = bucket[HEAD: HEAD + n]
+    head, tail = bucket[:HEAD], bucket[HEAD + n:]
     loss_buf = torch.zeros(2, dtype=torch.float32, device=dev)
     step_no = [0]
 
@@ -244,14 +250,16 @@ def main():
         loss, _, valid, _ = model.loss_and_grads(audio, labels, scale=1.0, seed=seed, train=True, grads_out=gflat,
                                                  sync=False)
         last["loss"], last["valid"] = loss, valid      # device tensors (static addresses under hipGraph replay)
-        if world > 1:                                  # the bucket's tail carries loss + finite flag through the all-reduce
-            grads[model.n_params] = loss[0]
-            grads[model.n_params + 1] = valid[0].to(torch.float32)
+        if world > 1:                                  # loss + finite flag travel with the gradients
+            tail[0] = loss[0]
+            tail[1] = valid[0].to(torch.float32)
+            head[0] = tail[1]
 
     # N > 1: the step runs in two halves (include/amt.h: amt_forward_backward_phase).  The gradients of the
     # decoder + transformer + final CNN norm (37 of the 46 MB) are complete after the first half and their
-    # all-reduce runs on a side stream while the CNN stages are still in their backward pass; the CNN
-    # bucket and the two scalars (loss, finite flag) follow.  Per-GPU work is identical to the one-call step.
+    # all-reduce (with the loss and the first half's finite flag behind them) runs on a side stream while the CNN
+    # stages are still in their backward pass; the CNN range, preceded by the whole step's finite flag, follows:
+    # two collectives per step.  Per-GPU work is identical to the one-call step.
     overlap = (world > 1 and not args.no_overlap) or args.force_overlap
     if overlap and dist is None:
         import torch.distributed as dist
@@ -260,10 +268,14 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     split = model.grad_bucket_split() if overlap else 0
     valid_buf = torch.ones(1, dtype=torch.int32, device=dev)
-    tail = grads[model.n_params:]
 
     def half(phase, seed):
         model.loss_and_grads_phase(phase, audio, labels, gflat, loss_buf, valid_buf, scale=1.0, seed=seed, train=True)
+        if phase == 1:      # captured with the half: no eager launches between the graphs and the collectives
+            tail[0] = loss_buf[0]
+            tail[1] = valid_buf[0].to(torch.float32)
+        else:
+            head[0] = valid_buf[0].to(torch.float32)
 
     # every allocation happens before graph capture: optimizer state, then the workspace plan
     if not args.no_optimizer:
@@ -290,6 +302,7 @@ def main():
             with torch.cuda.graph(graph):
                 fwd_bwd(12345)
     comm = torch.cuda.Stream(device=dev)
+    avg = dist.ReduceOp.AVG if dist is not None else None
 
     def one_step():
         step_no[0] += 1
@@ -299,24 +312,18 @@ def main():
             else: half(1, step_no[0])
             comm.wait_stream(main)
             with torch.cuda.stream(comm):
-                dist.all_reduce(grads[split:model.n_params], op=dist.ReduceOp.SUM)       # transformer + decoder bucket
+                dist.all_reduce(bucket[HEAD + split:], op=avg)      # transformer + decoder range, loss, first flag
             if graph_b is not None: graph_b.replay()
             else: half(2, step_no[0])
-            tail[0] = loss_buf[0]
-            tail[1] = valid_buf[0].to(torch.float32)
-            dist.all_reduce(grads[:split], op=dist.ReduceOp.SUM)                           # CNN bucket
-            dist.all_reduce(tail, op=dist.ReduceOp.SUM)                                    # loss, finite flag
+            dist.all_reduce(bucket[:HEAD + split], op=avg)           # whole-step flag + CNN range
             main.wait_stream(comm)
-            if world > 1:
-                grads.mul_(1.0 / world)
         else:
             if graph is not None:
                 graph.replay()
             else:
                 fwd_bwd(step_no[0])
             if world > 1:
-                dist.all_reduce(grads, op=dist.ReduceOp.SUM)        # ONE bucket: grads + loss + finite flag
-                grads.mul_(1.0 / world)                              # mean over the global batch (train.py:62)
+                dist.all_reduce(bucket, op=avg)                      # ONE bucket: flag, gradients, loss, flag
         if not args.no_optimizer:
             model.adamw_step(gflat, lr_base=1e-4, step=step_no[0])
 
@@ -403,7 +410,7 @@ def main():
                                    + ("" if args.no_optimizer else ", AdamW + global-norm clip + bf16 weight refresh"),
                        "global_batch": world * B_PER_GPU, "clip_seconds": CLIP_SECONDS, "frames": T_SAMPLES // 320,
                        "parallelism": f"dp{world}", "hipgraph": (graph is not None) or (graph_a is not None),
-                       "grad_allreduce": ("two buckets, first overlapped with the CNN backward" if overlap else "one bucket") if world > 1 or overlap else None,
+                       "grad_allreduce": ("two collectives (ReduceOp.AVG), the first overlapped with the CNN backward" if overlap else "one bucket (ReduceOp.AVG)") if world > 1 or overlap else None,
                        "weights": "random init (Equinox distributions), 11606230 params"},
             "model_tflops": round(world * FLOPS_PER_STEP / (elapsed / args.steps) / 1e12, 2),
             "loss": round(loss_val, 3),

@@ -270,7 +270,7 @@ def test_hipgraph_replay_reproduces_the_eager_step(small_conf):
 def test_two_phase_step_equals_one_call(small_conf):
     """amt_forward_backward_phase 1 + 2 (the data-parallel overlap form) issues the launches of
     amt_forward_backward: same loss, same gradients; after phase 1 alone the decoder / transformer /
-    final-norm range is already final and the CNN range still zero."""
+    final-norm range is already final and the CNN range of the caller's buffer has not been touched."""
     model = amt.OutputSequenceGenerator(small_conf, key=4, dtype="bfloat16", gamma=1.0)
     audio, labels = synth.make_batch(3, 320 * 90, seed=6)
     a = torch.from_numpy(audio).to("cuda", torch.bfloat16)
@@ -283,7 +283,7 @@ def test_two_phase_step_equals_one_call(small_conf):
     valid = torch.zeros(1, dtype=torch.int32, device="cuda")
     model.loss_and_grads_phase(1, a, y, g, loss, valid, seed=11, train=True)
     torch.cuda.synchronize()
-    assert float(g[:split].abs().max()) == 0.0
+    assert float((g[:split] - 3.0).abs().max()) == 0.0       # phase 2 writes this range
     assert float((g[split:] - ref.grads_flat[split:]).norm() / ref.grads_flat[split:].norm()) < 1e-5
     assert abs(float(loss[0]) - ref.loss) <= 1e-6 * abs(ref.loss) and int(valid.item()) == 1
     model.loss_and_grads_phase(2, a, y, g, loss, valid, seed=11, train=True)
