@@ -120,7 +120,9 @@ int32_t amt_forward_backward(amt_ctx* ctx, const void* audio, const float* label
  *             stream order) grads_flat[amt_grad_bucket_split(ctx) ..) is complete, unscaled and checked;
  *   phase 2 = backward of the CNN stages: completes grads_flat[0 .. split).
  * Same arguments in both calls; loss_out / logits are written by phase 1, grads_valid is AND-ed by both.
- * Phase 1 followed by phase 2 issues exactly the launches of amt_forward_backward. */
+ * Phase 1 followed by phase 2 computes what amt_forward_backward computes (same kernels; the weight gradients of the
+ * first transformer layer run as their own launch at the end of phase 1 instead of riding on a phase-2 launch).
+ * Neither phase touches the part of grads_flat that belongs to the other. */
 int32_t amt_forward_backward_phase(amt_ctx* ctx, const void* audio, const float* labels, int32_t B, int32_t T,
                                    float scale, uint64_t seed, int32_t train, float* loss_out, float* grads_flat,
                                    int32_t* grads_valid, float* logits, int32_t phase, void* stream);
