@@ -341,3 +341,41 @@ def test_fp8_attention_step_stays_close_to_the_bf16_step():
     f32m = amt.OutputSequenceGenerator(np_model.MODEL_CONFIG, key=1, dtype="float32", gamma=1.0)
     with pytest.raises(RuntimeError):
         f32m.set_attn_fp8(True)
+
+
+def test_gradient_buffer_alignment_and_fp8_under_graph_replay(small_conf):
+    """(1) The caller's gradient pointer may have any 4-byte alignment: the library accumulates in its own aligned
+    buffer and the last pass writes the caller's (csrc/model.hip: run_backward), so shifted views give the same
+    gradients.  (2) The fp8 attention switch works inside a captured step: the |max| roll is a kernel of the step,
+    so replays keep updating the delayed scales and stay finite and close to the eager fp8 step."""
+    model = amt.OutputSequenceGenerator(small_conf, key=4, dtype="bfloat16", gamma=1.0)
+    audio, labels = synth.make_batch(2, 320 * 64, seed=8)
+    a = torch.from_numpy(audio).to("cuda", torch.bfloat16)
+    y = torch.from_numpy(labels).cuda()
+    ref = model.loss_and_grads(a, y, seed=5, train=True)
+    big = torch.zeros(model.n_params + 8, dtype=torch.float32, device="cuda")
+    for off in (1, 4, 7):
+        big.zero_()
+        view = big[off: off + model.n_params]
+        out = model.loss_and_grads(a, y, seed=5, train=True, grads_out=view)
+        assert float((out.grads_flat - ref.grads_flat).norm() / ref.grads_flat.norm()) < 1e-5, off
+        assert float(big[:off].abs().max()) == 0.0 and float(big[off + model.n_params:].abs().max()) == 0.0
+
+    model.set_attn_fp8(True)
+    eager = model.loss_and_grads(a, y, seed=5, train=True)
+    assert eager.grads_valid
+    g = torch.zeros(model.n_params, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        model.loss_and_grads(a, y, seed=5, train=True, grads_out=g, sync=False)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        model.loss_and_grads(a, y, seed=5, train=True, grads_out=g, sync=False)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(g).all())
+    assert float((g - eager.grads_flat).norm() / eager.grads_flat.norm()) < 2e-2
+    assert float((g - ref.grads_flat).norm() / ref.grads_flat.norm()) < 5e-2
