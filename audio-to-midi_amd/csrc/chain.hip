@@ -566,7 +566,12 @@ void block_bwd_fused(hipStream_t s, DType dt, const BlockBwdArgs& a_in, float* d
 // ------------------------------------------------------------------ transformer layer, second half, forward
 // One workgroup per tile of TT tokens; all 256 hidden features of a token stay in the workgroup, so
 // the LayerNorm between the output projection and the FFN is a row pass over an LDS panel.
+// (backward chains: 16-token tiles with bf16 gave wrong gradients in an experiment - not investigated; 32 / 16 are the
+// tested pairs)
 template <typename T> struct FfnTile { static constexpr int TT = sizeof(T) == 2 ? 32 : 16; };
+// forward chains: 16-token tiles for both dtypes (250 instead of 125 workgroups at cfg2: qkv_fwd_fused 11.4 -> 10.1 us,
+// attn_out_fused 8.8 -> 8.0 us); the backward chains keep 32 (they are bound by their riders, profiles/r01_notes.md)
+template <typename T> struct FfnTileFwd { static constexpr int TT = 16; };
 
 // FULL = false stops after the LayerNorm (h, hn, mean, rstd written): the production form.  The full
 // chain streams 896 KiB of weights through every compute unit (~28 B/clk L2-hit rate per CU, less for
@@ -731,7 +736,7 @@ __global__ __launch_bounds__(256) void ffn_fwd_fused_kernel(FfnFwdArgs a) {
 
 template <typename T, bool FULL>
 static void ffn_fwd_fused_launch(hipStream_t s, const FfnFwdArgs& a) {
-  constexpr int TT = FfnTile<T>::TT;
+  constexpr int TT = FfnTileFwd<T>::TT;
   constexpr size_t lds = sizeof(T) * (size_t)TT * (3 * (256 + 8) + (FULL ? 512 + 8 : 0));
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool once = (lds > 64 * 1024
@@ -834,7 +839,7 @@ __global__ __launch_bounds__(256) void qkv_fwd_fused_kernel(QkvFwdArgs a) {
 
 template <typename T>
 static void qkv_fwd_fused_launch(hipStream_t s, const QkvFwdArgs& a) {
-  constexpr int TT = FfnTile<T>::TT;
+  constexpr int TT = FfnTileFwd<T>::TT;
   constexpr size_t lds = sizeof(T) * (size_t)TT * ((256 + 8) + (320 + 8) + (512 + 8));
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool once = (lds > 64 * 1024
