@@ -734,9 +734,8 @@ __global__ __launch_bounds__(256) void ffn_fwd_fused_kernel(FfnFwdArgs a) {
   AMT_STAMP_RT(7);
 }
 
-template <typename T, bool FULL>
-static void ffn_fwd_fused_launch(hipStream_t s, const FfnFwdArgs& a) {
-  constexpr int TT = FfnTileFwd<T>::TT;
+template <typename T, bool FULL, int TT>
+static void ffn_fwd_fused_launch_tt(hipStream_t s, const FfnFwdArgs& a) {
   constexpr size_t lds = sizeof(T) * (size_t)TT * (3 * (256 + 8) + (FULL ? 512 + 8 : 0));
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool once = (lds > 64 * 1024
@@ -746,6 +745,13 @@ static void ffn_fwd_fused_launch(hipStream_t s, const FfnFwdArgs& a) {
                       true);
   (void)once;
   hipLaunchKernelGGL((ffn_fwd_fused_kernel<T, TT, FULL>), dim3((a.N + TT - 1) / TT), dim3(256), lds, s, a);
+}
+// 16-token tiles while they are what fills the chip (N < 8192 tokens: cfg2), the longer tile of the backward chains
+// above that (weights are streamed once per tile)
+template <typename T, bool FULL>
+static void ffn_fwd_fused_launch(hipStream_t s, const FfnFwdArgs& a) {
+  if (a.N < 8192) ffn_fwd_fused_launch_tt<T, FULL, FfnTileFwd<T>::TT>(s, a);
+  else ffn_fwd_fused_launch_tt<T, FULL, FfnTile<T>::TT>(s, a);
 }
 
 void ffn_fwd_fused(hipStream_t s, DType dt, const FfnFwdArgs& a) {
@@ -837,9 +843,8 @@ __global__ __launch_bounds__(256) void qkv_fwd_fused_kernel(QkvFwdArgs a) {
   AMT_STAMP_RT(7);
 }
 
-template <typename T>
-static void qkv_fwd_fused_launch(hipStream_t s, const QkvFwdArgs& a) {
-  constexpr int TT = FfnTileFwd<T>::TT;
+template <typename T, int TT>
+static void qkv_fwd_fused_launch_tt(hipStream_t s, const QkvFwdArgs& a) {
   constexpr size_t lds = sizeof(T) * (size_t)TT * ((256 + 8) + (320 + 8) + (512 + 8));
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool once = (lds > 64 * 1024
@@ -849,6 +854,11 @@ static void qkv_fwd_fused_launch(hipStream_t s, const QkvFwdArgs& a) {
                       true);
   (void)once;
   hipLaunchKernelGGL((qkv_fwd_fused_kernel<T, TT>), dim3((a.N + TT - 1) / TT), dim3(256), lds, s, a);
+}
+template <typename T>
+static void qkv_fwd_fused_launch(hipStream_t s, const QkvFwdArgs& a) {
+  if (a.N < 8192) qkv_fwd_fused_launch_tt<T, FfnTileFwd<T>::TT>(s, a);
+  else qkv_fwd_fused_launch_tt<T, FfnTile<T>::TT>(s, a);
 }
 
 void qkv_fwd_fused(hipStream_t s, DType dt, const QkvFwdArgs& a) {
