@@ -184,14 +184,16 @@ void convert_transpose(hipStream_t s, DType dt, const float* src, void* dst, int
 }
 
 // One launch converts every GEMM weight of the model: descriptor d covers tiles
-// [tile_prefix[d], tile_prefix[d+1]) of 32x32 elements of its [rows x cols] destination.
+// [tile_prefix[d], tile_prefix[d+1]) of 32 x 64 elements of its [rows x cols] destination.
 // dst is [rows][cols]; source is fp32 [src_rows][cols] (plain; rows >= src_rows are zero-filled)
 // or, when transpose != 0, fp32 [cols][rows] with dst[r][c] = src[c][r] (cols >= src_rows zero-filled).
 template <typename T>
 __global__ __launch_bounds__(256) void convert_batch_kernel(const float* __restrict__ src, T* __restrict__ dst,
                                                             const ConvDesc* __restrict__ descs,
                                                             const int* __restrict__ prefix, int n_desc) {
-  __shared__ float tile[32][33];
+  // tile = 32 rows x 64 columns of the destination; a thread converts two adjacent columns (one 4-byte bf16 store:
+  // adjacent even / odd columns are adjacent in the row-major AND in the fragment-packed layout)
+  __shared__ float tile[64][33];
   int t = blockIdx.x;
   int lo = 0, hi = n_desc - 1;
   while (lo < hi) {
@@ -200,8 +202,8 @@ __global__ __launch_bounds__(256) void convert_batch_kernel(const float* __restr
   }
   const ConvDesc d = descs[lo];
   int lt = t - prefix[lo];
-  int tiles_c = (d.cols + 31) / 32;
-  int r0 = (lt / tiles_c) * 32, c0 = (lt % tiles_c) * 32;
+  int tiles_c = (d.cols + 63) / 64;
+  int r0 = (lt / tiles_c) * 32, c0 = (lt % tiles_c) * 64;
   const float* sp = src + d.src_off;
   T* dp = dst + d.dst_off;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -210,25 +212,42 @@ __global__ __launch_bounds__(256) void convert_batch_kernel(const float* __restr
     if (!d.pack) return (size_t)r * d.cols + c;
     return ((size_t)(r >> 4) * ksteps + (c >> 5)) * 512 + (size_t)((((c & 31) >> 3) << 4) + (r & 15)) * 8 + (c & 7);
   };
+  auto put2 = [&](int r, int c, float v0, float v1) {      // columns c (even), c + 1
+    if (r >= d.rows || c >= d.cols) return;
+    if (c + 1 < d.cols && (d.cols & 1) == 0) {
+      T pr[2] = {from_f<T>(v0), from_f<T>(v1)};
+      if constexpr (sizeof(T) == 2) *reinterpret_cast<uint32_t*>(dp + didx(r, c)) = *reinterpret_cast<const uint32_t*>(pr);
+      else { dp[didx(r, c)] = pr[0]; dp[didx(r, c + 1)] = pr[1]; }
+    } else {
+      dp[didx(r, c)] = from_f<T>(v0);
+      if (c + 1 < d.cols) dp[didx(r, c + 1)] = from_f<T>(v1);
+    }
+  };
   if (!d.transpose) {
     for (int i = ty; i < 32; i += 8) {
-      int r = r0 + i, c = c0 + tx;
-      if (r < d.rows && c < d.cols) dp[didx(r, c)] = from_f<T>(r < d.src_rows ? sp[(size_t)r * d.cols + c] : 0.f);
+      const int r = r0 + i, c = c0 + 2 * tx;
+      float v0 = 0.f, v1 = 0.f;
+      if (r < d.src_rows && r < d.rows) {
+        if (c < d.cols) v0 = sp[(size_t)r * d.cols + c];
+        if (c + 1 < d.cols) v1 = sp[(size_t)r * d.cols + c + 1];
+      }
+      put2(r, c, v0, v1);
     }
   } else {
     // src is [src_rows(valid cols of dst)][rows]
-    for (int i = ty; i < 32; i += 8) {
+    for (int i = ty; i < 64; i += 8) {
       int c = c0 + i, r = r0 + tx;     // read src[c][r], coalesced over r
       tile[i][tx] = (c < d.src_rows && c < d.cols && r < d.rows) ? sp[(size_t)c * d.rows + r] : 0.f;
     }
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
-      int r = r0 + i, c = c0 + tx;
-      if (r < d.rows && c < d.cols) {
-        float v = tile[tx][i];
-        if (d.scale_off >= 0) v *= src[d.scale_off + c];
-        dp[didx(r, c)] = from_f<T>(v);
+      const int r = r0 + i, c = c0 + 2 * tx;
+      float v0 = tile[2 * tx][i], v1 = tile[2 * tx + 1][i];
+      if (d.scale_off >= 0) {
+        if (c < d.cols) v0 *= src[d.scale_off + c];
+        if (c + 1 < d.cols) v1 *= src[d.scale_off + c + 1];
       }
+      put2(r, c, v0, v1);
     }
   }
 }

@@ -1174,7 +1174,7 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   }
   std::vector<int> prefix(L.conv.size() + 1, 0);
   for (size_t i = 0; i < L.conv.size(); ++i)
-    prefix[i + 1] = prefix[i] + ((L.conv[i].rows + 31) / 32) * ((L.conv[i].cols + 31) / 32);
+    prefix[i + 1] = prefix[i] + ((L.conv[i].rows + 31) / 32) * ((L.conv[i].cols + 63) / 64);   // head.hip: convert_batch_kernel tiles
   c->conv_tiles = prefix.back();
   if ((he = hipMalloc(&c->conv_dev, L.conv.size() * sizeof(ConvDesc))) != hipSuccess) return fail("hipMalloc", he);
   if ((he = hipMalloc(&c->conv_prefix_dev, prefix.size() * sizeof(int))) != hipSuccess) return fail("hipMalloc", he);
