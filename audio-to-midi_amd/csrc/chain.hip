@@ -6,15 +6,21 @@
 // Every tensor the backward pass reads is written exactly as the unfused launch sequence
 // (dwln_fwd, gemm_nt<gelu>, gemm_nt<scale_resid>) writes it, with the same roundings and the same
 // accumulation order, so both paths agree bit for bit (tests/test_model_gpu.py).
+#include <hip/hip_runtime.h>
+// Phase timestamps for the micro-benchmark (scratch/chain_bench.hip): compiled out of the library.
+#ifdef AMT_CHAIN_TIMING
+__device__ unsigned long long amt_stamps[128][256][8];   // [launch slot][workgroup][phase]
+// rider workgroups (wgrad.h: tn_body) stamp cycle counts into slot 127, indexed by blockIdx.x % 256 (last launch wins)
+#define AMT_WG_STAMP(k) do { if (threadIdx.x == 0) amt_stamps[127][blockIdx.x & 255][k] = __builtin_readcyclecounter(); } while (0)
+#define AMT_WG_NOTE(k, v) do { if (threadIdx.x == 0) amt_stamps[127][blockIdx.x & 255][k] = (unsigned long long)(v) + 1; } while (0)
+#endif
 #include "chain.h"
 #include "kernels.h"
 #include "prof.h"
 #include "rowops.h"
 #include "wgrad.h"
 
-// Phase timestamps for the micro-benchmark (scratch/chain_bench.hip): compiled out of the library.
 #ifdef AMT_CHAIN_TIMING
-__device__ unsigned long long amt_stamps[128][256][8];   // [launch slot][workgroup][phase]
 #define AMT_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) amt_stamps[a.dbg_slot & 127][blockIdx.x][k] = __builtin_readcyclecounter(); } while (0)
 #define AMT_STAMP_RT(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) amt_stamps[a.dbg_slot & 127][blockIdx.x][k] = wall_clock64(); } while (0)
 extern "C" int amt_debug_read_stamps(unsigned long long* out) {   // [128][256][8]; slots 6, 7 = 100 MHz real-time clock

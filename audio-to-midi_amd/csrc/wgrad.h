@@ -4,6 +4,11 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef AMT_WG_STAMP
+#define AMT_WG_STAMP(k) do { } while (0)
+#define AMT_WG_NOTE(k, v) do { } while (0)
+#endif
+
 namespace amt {
 
 // dW[m][k] += sum_n G[n][m] A[n][k].  Tokens are the MFMA K axis, so both operands are read as
@@ -79,11 +84,15 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
   };
 
   const int nsteps = (nend - nbeg + TOK - 1) / TOK;
+  AMT_WG_STAMP(0);
+  AMT_WG_NOTE(6, nsteps);
+  AMT_WG_NOTE(7, a.M * 1000 + a.Kp);
   if (nsteps > 0) load_tiles(nbeg);
   for (int st = 0; st < nsteps; ++st) {
     __syncthreads();                 // previous stage fully consumed
     store_tiles();
     __syncthreads();
+    if (st == 0) AMT_WG_STAMP(1);
     if (st + 1 < nsteps) load_tiles(nbeg + (st + 1) * TOK);
 #pragma unroll
     for (int kk = 0; kk < TOK / 32; ++kk) {
@@ -99,6 +108,7 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
     }
   }
 
+  AMT_WG_STAMP(2);
   // acc[i][j][e] = dW[m0 + wm*32 + i*16 + 4g + e][k0 + wk*32 + j*16 + r]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -117,6 +127,11 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
       }
     }
 
+  AMT_WG_STAMP(3);
+#ifdef AMT_CHAIN_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  AMT_WG_STAMP(4);
+#endif
   if (do_bias) {
     __syncthreads();
 #pragma unroll
