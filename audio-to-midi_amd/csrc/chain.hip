@@ -9,7 +9,7 @@
 #include <hip/hip_runtime.h>
 // Phase timestamps for the micro-benchmark (scratch/chain_bench.hip): compiled out of the library.
 #ifdef AMT_CHAIN_TIMING
-__device__ unsigned long long amt_stamps[128][256][8];   // [launch slot][workgroup][phase]
+__device__ unsigned long long amt_stamps[128][256][12];   // [launch slot][workgroup][phase]; 8 / 9: team barrier entered / left (100 MHz clock)
 // rider workgroups (wgrad.h: tn_body) stamp cycle counts into slot 127, indexed by blockIdx.x % 256 (last launch wins)
 #define AMT_WG_STAMP(k) do { if (threadIdx.x == 0) amt_stamps[127][blockIdx.x & 255][k] = __builtin_readcyclecounter(); } while (0)
 #define AMT_WG_NOTE(k, v) do { if (threadIdx.x == 0) amt_stamps[127][blockIdx.x & 255][k] = (unsigned long long)(v) + 1; } while (0)
@@ -18,15 +18,18 @@ __device__ unsigned long long amt_stamps[128][256][8];   // [launch slot][workgr
 #include "kernels.h"
 #include "prof.h"
 #include "rowops.h"
+#include "team.h"
 #include "wgrad.h"
 
 #ifdef AMT_CHAIN_TIMING
 #define AMT_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) amt_stamps[a.dbg_slot & 127][blockIdx.x][k] = __builtin_readcyclecounter(); } while (0)
 #define AMT_STAMP_RT(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) amt_stamps[a.dbg_slot & 127][blockIdx.x][k] = wall_clock64(); } while (0)
-extern "C" int amt_debug_read_stamps(unsigned long long* out) {   // [128][256][8]; slots 6, 7 = 100 MHz real-time clock
+extern "C" int amt_debug_read_stamps(unsigned long long* out) {   // [128][256][10]; slots 6 - 9 = 100 MHz real-time clock
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(amt_stamps), sizeof(amt_stamps));
 }
+#define AMT_DBG_IF(bit) if (!(a.dbg_slot & (bit)))   // timing experiments: switch a piece of the tile body off (wrong results)
 #else
+#define AMT_DBG_IF(bit)
 #define AMT_STAMP(k) do { } while (0)
 #define AMT_STAMP_RT(k) do { } while (0)
 #endif
@@ -67,15 +70,26 @@ template <int C> struct BlockTile {   // tokens per workgroup (bf16); chosen for
 
 // SAVE = false (inference): nothing but y leaves the workgroup and the tile is 2-4x longer, so the
 // weights are streamed once per 64-512 tokens instead of once per 16-128.
-template <typename T, int C, int TT, bool SAVE>
-__global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
+// One tile of TT rows starting at global row n0; rows >= Nlim are padding (Nlim = B * L for the one-launch-per-Block
+// form, the end of the tile's clip for the team form, whose tiles never straddle clips).  TEAM: X was written by
+// another workgroup of this XCD team earlier in the same launch, so it is read with sc1 loads (team.h).
+template <typename T, int C, int TT, bool SAVE, bool TEAM>
+AMT_DEV void block_fwd_tile(const BlockFwdArgs& a_in, const long n0, const long Nlim, unsigned char* chain_smem) {
+  // Every tensor is in global memory.  The one-launch-per-Block kernel knows that from its kernel arguments; in the team
+  // form the pointers come out of LDS, and as generic pointers they would turn every access into a flat_* instruction
+  // (which also counts in lgkmcnt: each LDS wait would then wait for the tile's fire-and-forget stores too).
+  BlockFwdArgs a = a_in;
+  a.X = team_global(a_in.X); a.wdw = team_global(a_in.wdw); a.bdw = team_global(a_in.bdw); a.lnw = team_global(a_in.lnw);
+  a.lnb = team_global(a_in.lnb); a.W1 = team_global(a_in.W1); a.b1 = team_global(a_in.b1); a.W2 = team_global(a_in.W2);
+  a.b2 = team_global(a_in.b2); a.gamma = team_global(a_in.gamma); a.LN = team_global(a_in.LN); a.mean = team_global(a_in.mean);
+  a.rstd = team_global(a_in.rstd); a.U = team_global(a_in.U); a.Hh = team_global(a_in.Hh); a.Z = team_global(a_in.Z);
+  a.Y = team_global(a_in.Y);
   constexpr int H2 = 2 * C, LDX = C + 8, LDH = H2 + 8;
   constexpr int LPR = C / 8, RPP = 256 / LPR;   // lanes per row, rows per pass of the row phase
   static_assert(TT % RPP == 0, "row phase covers the tile in whole passes");
   using S1 = ChainSplit<H2, TT>;
   using S2 = ChainSplit<C, TT>;
   constexpr int KC1 = ChainChunk<T, S1::RB, C>::KC, KC2 = ChainChunk<T, S2::RB, H2>::KC;
-  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
   T* Xs = reinterpret_cast<T*>(chain_smem);            // [TT][LDX]  LN output
   T* Rs = Xs + TT * LDX;                               // [TT][LDX]  block input (residual)
   T* Hs = Rs + TT * LDX;                               // [TT][LDH]  gelu(u)
@@ -83,23 +97,27 @@ __global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const long N = (long)a.B * a.L;
-  const long n0 = (long)blockIdx.x * TT;
+  const long N = Nlim;
   const T* X = reinterpret_cast<const T*>(a.X);
+  const __amdgpu_buffer_rsrc_t xrs = team_rsrc(a.X);
   const T* W1 = reinterpret_cast<const T*>(a.W1);
   const T* W2 = reinterpret_cast<const T*>(a.W2);
   const int m1 = (wave % S1::WF) * S1::RB * 16, t1 = (wave / S1::WF) * S1::NT * 16;
   const int m2 = (wave % S2::WF) * S2::RB * 16, t2 = (wave / S2::WF) * S2::NT * 16;
 
-  AMT_STAMP_RT(6);
-  AMT_STAMP(0);
+#ifdef AMT_CHAIN_TIMING
+  // tile-start stamps are parked in LDS and written out at the end of the tile: no vector-memory instruction at the start
+  __shared__ unsigned long long s_dbg_start[2];
+  if (threadIdx.x == 0) { s_dbg_start[0] = wall_clock64(); s_dbg_start[1] = __builtin_readcyclecounter(); }
+#endif
+
   // ---- what depends on nothing is requested first: the stage-1 weights (chunk 0), biases, gamma.
   // Their round trip overlaps the activation loads of the row phase.  The stage-2 weights follow
   // after the row phase (in flight during stage 1): holding both sets across the row phase pushed the
   // kernel past 256 registers = one wave per SIMD, and such launches paid ~6 us more between
   // dependent kernels in the training step (profiles/r01_notes.md).
   Frag<T> wa[KC1][S1::RB], wb[KC2][S2::RB];
-  chain_load_w<T, S1::RB, KC1, C>(wa, W1, m1, 0, lane);
+  AMT_DBG_IF(4096) chain_load_w<T, S1::RB, KC1, C>(wa, W1, m1, 0, lane);
   float bb1[S1::RB][4], bb2[S2::RB][4], gm[S2::RB][4];
 #pragma unroll
   for (int rb = 0; rb < S1::RB; ++rb)
@@ -133,7 +151,7 @@ __global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
       for (int k = 0; k < 7; ++k) {
         int ll = l + k - 3;
         int lc = ll < 0 ? 0 : (ll >= a.L ? a.L - 1 : ll);
-        load8f(X + (rowbase + lc) * C + sub * 8, x[k]);
+        team_load8f<TEAM>(xrs, X, (rowbase + lc) * C + sub * 8, x[k]);
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) d[i] = bv[i];
@@ -160,7 +178,7 @@ __global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
       }
     }
   }
-  chain_load_w<T, S2::RB, KC2, H2>(wb, W2, m2, 0, lane);
+  AMT_DBG_IF(4096) chain_load_w<T, S2::RB, KC2, H2>(wb, W2, m2, 0, lane);
   __syncthreads();
   AMT_STAMP(1);
 
@@ -168,7 +186,7 @@ __global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
   {
     f32x4 acc[S1::RB][S1::NT];
     chain_zero(acc);
-    chain_stage<T, S1::RB, S1::NT, KC1, C>(acc, wa, W1, m1, Xs, LDX, t1, lane);
+    AMT_DBG_IF(4096) chain_stage<T, S1::RB, S1::NT, KC1, C>(acc, wa, W1, m1, Xs, LDX, t1, lane);
     AMT_STAMP(2);
 #pragma unroll
     for (int rb = 0; rb < S1::RB; ++rb) {
@@ -205,7 +223,7 @@ __global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
   {
     f32x4 acc[S2::RB][S2::NT];
     chain_zero(acc);
-    chain_stage<T, S2::RB, S2::NT, KC2, H2>(acc, wb, W2, m2, Hs, LDH, t2, lane);
+    AMT_DBG_IF(4096) chain_stage<T, S2::RB, S2::NT, KC2, H2>(acc, wb, W2, m2, Hs, LDH, t2, lane);
     AMT_STAMP(4);
 #pragma unroll
     for (int rb = 0; rb < S2::RB; ++rb) {
@@ -233,6 +251,134 @@ __global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
   chain_copy_out<T, TT, C, LDX>(Rs, reinterpret_cast<T*>(a.Y), n0, N, tid);
   AMT_STAMP(5);
   AMT_STAMP_RT(7);
+#ifdef AMT_CHAIN_TIMING
+  if (threadIdx.x == 0 && blockIdx.x < 256) { amt_stamps[a.dbg_slot & 127][blockIdx.x][6] = s_dbg_start[0]; amt_stamps[a.dbg_slot & 127][blockIdx.x][0] = s_dbg_start[1]; }
+#endif
+}
+
+template <typename T, int C, int TT, bool SAVE>
+__global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  block_fwd_tile<T, C, TT, SAVE, false>(a, (long)blockIdx.x * TT, (long)a.B * a.L, chain_smem);
+}
+
+// ------------------------------------------------------------------ Block forward, a whole run of Blocks per launch
+// XCD-team form (team.h): the n Blocks of a CNN stage in ONE launch.  Clip b belongs to one XCD's team; Block j of
+// every clip of the team is evaluated tile by tile (the same tile body as above), then the team meets at its barrier:
+// the halo rows of Block j + 1 come from the neighbouring workgroups' stores, which are in the XCD's L2.
+template <typename T, int C, int TT>
+__global__ __launch_bounds__(256) void block_run_fwd_kernel(BlockRunFwdArgs r) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  // The kernel-argument segment lives in HOST memory (HIP default): a scalar load from it is a PCIe round trip.  An
+  // ordinary kernel pays that once, before its first instruction; reading item j at the top of every Block made every
+  // team barrier look 6-7 us long (profiles/r02_notes.md).  So: one cooperative copy of all items into LDS, up front.
+  __shared__ BlockRunFwdItem s_it[BLOCK_RUN_MAX];
+#if defined(__HIP_DEVICE_COMPILE__)
+  {
+    typedef const __attribute__((address_space(4))) unsigned long long* KernArg64;
+    KernArg64 ka = (KernArg64)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int W0 = (int)(offsetof(BlockRunFwdArgs, it) / 8), WPI = (int)(sizeof(BlockRunFwdItem) / 8);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(s_it);
+    for (int i = threadIdx.x; i < r.n * WPI; i += 256) dst[i] = ka[W0 + i];
+  }
+#endif
+#ifdef AMT_CHAIN_TIMING
+  unsigned long long t_left = 0, c_left = 0, c_spin = 0;
+  __shared__ unsigned long long s_dbg_loop;
+#endif
+  __shared__ __attribute__((aligned(16))) unsigned char s_warm[4096];   // landing zone of team_warm, never read
+  constexpr size_t WBYTES = chain_packed_elems(2 * C, C) * sizeof(T);    // == chain_packed_elems(C, 2 * C): W1 and W2
+  const TeamTicket ticket = team_register(r.st);   // (its barrier orders the copy above before the first read below)
+  {   // the first Block's weights, while the other workgroups are still arriving (assumes the usual 8 even teams: speed only)
+    const int guess = (int)gridDim.x / TEAM_MAX > 0 ? (int)gridDim.x / TEAM_MAX : 1;
+    team_warm(team_uniform(s_it[0].W1), WBYTES, ticket.rank % guess, guess, s_warm);
+    team_warm(team_uniform(s_it[0].W2), WBYTES, ticket.rank % guess, guess, s_warm);
+  }
+  Team t = team_assemble(r.st, ticket);
+  if (t.ok) {
+    const int tiles_per_clip = (r.L + TT - 1) / TT;
+#pragma unroll 1
+    for (int j = 0; j < r.n; ++j) {
+      BlockFwdArgs a;
+#ifdef AMT_TEAM_KERNARG_ITEMS   // experiment: items straight from the kernel-argument segment (global_* accesses, host-memory scalar loads)
+      const BlockRunFwdItem it = r.it[j];
+      a.X = j == 0 ? r.X0 : r.it[j - 1].Y;
+      a.wdw = it.wdw; a.bdw = it.bdw; a.lnw = it.lnw; a.lnb = it.lnb; a.W1 = it.W1; a.b1 = it.b1; a.W2 = it.W2; a.b2 = it.b2;
+      a.gamma = it.gamma; a.LN = it.LN; a.mean = it.mean; a.rstd = it.rstd; a.U = it.U; a.Hh = it.Hh; a.Z = it.Z; a.Y = it.Y;
+#else
+      const BlockRunFwdItem& it = s_it[j];
+      a.X = j == 0 ? r.X0 : team_uniform(s_it[j - 1].Y);
+      a.wdw = team_uniform(it.wdw); a.bdw = team_uniform(it.bdw); a.lnw = team_uniform(it.lnw); a.lnb = team_uniform(it.lnb);
+      a.W1 = team_uniform(it.W1); a.b1 = team_uniform(it.b1); a.W2 = team_uniform(it.W2); a.b2 = team_uniform(it.b2);
+      a.gamma = team_uniform(it.gamma); a.LN = team_uniform(it.LN); a.mean = team_uniform(it.mean); a.rstd = team_uniform(it.rstd);
+      a.U = team_uniform(it.U); a.Hh = team_uniform(it.Hh); a.Z = team_uniform(it.Z); a.Y = team_uniform(it.Y);
+#endif
+      a.B = r.B; a.L = r.L; a.C = C; a.dbg_slot = r.dbg_base + j;
+#ifdef AMT_CHAIN_TIMING
+      if (!(r.dbg_base & 8192))
+#endif
+      if (j + 1 < r.n) {   // the next Block's weights depend on nothing: into L2 now, each line requested by one member
+        team_warm(team_uniform(s_it[j + 1].W1), WBYTES, t.rank, t.size, s_warm);
+        team_warm(team_uniform(s_it[j + 1].W2), WBYTES, t.rank, t.size, s_warm);
+      }
+#ifdef AMT_CHAIN_TIMING
+      asm volatile("" :: "s"(a.Y), "s"(a.W1), "s"(a.X) : "memory");
+      const unsigned long long c_items = __builtin_readcyclecounter();   // the LDS reads of this Block's pointers are done
+#endif
+#pragma unroll 1
+      for (int clip = t.index; clip < r.B; clip += t.n_teams)
+#pragma unroll 1
+        for (int tile = t.rank; tile < tiles_per_clip; tile += t.size) {
+          // opaque copies: without them the compiler strength-reduces every address of the tile body over these
+          // two loops (dozens of 64-bit induction pointers in VGPRs: 256 registers + scratch at C = 256)
+          // (the parameter pointers too: hoisting a Block's weight / bias loads out of the tile loop keeps them live
+          // across the whole body)
+          int cl = clip, tl = tile;
+#ifdef AMT_CHAIN_TIMING
+          if (r.dbg_base & 32768) tl = tiles_per_clip - 1 - tile;   // experiment: reversed tile assignment
+          const unsigned long long c_loop = __builtin_readcyclecounter();   // top of the tile loop body
+          if (threadIdx.x == 0 && blockIdx.x < 256) s_dbg_loop = c_loop;
+#endif
+          BlockFwdArgs at = a;
+#ifdef AMT_TEAM_KERNARG_ITEMS
+          asm volatile("" : "+s"(cl), "+s"(tl));
+#else
+          asm volatile("" : "+s"(cl), "+s"(tl), "+s"(at.X), "+s"(at.wdw), "+s"(at.bdw), "+s"(at.lnw), "+s"(at.lnb), "+s"(at.W1),
+                       "+s"(at.b1), "+s"(at.W2), "+s"(at.b2), "+s"(at.gamma));
+#endif
+#ifdef AMT_CHAIN_TIMING
+          if (r.dbg_base & 2048)   // timing experiment only (wrong results): plain loads of X
+            block_fwd_tile<T, C, TT, true, false>(at, (long)cl * r.L + (long)tl * TT, (long)(cl + 1) * r.L, chain_smem);
+          else
+#endif
+          block_fwd_tile<T, C, TT, true, true>(at, (long)cl * r.L + (long)tl * TT, (long)(cl + 1) * r.L, chain_smem);
+#ifdef AMT_CHAIN_TIMING
+          if (threadIdx.x == 0 && blockIdx.x < 256) amt_stamps[a.dbg_slot & 127][blockIdx.x][4] = s_dbg_loop;
+#endif
+          __syncthreads();   // the tile's LDS panels are rewritten by the next tile
+        }
+#ifdef AMT_CHAIN_TIMING
+      if (threadIdx.x == 0 && blockIdx.x < 256) {
+        amt_stamps[a.dbg_slot & 127][blockIdx.x][8] = wall_clock64();
+        amt_stamps[a.dbg_slot & 127][blockIdx.x][11] = c_items;
+        if (j > 0) { amt_stamps[(a.dbg_slot - 1) & 127][blockIdx.x][9] = t_left; amt_stamps[(a.dbg_slot - 1) & 127][blockIdx.x][10] = c_left; if (r.dbg_base & 16384) amt_stamps[(a.dbg_slot - 1) & 127][blockIdx.x][5] = c_spin; }
+      }
+#endif
+      if (j + 1 < r.n && !team_barrier(r.st, t)) break;
+#ifdef AMT_CHAIN_TIMING
+      t_left = wall_clock64();   // stored after the NEXT Block's tiles: no vector-memory instruction between here and the tile
+      c_left = __builtin_readcyclecounter();
+      if (r.dbg_base & 16384) {   // experiment: 2000 s_nop 3 (no memory, no LDS) right after the barrier
+        for (int i = 0; i < 2000; ++i) asm volatile("s_nop 3");
+        c_spin = __builtin_readcyclecounter();
+      }
+#endif
+    }
+  }
+#ifdef AMT_CHAIN_TIMING
+  if (threadIdx.x == 0 && blockIdx.x < 256 && C == 128) amt_stamps[126][blockIdx.x][0] = (unsigned long long)(t.rank | (t.xcc << 8) | (t.size << 16)) + (1ull << 32);
+#endif
+  team_leave(r.st, t);
 }
 
 template <typename T, int C, bool SAVE>
@@ -249,6 +395,91 @@ static void block_fwd_fused_launch(hipStream_t s, const BlockFwdArgs& a) {
   const long N = (long)a.B * a.L;
   const int grid = (int)((N + TT - 1) / TT);
   hipLaunchKernelGGL((block_fwd_fused_kernel<T, C, TT, SAVE>), dim3(grid), dim3(256), lds, s, a);
+}
+
+static int team_grid() {   // one workgroup per compute unit, on the full 8-XCD chip only
+  static int cus = [] {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    if (const char* e = getenv("AMT_TEAM_GRID")) return atoi(e);   // experiments: fewer workgroups than compute units
+    return p.multiProcessorCount;
+  }();
+  return cus;
+}
+
+TeamState* team_state_create() {
+  TeamState* st = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&st), sizeof(TeamState)) != hipSuccess) return nullptr;
+  if (hipMemset(st, 0, sizeof(TeamState)) != hipSuccess) { (void)hipFree(st); return nullptr; }
+  return st;
+}
+
+int team_state_timeout(const TeamState* st) {
+  unsigned v = 0;
+  if (hipMemcpy(&v, reinterpret_cast<const char*>(st) + offsetof(TeamState, timeout), sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  return (int)v;
+}
+
+template <typename T, int C, int TT>
+static void block_run_fwd_launch_tt(hipStream_t s, const BlockRunFwdArgs& r, int grid) {
+  constexpr size_t lds = sizeof(T) * (size_t)TT * (2 * (C + 8) + 2 * (2 * C + 8));
+  static_assert(lds <= 156 * 1024, "LDS budget");
+  static bool once = (lds > 64 * 1024
+                          ? (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block_run_fwd_kernel<T, C, TT>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                          : (void)0,
+                      true);
+  (void)once;
+#ifdef AMT_CHAIN_TIMING
+  BlockRunFwdArgs rr = r;
+  if (const char* e = getenv("AMT_DBG_NOSTORE")) rr.dbg_base |= atoi(e);   // 256: no u/h, 512: no z, 1024: no LN (timing only)
+  hipLaunchKernelGGL((block_run_fwd_kernel<T, C, TT>), dim3(grid), dim3(256), lds, s, rr);
+  return;
+#endif
+  hipLaunchKernelGGL((block_run_fwd_kernel<T, C, TT>), dim3(grid), dim3(256), lds, s, r);
+}
+
+// Tile length of the team form: a clip's rows are shared by the ~grid / 8 workgroups of one XCD, and every tile pays the
+// same latency chain (operand round trip, LayerNorm, two GEMM stages, stores) and streams the Block's weights once.  With
+// the one-launch-per-Block tile (16 rows at C = 128) a 10-s clip has 63 tiles for 32 workgroups: two dependent tiles per
+// Block and workgroup.  Twice the tile = one tile each, half the weight stream per row.  Results do not depend on the tile.
+template <typename T, int C>
+static void block_run_fwd_launch(hipStream_t s, const BlockRunFwdArgs& r, int grid) {
+  constexpr int TT0 = BlockTile<C>::TT;
+  constexpr bool fits2 = sizeof(T) * (size_t)(2 * TT0) * (2 * (C + 8) + 2 * (2 * C + 8)) <= 156 * 1024;
+  const int members = grid / TEAM_MAX > 0 ? grid / TEAM_MAX : 1;
+  const int tiles0 = (r.L + TT0 - 1) / TT0;
+  if constexpr (fits2) {
+    if (tiles0 > members) { block_run_fwd_launch_tt<T, C, 2 * TT0>(s, r, grid); return; }
+  }
+  block_run_fwd_launch_tt<T, C, TT0>(s, r, grid);
+}
+
+bool block_run_fwd(hipStream_t s, DType dt, const BlockRunFwdArgs& r) {
+  const int grid = team_grid();
+  // the team form needs every workgroup resident at once (one per CU) and 32-bit byte offsets into X
+  if (grid < 8 || grid > TEAM_MAX * TEAM_MAX_MEMBERS || r.st == nullptr || r.n < 2 || r.n > BLOCK_RUN_MAX) return false;
+  const double N = (double)r.B * r.L, es = dt == DT_F32 ? 4 : 2;
+  if (N * r.C * es >= 2147483648.0) return false;
+  static const char* const names[] = {"block_run_fwd<16>", "block_run_fwd<32>", "block_run_fwd<64>", "block_run_fwd<128>", "block_run_fwd<256>"};
+  const char* name = r.C == 16 ? names[0] : r.C == 32 ? names[1] : r.C == 64 ? names[2] : r.C == 128 ? names[3] : names[4];
+  ProfScope ps(s, name, r.n * 2.0 * N * (7.0 * r.C + 4.0 * r.C * r.C), r.n * (8.0 * N * r.C + 4.0 * r.C * r.C) * es);
+#define AMT_BR_CASE(CC_)                                                                                       \
+  case CC_:                                                                                                    \
+    if (dt == DT_F32) block_run_fwd_launch<float, CC_>(s, r, grid); else block_run_fwd_launch<bf16, CC_>(s, r, grid);  \
+    return true
+  switch (r.C) {
+    AMT_BR_CASE(16);
+    AMT_BR_CASE(32);
+    AMT_BR_CASE(64);
+    AMT_BR_CASE(128);
+    AMT_BR_CASE(256);
+    default: break;
+  }
+#undef AMT_BR_CASE
+  return false;
 }
 
 void block_fwd_fused(hipStream_t s, DType dt, const BlockFwdArgs& a) {

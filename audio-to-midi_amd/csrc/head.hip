@@ -295,12 +295,23 @@ void reduce_partials(hipStream_t s, const PartDesc* descs_dev, int n_desc, const
 }
 
 // ------------------------------------------------------------------ AdamW
+// The step is gated on DEVICE flags so that it stays graph-capturable and free of host syncs: gate_i = the int32
+// all-finite flag of amt_forward_backward, gate_f = the same flag after a mean / sum-and-scale all-reduce (1.0 iff every
+// rank's flag is 1).  A closed gate leaves parameters, m and v untouched: the skip of train.py:369-377 without the
+// roll-back copy.  NaN compares false, so a poisoned float flag closes the gate too.
+AMT_DEV bool adamw_gate_open(const int* gate_i, const float* gate_f) {
+  if (gate_i != nullptr && gate_i[0] == 0) return false;
+  if (gate_f != nullptr && !(gate_f[0] >= 0.999f)) return false;
+  return true;
+}
 __global__ __launch_bounds__(256) void adamw_compute_kernel(const float* __restrict__ p, const float* __restrict__ g,
                                                             float* __restrict__ m, float* __restrict__ v,
                                                             float* __restrict__ upd, const float* __restrict__ lr_scale,
                                                             size_t n, float lr, float b1, float b2, float eps, float wd,
-                                                            float bc1, float bc2, float* __restrict__ norm2) {
+                                                            float bc1, float bc2, float* __restrict__ norm2,
+                                                            const int* __restrict__ gate_i, const float* __restrict__ gate_f) {
   __shared__ float red[4];
+  if (!adamw_gate_open(gate_i, gate_f)) return;   // non-finite gradients: m, v and the update stay untouched
   float acc = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float gi = g[i];
@@ -321,7 +332,9 @@ __global__ __launch_bounds__(256) void adamw_compute_kernel(const float* __restr
 }
 
 __global__ void adamw_apply_kernel(float* __restrict__ p, const float* __restrict__ upd, size_t n,
-                                   const float* __restrict__ norm2, float clip) {
+                                   const float* __restrict__ norm2, float clip, const int* __restrict__ gate_i,
+                                   const float* __restrict__ gate_f) {
+  if (!adamw_gate_open(gate_i, gate_f)) return;
   float nrm = sqrtf(norm2[0]);
   float f = (clip > 0.f && nrm > clip) ? clip / nrm : 1.f;   // optax.clip_by_global_norm
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -330,15 +343,16 @@ __global__ void adamw_apply_kernel(float* __restrict__ p, const float* __restric
 
 void adamw_compute(hipStream_t s, const float* params, const float* grads, float* m, float* v, float* upd,
                    const float* lr_scale, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
-                   float* norm2) {
+                   float* norm2, const int* gate_i, const float* gate_f) {
   float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
   ProfScope ps(s, "adamw_compute", 0, 28.0 * n);
   hipLaunchKernelGGL(adamw_compute_kernel, dim3(2048), dim3(256), 0, s, params, grads, m, v, upd, lr_scale, n, lr, b1,
-                     b2, eps, wd, bc1, bc2, norm2);
+                     b2, eps, wd, bc1, bc2, norm2, gate_i, gate_f);
 }
-void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, const float* norm2, float clip) {
+void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, const float* norm2, float clip,
+                 const int* gate_i, const float* gate_f) {
   ProfScope ps(s, "adamw_apply", 0, 12.0 * n);
-  hipLaunchKernelGGL(adamw_apply_kernel, dim3(2048), dim3(256), 0, s, params, upd, n, norm2, clip);
+  hipLaunchKernelGGL(adamw_apply_kernel, dim3(2048), dim3(256), 0, s, params, upd, n, norm2, clip, gate_i, gate_f);
 }
 
 // ------------------------------------------------------------------ profiler (prof.h)

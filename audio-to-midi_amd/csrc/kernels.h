@@ -152,6 +152,29 @@ struct BlockFwdArgs {
 };
 void block_fwd_fused(hipStream_t s, DType dt, const BlockFwdArgs& a);
 
+// XCD-team form (team.h, chain.hip): the Blocks of one CNN stage (same C, same L) in ONE launch of one 256-thread
+// workgroup per compute unit; clip b is owned by the workgroups of one XCD, which meet at a team barrier between Blocks.
+// Same tile body, same saved tensors, same bits as n launches of block_fwd_fused.  Training form only (C >= 16).
+struct TeamState;
+constexpr int BLOCK_RUN_MAX = 24;
+struct BlockRunFwdItem {
+  const void *W1, *W2; const float *wdw, *bdw, *lnw, *lnb, *b1, *b2, *gamma;
+  void *LN, *U, *Hh, *Z, *Y; float *mean, *rstd;
+};
+struct BlockRunFwdArgs {
+  const void* X0;            // input of the first Block
+  TeamState* st;
+  int B, L, C, n;
+  int dbg_base;              // micro-benchmark only (AMT_CHAIN_TIMING)
+  BlockRunFwdItem it[BLOCK_RUN_MAX];
+};
+// false if this (dtype, C, n, device) is not served by the team form: the caller launches the Blocks one by one
+bool block_run_fwd(hipStream_t s, DType dt, const BlockRunFwdArgs& r);
+// device words of the team protocol (zeroed); free with hipFree
+TeamState* team_state_create();
+// 0 = no team launch has timed out since the state was created (host-synchronous read)
+int team_state_timeout(const TeamState* st);
+
 // Data-gradient chain of a Block (C >= 16) in one launch: du, dln (LDS only), dD, dx and the per-workgroup
 // records of dlnw, dlnb, dwdw[7][C], dbdw, dgamma (summed by reduce_partials; `sink` is mandatory).
 // W2tg [2C][C] (pw2^T, columns scaled by gamma) and W1t [C][2C] are fragment-PACKED T copies.
@@ -286,9 +309,11 @@ void copy_pad_f32(hipStream_t s, const float* src, float* dst, size_t n, size_t 
 // pass 1: update m, v, write the (unclipped) update into upd, accumulate sum(upd^2) into norm2[0]
 void adamw_compute(hipStream_t s, const float* params, const float* grads, float* m, float* v, float* upd,
                    const float* lr_scale, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
-                   float* norm2);
+                   float* norm2, const int* gate_i = nullptr, const float* gate_f = nullptr);
 // pass 2: params += upd * min(1, clip / sqrt(norm2))
-void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, const float* norm2, float clip);
+// gate_i / gate_f (device, either may be null): both passes are no-ops unless *gate_i != 0 and *gate_f >= 0.999
+void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, const float* norm2, float clip,
+                 const int* gate_i = nullptr, const float* gate_f = nullptr);
 
 // batched fp32 -> T weight conversion (plain copy or transpose), one launch for the whole model
 struct ConvDesc { uint64_t src_off; uint64_t dst_off; int rows, cols; int src_rows; int transpose;
@@ -297,7 +322,7 @@ struct ConvDesc { uint64_t src_off; uint64_t dst_off; int rows, cols; int src_ro
 // Fragment-packed weight copy for the chain kernels: [rows/16][ceil(cols/32)][64 lanes][8], lane = 16 g + r
 // holds W[16 rb + r][32 ks + 8 g .. + 8) — one wave-level A-fragment load is 1 KiB contiguous
 // (row-major gives 16 rows x 64 B per load: half of every cache line per instruction).
-static inline size_t chain_packed_elems(int rows, int cols) { return (size_t)(rows / 16) * ((cols + 31) / 32) * 512; }
+static inline constexpr __host__ __device__ size_t chain_packed_elems(int rows, int cols) { return (size_t)(rows / 16) * ((cols + 31) / 32) * 512; }
 void convert_batch(hipStream_t s, DType dt, const float* src, void* dst, const ConvDesc* descs_dev,
                    const int* tile_prefix_dev, int n_desc, int total_tiles);
 

@@ -237,12 +237,17 @@ struct Arena {
   size_t cap = 0, off = 0, peak = 0;
   bool dry = false;
   bool overflow = false;
+  bool* stop = nullptr;   // also set on overflow: the "dry" switch of the launchers that are called outside RUN()
   void* alloc(size_t bytes) {
     size_t o = (off + 255) & ~(size_t)255;
     off = o + bytes;
     if (off > peak) peak = off;
     if (dry) return reinterpret_cast<void*>(o + 4096);  // fake non-null address, never dereferenced
-    if (off > cap) { overflow = true; return base; }     // never hand out memory past the plan
+    if (off > cap) {      // never hand out memory past the plan; every launch after this point is suppressed
+      overflow = true;
+      if (stop) *stop = true;
+      return base;
+    }
     return base + o;
   }
 };
@@ -271,6 +276,17 @@ struct amt_ctx {
   bool rope_user = false;
   Arena arena;
   int plan_B = 0, plan_T = 0, plan_train = -1;
+  // Every (B, T, mode) planned so far keeps its record descriptors on the device, and the arena / record workspace only
+  // ever grow: switching back to a shape that was planned before reallocates nothing, so a hipGraph captured for it
+  // stays valid.  plan_gen counts the events that DO move device memory a captured graph may point into.
+  struct PlanRec {
+    int B, T, train;
+    size_t peak, scratch_max, part_total, ev_needed;
+    PartDesc* desc_dev;
+    int n_desc, n_half;
+  };
+  std::vector<PlanRec> plans;
+  uint64_t plan_gen = 0;
   // optimizer state
   float *adam_m = nullptr, *adam_v = nullptr, *adam_upd = nullptr, *lr_scale = nullptr, *norm2 = nullptr;
   float lr_scale_decay = -1.f;
@@ -302,6 +318,7 @@ struct amt_ctx {
   int nochain = 0;              // debugging: AMT_NOCHAIN bit mask disables individual chain kernels / riders
   bool attn_fp8 = false;        // amt_set_attn_fp8: global-attention forward on fp8 MFMA (bf16 contexts only)
   float* amax = nullptr;        // [layers][prev q,k,v,- | cur q,k,v,-]: delayed per-tensor scaling state
+  TeamState* team = nullptr;    // XCD-team protocol words (team.h); null: team launches disabled (AMT_TEAM=0)
   bool fuse_ffn = false;        // AMT_FUSE_FFN=1: whole second half of a layer in one launch (measured slower)
 
   const float* P(size_t off) const { return params + off; }
@@ -387,7 +404,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
   const DType dt = c->dt;
   const size_t es = c->esz;
   const bool dry = A.dry;
-#define RUN(...) do { if (!dry) { __VA_ARGS__; } } while (0)
+#define RUN(...) do { if (!dry && !A.overflow) { __VA_ARGS__; } } while (0)   // an overflowed plan launches nothing more
   const Drop dp = drop_params(c, train);
 
   c->ssave.assign(cfg.n_stages, StageSave());
@@ -432,6 +449,40 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
     }
     const int N = B * Lcur;
     sv.blocks.assign(st.blocks.size(), BlockSave());
+    // XCD-team form: the whole stage in one launch (team.h; chain.hip: block_run_fwd)
+    if (save && c->fuse && c->team != nullptr && C >= 16 && st.blocks.size() >= 2 && st.blocks.size() <= (size_t)BLOCK_RUN_MAX &&
+        !(c->nochain & 1) && !(c->nochain & 1024)) {
+      BlockRunFwdArgs ra;
+      memset(&ra, 0, sizeof(ra));
+      ra.X0 = cur; ra.st = c->team; ra.B = B; ra.L = Lcur; ra.C = C; ra.n = (int)st.blocks.size(); ra.dbg_base = dbg_slot;
+      std::vector<BlockFwdArgs> single(st.blocks.size());
+      const void* xin = cur;
+      for (size_t j = 0; j < st.blocks.size(); ++j) {
+        const BlockP& bp = st.blocks[j];
+        BlockSave& bs = sv.blocks[j];
+        bs.x = const_cast<void*>(xin);
+        bs.ln = A.alloc((size_t)N * C * es);
+        bs.mean = (float*)A.alloc((size_t)N * sizeof(float));
+        bs.rstd = (float*)A.alloc((size_t)N * sizeof(float));
+        bs.u = A.alloc((size_t)N * 2 * C * es);
+        bs.h = A.alloc((size_t)N * 2 * C * es);
+        bs.z = A.alloc((size_t)N * C * es);
+        void* y = out_buf((size_t)N * C);
+        BlockRunFwdItem& it = ra.it[j];
+        it.W1 = c->WC(bp.c_pw1p); it.W2 = c->WC(bp.c_pw2p); it.wdw = c->P(bp.dw_w); it.bdw = c->P(bp.dw_b);
+        it.lnw = c->P(bp.ln_w); it.lnb = c->P(bp.ln_b); it.b1 = c->P(bp.pw1_b); it.b2 = c->P(bp.pw2_b); it.gamma = c->P(bp.gamma);
+        it.LN = bs.ln; it.U = bs.u; it.Hh = bs.h; it.Z = bs.z; it.Y = y; it.mean = bs.mean; it.rstd = bs.rstd;
+        single[j] = BlockFwdArgs{xin, it.wdw, it.bdw, it.lnw, it.lnb, it.W1, it.b1, it.W2, it.b2, it.gamma, bs.ln, bs.mean,
+                                 bs.rstd, bs.u, bs.h, bs.z, y, B, Lcur, C, dbg_slot++};
+        xin = y;
+      }
+      cur = const_cast<void*>(xin);
+      if (!dry && !A.overflow) {
+        if (!block_run_fwd(s, dt, ra))
+          for (const BlockFwdArgs& fa : single) block_fwd_fused(s, dt, fa);
+      }
+      continue;
+    }
     for (size_t j = 0; j < st.blocks.size(); ++j) {
       const BlockP& bp = st.blocks[j];
       BlockSave& bs = sv.blocks[j];
@@ -598,13 +649,15 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   const size_t es = c->esz;
   const bool dry = A.dry;
   bool live = (phase != 2);            // launches enabled (first half active unless phase == 2)
-#define RUN(...) do { if (!dry && live) { __VA_ARGS__; } } while (0)
+#define RUN(...) do { if (!dry && live && !A.overflow) { __VA_ARGS__; } } while (0)
   const Drop dp = drop_params(c, train);
   const int S = T / 320, N = B * S, H = L.H;
   PartialSink sink;
   sink.ws = c->partials;
   sink.grads_base = grads;
   sink.dry = dry || !live;             // launchers that take the sink account but do not launch when it is "dry"
+  struct StopGuard { Arena& a; ~StopGuard() { a.stop = nullptr; } } stop_guard{A};
+  A.stop = &sink.dry;
   if (dry) { c->part_descs.clear(); sink.descs = &c->part_descs; }
 
   int dbg_bwd = 0;   // micro-benchmark builds only (AMT_CHAIN_TIMING)
@@ -872,7 +925,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     RUN(grads_finalize(s, grads + L.fn_w, grads_out + L.fn_w, L.n_params - L.fn_w, 1.f / scale, grads_valid));
     return 0;
   }
-  if (phase == 2) { live = true; sink.dry = dry; deferred.clear(); }   // phase 1 ran the deferred problems itself (none of them takes sink records)
+  if (phase == 2) { live = true; sink.dry = dry || A.overflow; deferred.clear(); }   // phase 1 ran the deferred problems itself (none of them takes sink records)
   // CNN stages, last to first
   int Lcur = S;
   for (int si = cfg.n_stages - 1; si >= 0; --si) {
@@ -986,7 +1039,23 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
 
 int plan(amt_ctx* c, int B, int T, int train_mode, hipStream_t s) {
   // train_mode: 0 = inference (recycled buffers), 1 = training (everything saved + backward scratch)
+  c->arena.overflow = false;
   if (c->plan_B == B && c->plan_T == T && c->plan_train == train_mode && c->arena.base) return 0;
+  for (const amt_ctx::PlanRec& r : c->plans) {
+    if (r.B != B || r.T != T || r.train != train_mode) continue;
+    // planned before: the arena and the record workspace are at least as large as this plan needs (they only
+    // grow), its descriptors are still on the device: nothing is allocated, no captured graph is invalidated
+    c->scratch_max = r.scratch_max;
+    c->part_total = r.part_total;
+    c->part_desc_dev = r.desc_dev;
+    c->n_part_desc = r.n_desc;
+    c->n_part_desc_half = r.n_half;
+    c->ev_needed = r.ev_needed;
+    c->arena.off = 0;
+    c->arena.peak = 0;
+    c->plan_B = B; c->plan_T = T; c->plan_train = train_mode;
+    return 0;
+  }
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &cs);
   if (cs != hipStreamCaptureStatusNone) {
@@ -999,6 +1068,10 @@ int plan(amt_ctx* c, int B, int T, int train_mode, hipStream_t s) {
   dryA.dry = true;
   Arena keep = c->arena;
   c->arena = dryA;
+  c->part_descs.clear();
+  c->part_total = 0;
+  c->n_part_desc_half = 0;
+  c->ev_needed = 0;
   run_forward(c, s, nullptr, B, T, train_mode == 1, true, 0);
   if (train_mode == 1) {
     // pass 1 measures the per-scope scratch, pass 2 lays out the two alternating scratch regions
@@ -1009,7 +1082,9 @@ int plan(amt_ctx* c, int B, int T, int train_mode, hipStream_t s) {
     c->arena.peak = fwd_end;
     run_backward(c, s, nullptr, nullptr, B, T, 1.f, true, 0, nullptr, nullptr);
   }
-  size_t need = c->arena.peak + 4096;
+  const size_t need = c->arena.peak + 4096;
+  c->arena = keep;
+  amt_ctx::PlanRec rec{B, T, train_mode, need, c->scratch_max, c->part_total, c->ev_needed, nullptr, 0, 0};
   if (train_mode == 1) {
     while (c->ev_pool.size() < c->ev_needed + 8) {
       hipEvent_t e;
@@ -1020,30 +1095,34 @@ int plan(amt_ctx* c, int B, int T, int train_mode, hipStream_t s) {
       HIPCHK(c, hipDeviceSynchronize());
       if (c->partials) (void)hipFree(c->partials);
       c->partials = nullptr;
+      c->partials_cap = 0;
+      c->plan_gen++;                    // graphs captured earlier hold the old record workspace
       HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->partials), c->part_total * sizeof(float)));
       c->partials_cap = c->part_total;
     }
-    if (c->part_desc_dev) (void)hipFree(c->part_desc_dev);
-    c->part_desc_dev = nullptr;
-    c->n_part_desc = (int)c->part_descs.size();
-    if (c->n_part_desc > 0) {
-      HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->part_desc_dev), c->part_descs.size() * sizeof(PartDesc)));
-      HIPCHK(c, hipMemcpy(c->part_desc_dev, c->part_descs.data(), c->part_descs.size() * sizeof(PartDesc),
-                          hipMemcpyHostToDevice));
+    rec.n_desc = (int)c->part_descs.size();
+    rec.n_half = c->n_part_desc_half;
+    if (rec.n_desc > 0) {   // owned by the plan record until the context is destroyed
+      HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&rec.desc_dev), c->part_descs.size() * sizeof(PartDesc)));
+      HIPCHK(c, hipMemcpy(rec.desc_dev, c->part_descs.data(), c->part_descs.size() * sizeof(PartDesc), hipMemcpyHostToDevice));
     }
+    c->part_desc_dev = rec.desc_dev;
+    c->n_part_desc = rec.n_desc;
   }
-  c->arena = keep;
+  c->plans.push_back(rec);
   if (need > c->arena.cap) {
     HIPCHK(c, hipDeviceSynchronize());
     if (c->arena.base) (void)hipFree(c->arena.base);
     c->arena.base = nullptr;
     c->arena.cap = 0;
+    c->plan_gen++;                      // graphs captured earlier hold pointers into the old arena
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->arena.base), need));
     c->arena.cap = need;
   }
   c->arena.off = 0;
   c->arena.peak = 0;
   c->arena.dry = false;
+  c->arena.overflow = false;
   c->plan_B = B; c->plan_T = T; c->plan_train = train_mode;
   return 0;
 }
@@ -1139,6 +1218,11 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   c->fuse = !(getenv("AMT_FUSE") && atoi(getenv("AMT_FUSE")) == 0);
   c->nochain = getenv("AMT_NOCHAIN") ? atoi(getenv("AMT_NOCHAIN")) : 0;
   c->fuse_ffn = getenv("AMT_FUSE_FFN") && atoi(getenv("AMT_FUSE_FFN")) != 0;
+  // XCD-team launches (team.h): opt-in while they are not faster than one launch per Block (profiles/r02_notes.md)
+  if (getenv("AMT_TEAM") && atoi(getenv("AMT_TEAM")) != 0) {
+    c->team = team_state_create();
+    if (c->team == nullptr) { g_create_error = "hipMalloc(team state)"; delete c; return 1; }
+  }
   if (c->nochain == 0) {   // keep only the conversions the selected execution mode reads (debug mask: keep all)
     const bool chain_tr = c->fuse && cfg->dims[cfg->n_stages - 1] == 256 && cfg->ffn_inter == 512 &&
                           cfg->n_heads * cfg->head_dim == 256 && cfg->kv_compress == 64;
@@ -1189,7 +1273,9 @@ void amt_destroy(amt_ctx* c) {
   (void)hipSetDevice(c->device);
   void* ptrs[] = {c->params, c->wc, c->head_bias, c->conv_dev, c->conv_prefix_dev, c->rope_cos, c->rope_sin,
                   c->arena.base, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, c->norm2, c->loss_acc,
-                  c->partials, c->part_desc_dev, c->amax, c->gacc};
+                  c->partials, c->amax, c->gacc, c->team};
+  for (const amt_ctx::PlanRec& r : c->plans)
+    if (r.desc_dev) (void)hipFree(r.desc_dev);
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1289,6 +1375,10 @@ uint64_t amt_grad_bucket_split(const amt_ctx* c) { return c->L.fn_w; }
 
 uint64_t amt_workspace_bytes(const amt_ctx* c) { return c->arena.cap; }
 
+uint64_t amt_plan_generation(const amt_ctx* c) { return c->plan_gen; }
+
+int32_t amt_team_status(const amt_ctx* c) { return c->team ? team_state_timeout(c->team) : 0; }
+
 void amt_profile_begin(void) {
   Profiler& p = profiler();
   p.recs.clear();
@@ -1348,18 +1438,27 @@ int32_t amt_optimizer_init(amt_ctx* c, float layer_lr_decay) {
   return 0;
 }
 
-int32_t amt_adamw_step(amt_ctx* c, const float* grads_flat, float lr_base, float layer_lr_decay, float b1, float b2,
-                       float eps, float weight_decay, float clip_norm, int32_t step, void* stream) {
+int32_t amt_adamw_step_gated(amt_ctx* c, const float* grads_flat, float lr_base, float layer_lr_decay, float b1, float b2,
+                             float eps, float weight_decay, float clip_norm, int32_t step, const int32_t* valid_i32,
+                             const float* valid_f32, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t n = c->L.n_params;
+  // optax counts from 1: step <= 0 makes the bias corrections 1 - b^step zero or negative (m / 0 = inf in every parameter)
+  if (step < 1) { c->err = "amt_adamw_step: step must be >= 1 (the first optimizer step is step 1)"; return 1; }
   if (!c->adam_m || c->lr_scale_decay != layer_lr_decay) {
     if (amt_optimizer_init(c, layer_lr_decay)) return 1;
   }
   fill_f32(s, c->norm2, 0.f, 1);
   adamw_compute(s, c->params, grads_flat, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, n, lr_base, b1, b2, eps,
-                weight_decay, step, c->norm2);
-  adamw_apply(s, c->params, c->adam_upd, n, c->norm2, clip_norm);
+                weight_decay, step, c->norm2, valid_i32, valid_f32);
+  adamw_apply(s, c->params, c->adam_upd, n, c->norm2, clip_norm, valid_i32, valid_f32);
   return refresh(c, s);
+}
+
+int32_t amt_adamw_step(amt_ctx* c, const float* grads_flat, float lr_base, float layer_lr_decay, float b1, float b2,
+                       float eps, float weight_decay, float clip_norm, int32_t step, void* stream) {
+  return amt_adamw_step_gated(c, grads_flat, lr_base, layer_lr_decay, b1, b2, eps, weight_decay, clip_norm, step, nullptr,
+                              nullptr, stream);
 }
 
 }  // extern "C"

@@ -94,7 +94,10 @@ SIGNATURES = {
     "amt_forward_backward_phase": (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _u64, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "amt_grad_bucket_split": (_u64, [_vp]),
     "amt_workspace_bytes": (_u64, [_vp]),
+    "amt_plan_generation": (_u64, [_vp]),
+    "amt_team_status": (_i32, [_vp]),
     "amt_adamw_step": (_i32, [_vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "amt_adamw_step_gated": (_i32, [_vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp, _vp]),
     "amt_optimizer_init": (_i32, [_vp, _f32]),
     "amt_profile_begin": (None, []),
     "amt_profile_end": (_i32, [_vp, _i32]),

@@ -237,14 +237,34 @@ class OutputSequenceGenerator:
         self._check(self._L.amt_optimizer_init(self._h, float(layer_lr_decay)), "amt_optimizer_init")
 
     def adamw_step(self, grads_flat, lr_base, step, layer_lr_decay=0.7, b1=0.9, b2=0.999, eps=1e-3,
-                   weight_decay=0.005, clip_norm=1.0):
-        """optimizer half of compute_training_step (train.py:324-325, 646-729)."""
-        self._check(self._L.amt_adamw_step(self._h, _lib.ptr(grads_flat), float(lr_base), float(layer_lr_decay),
-                                           float(b1), float(b2), float(eps), float(weight_decay), float(clip_norm),
-                                           int(step), self._stream()), "amt_adamw_step")
+                   weight_decay=0.005, clip_norm=1.0, valid: Optional[torch.Tensor] = None,
+                   valid_mean: Optional[torch.Tensor] = None):
+        """optimizer half of compute_training_step (train.py:324-325, 646-729).  ``step`` counts from 1 (optax).
+
+        ``valid`` (device int32[1], the grads_valid word of ``loss_and_grads``) and ``valid_mean`` (device
+        float32[1], that flag after a mean all-reduce: 1.0 iff every rank's is 1) gate the update ON THE DEVICE:
+        with a closed gate parameters, m and v stay untouched (the skip of train.py:369-377) and no host sync is
+        needed, so the step stays hipGraph-capturable."""
+        if valid is not None and (valid.dtype != torch.int32 or not valid.is_cuda):
+            raise ValueError("valid must be a device int32 tensor")
+        if valid_mean is not None and (valid_mean.dtype != torch.float32 or not valid_mean.is_cuda):
+            raise ValueError("valid_mean must be a device float32 tensor")
+        self._check(self._L.amt_adamw_step_gated(self._h, _lib.ptr(grads_flat), float(lr_base), float(layer_lr_decay),
+                                                 float(b1), float(b2), float(eps), float(weight_decay), float(clip_norm),
+                                                 int(step), _lib.ptr(valid), _lib.ptr(valid_mean), self._stream()),
+                    "amt_adamw_step")
 
     def workspace_bytes(self) -> int:
         return int(self._L.amt_workspace_bytes(self._h))
+
+    def plan_generation(self) -> int:
+        """Changes exactly when a first-time plan had to replace the workspace, which invalidates every hipGraph
+        captured from this model (include/amt.h: amt_plan_generation).  Record at capture, compare before replay."""
+        return int(self._L.amt_plan_generation(self._h))
+
+    def team_status(self) -> int:
+        """0 unless an in-launch XCD-team hand-off has timed out (fatal; include/amt.h: amt_team_status)."""
+        return int(self._L.amt_team_status(self._h))
 
 
 class _DevView:

@@ -131,6 +131,19 @@ uint64_t amt_grad_bucket_split(const amt_ctx* ctx);
 /* Bytes of activation workspace currently held (diagnostics). */
 uint64_t amt_workspace_bytes(const amt_ctx* ctx);
 
+/* Workspace and hipGraph capture.  The first call for a new (B, T, inference | training) shape plans and allocates
+ * (synchronously: make it outside stream capture); every later call for a shape planned before allocates nothing,
+ * whatever other shapes were run in between: the workspace only grows and each plan keeps its descriptors.  A graph
+ * captured for one shape therefore stays valid while other, already planned shapes run eagerly.  What DOES invalidate
+ * every graph captured from this context is a first-time plan that needs a larger workspace (the old one is freed):
+ * amt_plan_generation() changes exactly then.  Record it at capture time and re-capture when it differs. */
+uint64_t amt_plan_generation(const amt_ctx* ctx);
+
+/* In-launch XCD-team hand-offs (csrc/team.h) spin with a bound.  0 = none has ever given up in this context; non-zero =
+ * a launch timed out (its outputs are undefined and every later team launch falls through): treat as fatal.
+ * Host-synchronous read. */
+int32_t amt_team_status(const amt_ctx* ctx);
+
 /* ---- next-row: optimizer step of compute_training_step (train.py:324-325, 646-729) ----------
  * optax.adamw(b1, b2, eps, weight_decay) per depth label, then clip_by_global_norm(1.0) on the
  * UPDATES, then apply.  lr_base is the scheduled base learning rate for this step; conv leaves
@@ -140,6 +153,15 @@ uint64_t amt_workspace_bytes(const amt_ctx* ctx);
 int32_t amt_optimizer_init(amt_ctx* ctx, float layer_lr_decay);
 int32_t amt_adamw_step(amt_ctx* ctx, const float* grads_flat, float lr_base, float layer_lr_decay, float b1,
                        float b2, float eps, float weight_decay, float clip_norm, int32_t step, void* stream);
+/* The same step gated on DEVICE flags (no host sync, hipGraph-capturable): parameters, m and v are left untouched
+ * unless *valid_i32 != 0 (the grads_valid word of amt_forward_backward) and *valid_f32 >= 0.999 (that flag as a float
+ * after a mean all-reduce over ranks: 1.0 iff every rank's gradients are finite).  Either pointer may be NULL.
+ * This is the skip of train.py:369-377 (the reference rolls back to a copy instead).
+ * `step` counts optimizer steps from 1 (optax); step < 1 is an error in both entry points: the bias corrections
+ * 1 - b^step would be zero. */
+int32_t amt_adamw_step_gated(amt_ctx* ctx, const float* grads_flat, float lr_base, float layer_lr_decay, float b1,
+                             float b2, float eps, float weight_decay, float clip_norm, int32_t step,
+                             const int32_t* valid_i32, const float* valid_f32, void* stream);
 
 /* ---- measurement aid (bench.py roofline leg): per-kernel-class timing with HIP events recorded
  * on the launch stream around every kernel launch.  Process-global; off by default. */

@@ -34,7 +34,7 @@ if os.environ.get("PREDICT") == "1":
         model.predict(None, audio)
 torch.cuda.synchronize()
 L = amtlib.load()
-buf = np.zeros((128, 256, 8), dtype=np.uint64)
+buf = np.zeros((128, 256, 12), dtype=np.uint64)
 rc = L.amt_debug_read_stamps(C.c_void_p(buf.ctypes.data))
 print("rc", rc)
 prev_end = None

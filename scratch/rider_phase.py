@@ -24,7 +24,7 @@ for i in range(10):
     g.replay()
 torch.cuda.synchronize()
 L = amtlib.load()
-buf = np.zeros((128, 256, 8), dtype=np.uint64)
+buf = np.zeros((128, 256, 12), dtype=np.uint64)
 L.amt_debug_read_stamps(C.c_void_p(buf.ctypes.data))
 s = buf[127].astype(np.int64)
 live = s[:, 0] > 0
