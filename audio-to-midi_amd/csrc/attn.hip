@@ -133,6 +133,7 @@ AMT_DEV uint32_t gdrop_idx(int b, int H, int h, int S, int q, int key) {
 // cycles of VALU issue.
 template <typename T, int NG>
 __global__ __launch_bounds__(256 * NG) void attn_global_fwd_kernel(AttnArgs a) {
+  a.seed = eff_seed(a.seed, a.seed_dev);   // kernel argument + the context's device seed word (common.h)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid_all = threadIdx.x, half = tid_all >> 8, tid = tid_all & 255;   // half = key-tile group 0 .. NG-1
   T* Ks = reinterpret_cast<T*>(smem_raw) + half * (3 * 64 * ALD);
@@ -362,6 +363,7 @@ AMT_DEV void fp8_kv_store(unsigned char* Ks8, unsigned char* Vt8, const Fp8Stage
 
 __global__ __launch_bounds__(256) void attn_global_fwd_fp8_kernel(AttnArgs a, const float* __restrict__ amax_prev,
                                                                   float* __restrict__ amax_cur) {
+  a.seed = eff_seed(a.seed, a.seed_dev);   // kernel argument + the context's device seed word (common.h)
   typedef bf16 T;
   __shared__ __attribute__((aligned(16))) unsigned char Ks8[64 * F8LD];   // [key][d]
   __shared__ __attribute__((aligned(16))) unsigned char Vt8[64 * F8LD];   // [d][key]
@@ -809,6 +811,7 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
 // blocks [0, ntile) of a (clip, head) compute dQ, blocks [ntile, 2 ntile) dK/dV
 template <typename T, int NG>
 __global__ __launch_bounds__(256 * NG, 2 * NG) void attn_global_bwd_kernel(AttnBwdArgs ba, int ntile) {
+  ba.f.seed = eff_seed(ba.f.seed, ba.f.seed_dev);   // kernel argument + the context's device seed word (common.h)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // XCD-aware order: the 2 * ntile workgroups of one (clip, head) share its Q/K/V/dO: same id % 8
   const int per = 2 * ntile;
@@ -920,6 +923,7 @@ AMT_DEV void store_roped(T* row, int c, const float (&x)[8], const float* cs, co
 
 template <typename T>
 __global__ __launch_bounds__(64) void attn_local_fwd_kernel(AttnArgs a, int padL, int nW) {
+  a.seed = eff_seed(a.seed, a.seed_dev);   // kernel argument + the context's device seed word (common.h)
   // qs: the stripe's 8 queries twice: row i rotated as row i of window B, row 8 + i as row 8 + i of window A
   __shared__ __attribute__((aligned(16))) T qs[16][ALD], kA[16][ALD], kB[16][ALD], vs[24][ALD], Pt[8][OLD];
   const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
@@ -1015,6 +1019,7 @@ AMT_DEV float local_cnt(int p, int nW) {
 
 template <typename T>
 __global__ __launch_bounds__(64) void attn_local_bwd_kernel(AttnBwdArgs ba, int padL, int nW) {
+  ba.f.seed = eff_seed(ba.f.seed, ba.f.seed_dev);   // kernel argument + the context's device seed word (common.h)
   const AttnArgs& a = ba.f;
   __shared__ __attribute__((aligned(16))) T qA[16][ALD], qB[16][ALD], kA[16][ALD], kB[16][ALD], vs[24][ALD], dOs[24][ALD];
   // operand tiles of the second GEMMs, k = 0..15 window A, k = 16..31 window B:

@@ -817,6 +817,7 @@ template <typename T> struct FfnTileFwd { static constexpr int TT = 16; };
 // whose 64 x 64 tiles move 3.5x fewer weight bytes per CU (profiles/r01_notes.md).
 template <typename T, int TT, bool FULL>
 __global__ __launch_bounds__(256) void ffn_fwd_fused_kernel(FfnFwdArgs a) {
+  a.seed = eff_seed(a.seed, a.seed_dev);   // kernel argument + the context's device seed word (common.h)
   constexpr int H = 256, I = 512, I2 = 1024, LDX = H + 8, LDG = I + 8;
   using SO = ChainSplit<H, TT>;        // Wo and W2 stages: 256 output features
   using S1 = ChainSplit<I2 / 2, TT>;   // W1 in two halves of 512 permuted rows
@@ -1109,6 +1110,7 @@ void qkv_fwd_fused(hipStream_t s, DType dt, const QkvFwdArgs& a) {
 // ------------------------------------------------------------------ transformer layer backward chains
 template <typename T, int TT>
 __global__ __launch_bounds__(256) void qkv_bwd_fused_kernel(QkvBwdArgs a, WgradGroup riders) {
+  a.seed = eff_seed(a.seed, a.seed_dev);   // kernel argument + the context's device seed word (common.h)
   constexpr int H = 256, QC = 320, CK = 64, KV = 512, LDX = H + 8, LDQ = QC + 8, LDK = KV + 8;
   using SC = ChainSplit<CK, TT>;     // dc: 64 features
   using SX = ChainSplit<H, TT>;      // dxn: 256 features

@@ -281,6 +281,9 @@ AMT_DEV uint32_t rng_key(uint64_t seed, uint32_t stream) {
 AMT_DEV uint32_t rng_u32(uint64_t seed, uint32_t stream, uint32_t idx) {
   return mix32((idx * 0x9e3779b1U) ^ rng_key(seed, stream));
 }
+// The seed of a launch is `seed` (a kernel argument, frozen when a hipGraph is captured) plus an optional device word
+// the host or a tiny kernel changes between replays (include/amt.h: amt_seed_word): replayed steps get fresh masks.
+AMT_DEV uint64_t eff_seed(uint64_t seed, const uint64_t* seed_dev) { return seed_dev ? seed + *seed_dev : seed; }
 // keep with probability (1 - p): threshold on the top 24 bits
 AMT_DEV bool rng_keep(uint64_t seed, uint32_t stream, uint32_t idx, uint32_t drop_thresh24) {
   return (rng_u32(seed, stream, idx) >> 8) >= drop_thresh24;

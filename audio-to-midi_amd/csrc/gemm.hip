@@ -110,6 +110,7 @@ AMT_DEV void epi_glu(const GemmArgs& a, int n, int m, float (&u1)[4], float (&u2
 // tile BT tokens x 64 features; per wave (BT/2) x 32 = TI x 2 MFMA 16x16 sub-tiles.
 template <typename T, int EPI, int BT, int BK>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
+  a.seed = eff_seed(a.seed, a.seed_dev);   // kernel argument + the context's device seed word (common.h)
   constexpr int TI = BT / 32;
   constexpr int FI = 2;
   // BK = K panel per LDS stage, chosen by the launcher as the smallest of {64, 128, 256} (bf16) that

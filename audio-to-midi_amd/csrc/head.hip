@@ -79,7 +79,8 @@ void bce_loss(hipStream_t s, DType dt, const float* logits_pad, int ldl, const f
 
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ X, T* __restrict__ Y, size_t n, uint64_t seed, uint32_t stream,
-                               uint32_t thr, float inv_keep) {
+                               uint32_t thr, float inv_keep, const uint64_t* __restrict__ seed_dev) {
+  seed = eff_seed(seed, seed_dev);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     bool keep = rng_keep(seed, stream, (uint32_t)i, thr);
     Y[i] = keep ? from_f<T>(to_f(X[i]) * inv_keep) : from_f<T>(0.f);
@@ -87,15 +88,15 @@ __global__ void dropout_kernel(const T* __restrict__ X, T* __restrict__ Y, size_
 }
 
 void dropout_apply(hipStream_t s, DType dt, const void* X, void* Y, size_t n, uint64_t seed, uint32_t stream,
-                   uint32_t thr, float inv_keep) {
+                   uint32_t thr, float inv_keep, const uint64_t* seed_dev) {
   ProfScope ps(s, "dropout_apply", 0, 2.0 * n * (dt == DT_F32 ? 4 : 2));
   int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   if (dt == DT_F32)
     hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)X, (float*)Y, n, seed,
-                       stream, thr, inv_keep);
+                       stream, thr, inv_keep, seed_dev);
   else
     hipLaunchKernelGGL((dropout_kernel<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)X, (bf16*)Y, n, seed, stream,
-                       thr, inv_keep);
+                       thr, inv_keep, seed_dev);
 }
 
 __global__ void grads_finalize_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n, float mul,

@@ -34,7 +34,8 @@ struct GemmArgs {
   const void* R; int ldr;   // residual (T)
   const void* U; int ldu;   // saved pre-activation (T)
   const float* gamma;       // [M]
-  uint64_t seed; uint32_t stream; uint32_t drop_thresh24; float inv_keep;  // dropout (drop_thresh24 == 0: off)
+  uint64_t seed; uint32_t stream; uint32_t drop_thresh24; float inv_keep;
+  const uint64_t* seed_dev;   // optional device word ADDED to `seed` by the kernel (fresh masks under hipGraph replay)
 };
 // requirements: M % 4 == 0; (K % 8 == 0 and ldx, ldw % 8 == 0) or (K == 4 and ldx, ldw % 4 == 0)
 void gemm_nt(hipStream_t s, DType dt, EpiKind epi, const GemmArgs& a);
@@ -206,6 +207,7 @@ struct FfnFwdArgs {
   void* Hout; void* HN; float* mean; float* rstd; void* U; void* G; void* Y;
   int N;
   uint64_t seed; uint32_t stream; uint32_t drop_thresh24; float inv_keep;
+  const uint64_t* seed_dev;   // optional device word ADDED to `seed` by the kernel (fresh masks under hipGraph replay)
   int dbg_slot;
 };
 void ffn_fwd_fused(hipStream_t s, DType dt, const FfnFwdArgs& a);
@@ -237,6 +239,7 @@ struct QkvBwdArgs {
   int N;
   int n_chain;                                // workgroups of the chain; the rest run the riders (launcher)
   uint64_t seed; uint32_t stream; uint32_t drop_thresh24; float inv_keep;
+  const uint64_t* seed_dev;   // optional device word ADDED to `seed` by the kernel (fresh masks under hipGraph replay)
   int dbg_slot;
 };
 void qkv_bwd_fused(hipStream_t s, DType dt, const QkvBwdArgs& a, float* dlnw, float* dlnb, PartialSink* sink,
@@ -266,6 +269,7 @@ struct AttnArgs {
   const float* cos; const float* sin;  // [n_pos][32]
   int B, S, H;                // H heads of dim 64
   uint64_t seed; uint32_t stream; uint32_t drop_thresh24; float inv_keep;
+  const uint64_t* seed_dev;   // optional device word ADDED to `seed` by the kernel (fresh masks under hipGraph replay)
 };
 struct AttnBwdArgs {
   AttnArgs f;                 // forward tensors (O = forward output, LSE)
@@ -293,7 +297,7 @@ void bce_loss(hipStream_t s, DType dt, const float* logits_pad, int ldl, const f
               void* dlogits, int ldd, int N, int V, float scale, int B);
 // elementwise dropout: Y = X * keep / (1-p)
 void dropout_apply(hipStream_t s, DType dt, const void* X, void* Y, size_t n, uint64_t seed, uint32_t stream,
-                   uint32_t drop_thresh24, float inv_keep);
+                   uint32_t drop_thresh24, float inv_keep, const uint64_t* seed_dev = nullptr);
 // g[i] *= mul ; flag[0] = 0 if any non-finite
 // dst[i] = src[i] * mul, AND-ing `valid_flag` with "all finite" (src == dst allowed)
 void grads_finalize(hipStream_t s, const float* src, float* dst, size_t n, float mul, int* valid_flag);

@@ -318,6 +318,7 @@ struct amt_ctx {
   int nochain = 0;              // debugging: AMT_NOCHAIN bit mask disables individual chain kernels / riders
   bool attn_fp8 = false;        // amt_set_attn_fp8: global-attention forward on fp8 MFMA (bf16 contexts only)
   float* amax = nullptr;        // [layers][prev q,k,v,- | cur q,k,v,-]: delayed per-tensor scaling state
+  uint64_t* seed_word = nullptr;   // device word added to every dropout seed (amt_seed_word / amt_advance_seed)
   TeamState* team = nullptr;    // XCD-team protocol words (team.h); null: team launches disabled (AMT_TEAM=0)
   bool fuse_ffn = false;        // AMT_FUSE_FFN=1: whole second half of a layer in one launch (measured slower)
 
@@ -574,7 +575,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
     memset(&aa, 0, sizeof(aa));
     aa.QC = ls.qc; aa.ldqc = L.QC; aa.KV = ls.kv; aa.ldkv = L.KVW; aa.O = ls.ao; aa.ldo = H; aa.LSE = ls.lse;
     aa.cos = c->rope_cos; aa.sin = c->rope_sin; aa.B = B; aa.S = S; aa.H = cfg.n_heads;
-    aa.seed = seed; aa.stream = stream_attn((int)li); aa.drop_thresh24 = dp.thr; aa.inv_keep = dp.inv_keep;
+    aa.seed = seed; aa.seed_dev = c->seed_word; aa.stream = stream_attn((int)li); aa.drop_thresh24 = dp.thr; aa.inv_keep = dp.inv_keep;
     if (local) RUN(attn_local_fwd(s, dt, aa));
     else if (fp8) RUN(attn_global_fwd_fp8(s, aa, c->amax + 8 * li, c->amax + 8 * li + 4));
     else RUN(attn_global_fwd(s, dt, aa));
@@ -590,7 +591,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
       if (c->fuse_ffn) {
         fa.W1 = c->WC(lp.c_w1p); fa.b1 = c->P(lp.b1); fa.W2 = c->WC(lp.c_w2p); fa.b2 = c->P(lp.b2);
         fa.U = ls.u; fa.G = ls.g; fa.Y = y;
-        fa.seed = seed; fa.stream = stream_ffn((int)li); fa.drop_thresh24 = dp.thr; fa.inv_keep = dp.inv_keep;
+        fa.seed = seed; fa.seed_dev = c->seed_word; fa.stream = stream_ffn((int)li); fa.drop_thresh24 = dp.thr; fa.inv_keep = dp.inv_keep;
         RUN(ffn_fwd_fused(s, dt, fa));
         cur = y;
         continue;
@@ -607,7 +608,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
     RUN(gemm_nt(s, dt, EPI_GLU, g1));
     GemmArgs g2 = gargs(ls.g, L.I2 / 2, c->WC(lp.c_w2), L.I2 / 2, N, H, L.I2 / 2, c->P(lp.b2), y, H);
     g2.R = ls.h; g2.ldr = H;
-    g2.seed = seed; g2.stream = stream_ffn((int)li); g2.drop_thresh24 = dp.thr; g2.inv_keep = dp.inv_keep;
+    g2.seed = seed; g2.seed_dev = c->seed_word; g2.stream = stream_ffn((int)li); g2.drop_thresh24 = dp.thr; g2.inv_keep = dp.inv_keep;
     RUN(gemm_nt(s, dt, EPI_RESID, g2));
     cur = y;
   }
@@ -626,6 +627,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
 }
 
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
+__global__ void advance_seed_kernel(uint64_t* p, uint64_t delta) { *p += delta; }
 
 // ------------------------------------------------------------------------------------ backward
 // phase 0: the whole backward pass.  phase 1 / 2: its two halves for the overlapped data-parallel step —
@@ -823,7 +825,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
         dyd = pre_dropped;            // written by the previous scope's qkv_bwd_fused
       } else {
         void* t = A.alloc((size_t)N * H * es);
-        RUN(dropout_apply(s, dt, dy, t, (size_t)N * H, seed, stream_ffn(li), dp.thr, dp.inv_keep));
+        RUN(dropout_apply(s, dt, dy, t, (size_t)N * H, seed, stream_ffn(li), dp.thr, dp.inv_keep, c->seed_word));
         dyd = t;
       }
     }
@@ -866,7 +868,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     memset(&ab, 0, sizeof(ab));
     ab.f.QC = ls.qc; ab.f.ldqc = L.QC; ab.f.KV = ls.kv; ab.f.ldkv = L.KVW; ab.f.O = ls.ao; ab.f.ldo = H;
     ab.f.LSE = ls.lse; ab.f.cos = c->rope_cos; ab.f.sin = c->rope_sin; ab.f.B = B; ab.f.S = S; ab.f.H = cfg.n_heads;
-    ab.f.seed = seed; ab.f.stream = stream_attn(li); ab.f.drop_thresh24 = dp.thr; ab.f.inv_keep = dp.inv_keep;
+    ab.f.seed = seed; ab.f.seed_dev = c->seed_word; ab.f.stream = stream_attn(li); ab.f.drop_thresh24 = dp.thr; ab.f.inv_keep = dp.inv_keep;
     ab.dO = dao; ab.lddo = H; ab.dQC = dqc; ab.lddqc = L.QC; ab.dKV = dkv; ab.lddkv = L.KVW; ab.delta = delta;
     if (local) RUN(attn_local_bwd(s, dt, ab)); else RUN(attn_global_bwd(s, dt, ab));
     const int ckv = cfg.kv_compress;
@@ -880,7 +882,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       qa.X = ls.x; qa.mean = ls.m1; qa.rstd = ls.r1; qa.ln_w = c->P(lp.ln1_w); qa.dH = dh; qa.dX = dx; qa.N = N;
       if (dp.thr && li > 0 && !(c->nochain & 256)) {   // the next scope's FFN-output dropout mask is applied here (saves its dropout_apply launch)
         void* dxd = dropbuf[di];
-        qa.dXD = dxd; qa.seed = seed; qa.stream = stream_ffn(li - 1); qa.drop_thresh24 = dp.thr; qa.inv_keep = dp.inv_keep;
+        qa.dXD = dxd; qa.seed = seed; qa.seed_dev = c->seed_word; qa.stream = stream_ffn(li - 1); qa.drop_thresh24 = dp.thr; qa.inv_keep = dp.inv_keep;
         pre_dropped = dxd;
       }
       qkv_bwd_fused(s, dt, qa, G(lp.ln1_w), G(lp.ln1_b), &sink, riders_b.data(), (int)riders_b.size());
@@ -1248,6 +1250,8 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   if ((he = hipMemset(c->wc, 0, L.n_compute * c->esz)) != hipSuccess) return fail("hipMemset", he);   // packed copies: padding stays zero
   if ((he = hipMalloc(&c->head_bias, L.VP * sizeof(float))) != hipSuccess) return fail("hipMalloc(head bias)", he);
   if ((he = hipMalloc(&c->loss_acc, 2 * sizeof(float))) != hipSuccess) return fail("hipMalloc(loss)", he);
+  if ((he = hipMalloc(reinterpret_cast<void**>(&c->seed_word), sizeof(uint64_t))) != hipSuccess) return fail("hipMalloc(seed word)", he);
+  if ((he = hipMemset(c->seed_word, 0, sizeof(uint64_t))) != hipSuccess) return fail("hipMemset", he);
   if ((he = hipMalloc(reinterpret_cast<void**>(&c->gacc), (L.n_params + 64) * sizeof(float))) != hipSuccess)
     return fail("hipMalloc(gradient accumulator)", he);
   if (!L.layers.empty()) {
@@ -1273,7 +1277,7 @@ void amt_destroy(amt_ctx* c) {
   (void)hipSetDevice(c->device);
   void* ptrs[] = {c->params, c->wc, c->head_bias, c->conv_dev, c->conv_prefix_dev, c->rope_cos, c->rope_sin,
                   c->arena.base, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, c->norm2, c->loss_acc,
-                  c->partials, c->amax, c->gacc, c->team};
+                  c->partials, c->amax, c->gacc, c->team, c->seed_word};
   for (const amt_ctx::PlanRec& r : c->plans)
     if (r.desc_dev) (void)hipFree(r.desc_dev);
   for (void* p : ptrs)
@@ -1376,6 +1380,15 @@ uint64_t amt_grad_bucket_split(const amt_ctx* c) { return c->L.fn_w; }
 uint64_t amt_workspace_bytes(const amt_ctx* c) { return c->arena.cap; }
 
 uint64_t amt_plan_generation(const amt_ctx* c) { return c->plan_gen; }
+
+uint64_t* amt_seed_word(amt_ctx* c) { return c->seed_word; }
+
+int32_t amt_advance_seed(amt_ctx* c, uint64_t delta, void* stream) {
+  hipLaunchKernelGGL(advance_seed_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), c->seed_word, delta);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { c->err = std::string("amt_advance_seed: ") + hipGetErrorString(e); return 1; }
+  return 0;
+}
 
 int32_t amt_team_status(const amt_ctx* c) { return c->team ? team_state_timeout(c->team) : 0; }
 

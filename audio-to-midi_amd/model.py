@@ -257,6 +257,18 @@ class OutputSequenceGenerator:
     def workspace_bytes(self) -> int:
         return int(self._L.amt_workspace_bytes(self._h))
 
+    def advance_seed(self, delta: int = 1):
+        """*seed_word += delta on the current stream (include/amt.h: amt_advance_seed).  Every dropout mask is drawn
+        from ``seed + seed_word``; capturing this call at the head of a step graph gives each replay fresh masks."""
+        self._check(self._L.amt_advance_seed(self._h, int(delta), self._stream()), "amt_advance_seed")
+
+    def seed_word(self) -> torch.Tensor:
+        """The context's device seed word as an int64[1] tensor view (write to it to set the offset directly)."""
+        ptr = self._L.amt_seed_word(self._h)
+        if not ptr:
+            raise RuntimeError("amt_seed_word returned NULL")
+        return _DevView(ptr, 1, self.device, typestr="<i8").tensor()
+
     def plan_generation(self) -> int:
         """Changes exactly when a first-time plan had to replace the workspace, which invalidates every hipGraph
         captured from this model (include/amt.h: amt_plan_generation).  Record at capture, compare before replay."""
@@ -270,8 +282,8 @@ class OutputSequenceGenerator:
 class _DevView:
     """Wrap a raw device pointer as a torch tensor through __cuda_array_interface__."""
 
-    def __init__(self, ptr, n, device):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 3}
+    def __init__(self, ptr, n, device, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 3}
         self._device = device
 
     def tensor(self):

@@ -107,3 +107,211 @@ def compute_training_step(model, audio, labels, *, grad_scale: float, seed: int,
     if apply_update and valid and model is not None:
         model.adamw_step(grads, lr_base=lr_base, step=step)
     return loss, scaled_loss, valid
+
+
+# ======================================================================================================
+# The device-resident data-parallel step (the form bench.py times and a training loop runs).
+#
+# Everything stays on the device between steps: gradients, loss and the finite flags live in ONE flat fp32
+# bucket, the collectives average it over the ranks, and the optimizer is gated by the all-reduced flag ON THE
+# DEVICE (amt_adamw_step_gated), so a step has no host synchronisation and can be replayed as hipGraphs.
+# bench.py, the gloo world-2 test (tests/test_dp_cpu.py) and a training loop all go through DataParallelStep, so
+# the protocol that is tested is the protocol that is timed.
+# ======================================================================================================
+
+class GradBucket:
+    """``[ valid_all, 0, 0, 0 | gradients (amt flat layout, n) | loss, valid_first ]`` in one fp32 buffer.
+
+    * ``valid_all``  : 1.0 iff every gradient of this rank's step is finite (train.py:320-322);
+    * ``valid_first``: the same flag for the first half of the two-phase step (decoder, transformer, final CNN norm);
+    * ``loss``       : mean over this rank's clips of the summed BCE (train.py:60-62).
+
+    The four head floats keep the gradient range 16-byte aligned.  After the mean all-reduce a flag is 1.0 iff it
+    was 1 on every rank, and loss / gradients are the means over the global batch (train.py:62)."""
+
+    HEAD = 4
+    TAIL = 2
+
+    def __init__(self, n_params: int, device):
+        self.n = int(n_params)
+        self.buf = torch.zeros(self.HEAD + self.n + self.TAIL, dtype=torch.float32, device=device)
+        self.head = self.buf[:self.HEAD]
+        self.grads = self.buf[self.HEAD:self.HEAD + self.n]
+        self.tail = self.buf[self.HEAD + self.n:]
+
+    def first_range(self, split: int) -> torch.Tensor:
+        """complete after phase 1: gradients [split, n), loss, valid_first"""
+        return self.buf[self.HEAD + split:]
+
+    def second_range(self, split: int) -> torch.Tensor:
+        """complete after phase 2: valid_all and gradients [0, split)"""
+        return self.buf[:self.HEAD + split]
+
+    @property
+    def valid_all(self) -> torch.Tensor:      # float32[1] view: the optimizer gate
+        return self.buf[0:1]
+
+
+class HipTrainBackend:
+    """Per-rank forward/backward/optimizer on the HIP library for fixed, device-resident inputs."""
+
+    def __init__(self, model, audio: torch.Tensor, labels: torch.Tensor, bucket: GradBucket, scale: float = 1.0,
+                 use_optimizer: bool = True):
+        self.model, self.audio, self.labels, self.bucket, self.scale = model, audio, labels, bucket, float(scale)
+        self.use_optimizer = use_optimizer
+        dev = audio.device
+        self.loss_buf = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.valid_buf = torch.ones(1, dtype=torch.int32, device=dev)
+        self.split = model.grad_bucket_split()
+        if use_optimizer:
+            model.init_optimizer()
+
+    def full(self, seed: int):
+        b = self.bucket
+        loss, _, valid, _ = self.model.loss_and_grads(self.audio, self.labels, scale=self.scale, seed=seed, train=True,
+                                                      grads_out=b.grads, sync=False)
+        b.tail[0] = loss[0]
+        b.tail[1] = valid[0].to(torch.float32)
+        b.head[0] = b.tail[1]
+
+    def half(self, phase: int, seed: int):
+        b = self.bucket
+        self.model.loss_and_grads_phase(phase, self.audio, self.labels, b.grads, self.loss_buf, self.valid_buf,
+                                        scale=self.scale, seed=seed, train=True)
+        if phase == 1:      # captured with the half: no eager launches between the graphs and the collectives
+            b.tail[0] = self.loss_buf[0]
+            b.tail[1] = self.valid_buf[0].to(torch.float32)
+        else:
+            b.head[0] = self.valid_buf[0].to(torch.float32)
+
+    def advance_seed(self):
+        self.model.advance_seed(1)
+
+    def apply(self, step: int, lr_base: float):
+        if self.use_optimizer:   # gated on the all-reduced flag, on the device
+            self.model.adamw_step(self.bucket.grads, lr_base=lr_base, step=step, valid_mean=self.bucket.valid_all)
+
+    def generation(self) -> int:
+        return self.model.plan_generation()
+
+
+class DataParallelStep:
+    """One optimizer step of the data-parallel loop (train.py:259-332 with the GSPMD all-reduce made explicit).
+
+    ``overlap=True``: the step runs in two halves (amt_forward_backward_phase); the collective of the range the
+    first half completes (37 of the 46 MB at the reference configuration, with the loss and the first flag behind
+    it) runs on a side stream while the second half (CNN backward) executes, the rest follows on the main stream:
+    two collectives per step.  ``overlap=False``: one collective over the whole bucket after the backward pass.
+    The reduction is a MEAN over ranks: ``ReduceOp.AVG`` where the backend has it (RCCL), SUM followed by a scale
+    of the same range otherwise (gloo).  On CUDA/HIP devices the per-rank work is captured into hipGraphs unless
+    ``graph=False``; the dropout seed of a replay is ``seed + seed_word`` with the device word advanced inside the
+    graph, so replays draw fresh masks."""
+
+    def __init__(self, backend, bucket: GradBucket, split: int, dist=None, overlap: bool = False, graph: bool = True,
+                 lr_base: float = 1e-4):
+        self.backend, self.bucket, self.split, self.dist = backend, bucket, int(split), dist
+        self.world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
+        self.overlap = bool(overlap)
+        self.lr_base = lr_base
+        self.cuda = bucket.buf.is_cuda
+        self.graph = bool(graph) and self.cuda
+        self.step_no = 0
+        self._graphs = None
+        self._gen = None
+        self._comm = torch.cuda.Stream(device=bucket.buf.device) if self.cuda else None
+        if self.overlap and self.world > 1 and not (0 < self.split < bucket.n):
+            raise ValueError("overlap needs 0 < split < n_params")
+        self._avg = None
+        if self.dist is not None and self.world >= 1 and self.dist.is_initialized():
+            self._avg = self.dist.ReduceOp.AVG if self.dist.get_backend() == "nccl" else None
+
+    # ---- collectives -------------------------------------------------------------------------------
+    def _mean_allreduce(self, t: torch.Tensor):
+        if self.dist is None or not self.dist.is_initialized():
+            return
+        if self._avg is not None:
+            self.dist.all_reduce(t, op=self._avg)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            t.mul_(1.0 / self.world)
+
+    # ---- capture -----------------------------------------------------------------------------------
+    def prepare(self, seed: int = 0):
+        """Run once eagerly (plans the workspace: every allocation happens here), then capture the graphs."""
+        be = self.backend
+        be.full(seed)
+        if self.overlap:
+            be.half(1, seed); be.half(2, seed)
+        if self.cuda:
+            torch.cuda.synchronize()
+        if not self.graph:
+            return
+        side = torch.cuda.Stream(device=self.bucket.buf.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up on a side stream, as torch's capture rules want
+            be.full(seed)
+            if self.overlap:
+                be.half(1, seed); be.half(2, seed)
+        torch.cuda.current_stream().wait_stream(side)
+        if self.overlap:
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                be.advance_seed()
+                be.half(1, seed)
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                be.half(2, seed)
+            self._graphs = (ga, gb)
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                be.advance_seed()
+                be.full(seed)
+            self._graphs = (g,)
+        self._gen = be.generation() if hasattr(be, "generation") else None
+
+    def _check_generation(self):
+        if self._graphs is not None and self._gen is not None and self.backend.generation() != self._gen:
+            raise RuntimeError("the workspace was re-planned after capture (amt_plan_generation changed): "
+                               "the captured graphs are stale, call prepare() again")
+
+    # ---- one step ----------------------------------------------------------------------------------
+    def step(self, seed: Optional[int] = None):
+        """Issue one step (asynchronous on a device).  ``seed`` is used by eager steps; graph replays advance the
+        device seed word instead."""
+        self.step_no += 1
+        be, b = self.backend, self.bucket
+        seed = self.step_no if seed is None else seed
+        self._check_generation()
+        if self.overlap:
+            if self._graphs is not None:
+                self._graphs[0].replay()
+            else:
+                be.half(1, seed)
+            if self.cuda:
+                main = torch.cuda.current_stream()
+                self._comm.wait_stream(main)
+                with torch.cuda.stream(self._comm):
+                    self._mean_allreduce(b.first_range(self.split))     # transformer + decoder range, loss, first flag
+            else:
+                self._mean_allreduce(b.first_range(self.split))
+            if self._graphs is not None:
+                self._graphs[1].replay()
+            else:
+                be.half(2, seed)
+            self._mean_allreduce(b.second_range(self.split))             # whole-step flag + CNN range
+            if self.cuda:
+                torch.cuda.current_stream().wait_stream(self._comm)
+        else:
+            if self._graphs is not None:
+                self._graphs[0].replay()
+            else:
+                be.full(seed)
+            if self.world > 1:
+                self._mean_allreduce(b.buf)                               # ONE bucket: flag, gradients, loss, flag
+        be.apply(self.step_no, self.lr_base)
+
+    def result(self) -> Tuple[float, bool]:
+        """(loss, grads_valid) of the last step; synchronises.  grads_valid is the AND over ranks and halves."""
+        v = self.bucket.buf[[0, self.bucket.HEAD + self.bucket.n, self.bucket.HEAD + self.bucket.n + 1]].tolist()
+        valid = v[0] >= 0.999 and v[2] >= 0.999
+        return float(v[1]), bool(valid)

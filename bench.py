@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -43,7 +44,7 @@ def log(*a):
 
 def cpu_baseline(seconds_budget: float = 25.0):
     """Oracle (torch-CPU fp32 restatement of the reference; JAX is unavailable offline) on the host
-    cores: fwd + bwd of B=2 x 10 s clips (the same per-step batch as one GPU)."""
+    cores: fwd + bwd of B=8 x 10 s clips (the same per-step batch as one GPU)."""
     from oracle import np_model, torch_model
     import audio_to_midi_amd as amt
     conf = np_model.MODEL_CONFIG
@@ -233,28 +234,14 @@ def main():
     audio_np, labels_np = amt.synth.make_batch_fast(B_PER_GPU, T_SAMPLES, seed=100 + rank)
     audio = torch.from_numpy(audio_np).to(dev, torch.bfloat16)       # inputs resident in HBM
     labels = torch.from_numpy(labels_np).to(dev)
-    # One flat fp32 bucket: [finite flag of the whole step, 3 pad | gradients (amt layout) | loss, finite flag of the
-    # first half].  The four head floats keep the gradient range 16-byte aligned.  With N > 1 the bucket is
-    # all-reduced with ReduceOp.AVG (mean over the global batch, train.py:62; a flag stays 1.0 iff every rank's is 1).
-    HEAD = 4
-    n = model.n_params
-    bucket = torch.zeros(HEAD + n + 2, dtype=torch.float32, device=dev)
-    gflat = bucket[HEAD: HEAD + n]
-    head, tail = bucket[:HEAD], bucket[HEAD + n:]
-    loss_buf = torch.zeros(2, dtype=torch.float32, device=dev)
-    step_no = [0]
-
-    last = {}
-
-    def fwd_bwd(seed):
-        loss, _, valid, _ = model.loss_and_grads(audio, labels, scale=1.0, seed=seed, train=True, grads_out=gflat,
-                                                 sync=False)
-        last["loss"], last["valid"] = loss, valid      # device tensors (static addresses under hipGraph replay)
-        if world > 1:                                  # loss + finite flag travel with the gradients
-            tail[0] = loss[0]
-            tail[1] = valid[0].to(torch.float32)
-            head[0] = tail[1]
-
+    # One flat fp32 bucket (audio_to_midi_amd.train.GradBucket): [finite flag of the whole step, 3 pad | gradients
+    # (amt layout) | loss, finite flag of the first half].  With N > 1 it is averaged over the ranks (ReduceOp.AVG:
+    # mean over the global batch, train.py:62; a flag stays 1.0 iff every rank's is 1).  The step itself - two-phase
+    # overlap, graph capture, collectives, device-gated AdamW - is audio_to_midi_amd.train.DataParallelStep, the same
+    # code the gloo world-2 test drives (tests/test_dp_cpu.py).
+    from audio_to_midi_amd import train as amt_train
+    bucket = amt_train.GradBucket(model.n_params, dev)
+    gflat = bucket.grads
     # N > 1: the step runs in two halves (include/amt.h: amt_forward_backward_phase).  The gradients of the
     # decoder + transformer + final CNN norm (37 of the 46 MB) are complete after the first half and their
     # all-reduce (with the loss and the first half's finite flag behind them) runs on a side stream while the CNN
@@ -266,66 +253,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    split = model.grad_bucket_split() if overlap else 0
-    valid_buf = torch.ones(1, dtype=torch.int32, device=dev)
-
-    def half(phase, seed):
-        model.loss_and_grads_phase(phase, audio, labels, gflat, loss_buf, valid_buf, scale=1.0, seed=seed, train=True)
-        if phase == 1:      # captured with the half: no eager launches between the graphs and the collectives
-            tail[0] = loss_buf[0]
-            tail[1] = valid_buf[0].to(torch.float32)
-        else:
-            head[0] = valid_buf[0].to(torch.float32)
-
-    # every allocation happens before graph capture: optimizer state, then the workspace plan
-    if not args.no_optimizer:
-        model.init_optimizer()
-    fwd_bwd(0)
-    torch.cuda.synchronize()
-    graph = graph_a = graph_b = None
-    side = torch.cuda.Stream(device=dev)
-    if not args.no_graph:
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            fwd_bwd(0)
-            if overlap:
-                half(1, 0); half(2, 0)
-        torch.cuda.current_stream().wait_stream(side)
-        if overlap:
-            graph_a, graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_a):
-                half(1, 12345)
-            with torch.cuda.graph(graph_b, pool=graph_a.pool()):
-                half(2, 12345)
-        else:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                fwd_bwd(12345)
-    comm = torch.cuda.Stream(device=dev)
-    avg = dist.ReduceOp.AVG if dist is not None else None
+    backend = amt_train.HipTrainBackend(model, audio, labels, bucket, scale=1.0, use_optimizer=not args.no_optimizer)
+    dp = amt_train.DataParallelStep(backend, bucket, backend.split, dist=dist, overlap=overlap, graph=not args.no_graph,
+                                    lr_base=1e-4)
+    dp.prepare(seed=12345)       # every allocation (optimizer state, workspace plan) happens before graph capture
+    graph = dp._graphs
 
     def one_step():
-        step_no[0] += 1
-        if overlap:
-            main = torch.cuda.current_stream()
-            if graph_a is not None: graph_a.replay()
-            else: half(1, step_no[0])
-            comm.wait_stream(main)
-            with torch.cuda.stream(comm):
-                dist.all_reduce(bucket[HEAD + split:], op=avg)      # transformer + decoder range, loss, first flag
-            if graph_b is not None: graph_b.replay()
-            else: half(2, step_no[0])
-            dist.all_reduce(bucket[:HEAD + split], op=avg)           # whole-step flag + CNN range
-            main.wait_stream(comm)
-        else:
-            if graph is not None:
-                graph.replay()
-            else:
-                fwd_bwd(step_no[0])
-            if world > 1:
-                dist.all_reduce(bucket, op=avg)                      # ONE bucket: flag, gradients, loss, flag
-        if not args.no_optimizer:
-            model.adamw_step(gflat, lr_base=1e-4, step=step_no[0])
+        dp.step()
 
     for _ in range(args.warmup):
         one_step()
@@ -347,16 +282,20 @@ def main():
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B_PER_GPU * CLIP_SECONDS / (elapsed / args.steps)
-    loss_val = float(loss_buf[0].item()) if overlap else float(last["loss"][0].item())
+    loss_val, grads_valid = dp.result()
+    # a non-finite step would have been skipped on the device (gated AdamW); the timed run must not contain one
+    if not (math.isfinite(loss_val) and grads_valid):
+        raise SystemExit(f"bench: non-finite step in the timed run (loss {loss_val}, grads_valid {grads_valid})")
+    if model.team_status() != 0:
+        raise SystemExit("bench: an XCD-team launch timed out (amt_team_status != 0)")
 
     # ---- roofline leg: per-kernel HIP-event timing on the launch stream (eager, extra steps)
     roofline, breakdown = None, []
     if rank == 0 and args.profile_steps > 0:
         amtlib.profile_begin()
         for i in range(args.profile_steps):
-            fwd_bwd(1000 + i)
-            if not args.no_optimizer:
-                model.adamw_step(gflat, lr_base=1e-4, step=step_no[0] + 1 + i)
+            backend.full(1000 + i)
+            backend.apply(dp.step_no + 1 + i, 1e-4)
         ents = amtlib.profile_end()
         tot = sum(e["total_ms"] for e in ents) or 1.0
         ents.sort(key=lambda e: -e["total_ms"])
@@ -409,11 +348,11 @@ def main():
                                    "GPU, train mode (dropout 0.1)" + (", global-attention forward on fp8 MFMA" if args.attn_fp8 else "") + (", RCCL all-reduce of the fp32 grad bucket" if world > 1 else "")
                                    + ("" if args.no_optimizer else ", AdamW + global-norm clip + bf16 weight refresh"),
                        "global_batch": world * B_PER_GPU, "clip_seconds": CLIP_SECONDS, "frames": T_SAMPLES // 320,
-                       "parallelism": f"dp{world}", "hipgraph": (graph is not None) or (graph_a is not None),
+                       "parallelism": f"dp{world}", "hipgraph": graph is not None,
                        "grad_allreduce": ("two collectives (ReduceOp.AVG), the first overlapped with the CNN backward" if overlap else "one bucket (ReduceOp.AVG)") if world > 1 or overlap else None,
                        "weights": "random init (Equinox distributions), 11606230 params"},
             "model_tflops": round(world * FLOPS_PER_STEP / (elapsed / args.steps) / 1e12, 2),
-            "loss": round(loss_val, 3),
+            "loss": round(loss_val, 3), "grads_valid": bool(grads_valid), "loss_finite": True,
             "roofline": roofline,
             "rooflines": named_rooflines(breakdown, args.profile_steps) if breakdown else None,
             "cpu_baseline": cpu,

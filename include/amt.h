@@ -139,6 +139,15 @@ uint64_t amt_workspace_bytes(const amt_ctx* ctx);
  * amt_plan_generation() changes exactly then.  Record it at capture time and re-capture when it differs. */
 uint64_t amt_plan_generation(const amt_ctx* ctx);
 
+/* Dropout seed under hipGraph replay.  `seed` is a by-value kernel argument, so a captured step would replay the masks
+ * it was captured with.  Every mask is therefore drawn from seed + *amt_seed_word(ctx): a device uint64 owned by the
+ * context (0 after amt_create).  Change it between replays with a copy to that address or with amt_advance_seed, a
+ * one-thread kernel (*word += delta) that may itself be captured as the first node of the step: each replay then draws
+ * fresh masks with no host involvement.  Backward regenerates the forward masks from the same word, so the word must
+ * not change between the forward and the backward pass of one step. */
+uint64_t* amt_seed_word(amt_ctx* ctx);
+int32_t amt_advance_seed(amt_ctx* ctx, uint64_t delta, void* stream);
+
 /* In-launch XCD-team hand-offs (csrc/team.h) spin with a bound.  0 = none has ever given up in this context; non-zero =
  * a launch timed out (its outputs are undefined and every later team launch falls through): treat as fatal.
  * Host-synchronous read. */

@@ -379,3 +379,137 @@ def test_gradient_buffer_alignment_and_fp8_under_graph_replay(small_conf):
     assert bool(torch.isfinite(g).all())
     assert float((g - eager.grads_flat).norm() / eager.grads_flat.norm()) < 2e-2
     assert float((g - ref.grads_flat).norm() / ref.grads_flat.norm()) < 5e-2
+
+
+# ------------------------------------------------------------------ round 2: device gate, device seed, re-planning, teams
+def test_adamw_is_gated_on_device_flags_and_rejects_step_zero(small_conf):
+    """amt_adamw_step_gated: a closed gate (int flag 0, or float flag < 1 after the mean all-reduce, or NaN) leaves
+    parameters, m and v untouched (the skip of train.py:369-377 without a host sync); step < 1 is an error (the
+    bias corrections 1 - b^step would be zero)."""
+    model = amt.OutputSequenceGenerator(small_conf, key=5, dtype="float32", gamma=1.0)
+    model.init_optimizer()
+    g = torch.randn(model.n_params, device="cuda") * 1e-2
+    p0 = model.weights_tensor().clone()
+    zero_i = torch.zeros(1, dtype=torch.int32, device="cuda")
+    one_i = torch.ones(1, dtype=torch.int32, device="cuda")
+    for gate in (dict(valid=zero_i), dict(valid_mean=torch.tensor([0.875], device="cuda")),
+                 dict(valid_mean=torch.tensor([float("nan")], device="cuda")),
+                 dict(valid=one_i, valid_mean=torch.tensor([0.5], device="cuda"))):
+        model.adamw_step(g, lr_base=1e-3, step=1, **gate)
+        torch.cuda.synchronize()
+        assert torch.equal(model.weights_tensor(), p0), gate
+    # open gate: the first step of an untouched optimizer state must equal an ungated first step on a twin model
+    twin = amt.OutputSequenceGenerator(small_conf, key=5, dtype="float32", gamma=1.0)
+    twin.adamw_step(g, lr_base=1e-3, step=1)
+    model.adamw_step(g, lr_base=1e-3, step=1, valid=one_i, valid_mean=torch.tensor([1.0], device="cuda"))
+    torch.cuda.synchronize()
+    assert not torch.equal(model.weights_tensor(), p0)
+    # closed gates had left m and v untouched (the global-norm sum is an atomic reduction: last-bit differences only)
+    assert float((model.weights_tensor() - twin.weights_tensor()).abs().max()) < 1e-6
+    with pytest.raises(RuntimeError):
+        model.adamw_step(g, lr_base=1e-3, step=0)
+
+
+def test_device_seed_word_gives_fresh_masks_under_graph_replay(small_conf):
+    """Dropout masks are drawn from seed + *amt_seed_word: a captured step whose first node advances the word draws
+    fresh masks on every replay, and replay k equals the eager step with seed + k."""
+    model = amt.OutputSequenceGenerator(small_conf, key=6, dtype="bfloat16", gamma=1.0)
+    audio, labels = synth.make_batch(2, 320 * 64, seed=4)
+    a, y = torch.from_numpy(audio).to("cuda", torch.bfloat16), torch.from_numpy(labels).cuda()
+    gbuf = torch.zeros(model.n_params, dtype=torch.float32, device="cuda")
+    word = model.seed_word()
+    assert int(word.item()) == 0
+
+    def eager(seed):
+        word.zero_()
+        out = model.loss_and_grads(a, y, seed=seed, train=True)
+        return out.loss, out.grads_flat.clone()
+
+    refs = [eager(100 + k) for k in range(1, 4)]
+    assert abs(refs[0][0] - refs[1][0]) > 0 and float((refs[0][1] - refs[1][1]).norm()) > 0   # masks do differ
+    word.zero_()
+
+    def step():
+        model.advance_seed(1)
+        return model.loss_and_grads(a, y, seed=100, train=True, grads_out=gbuf, sync=False)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    word.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = step()
+    for k in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(word.item()) == k + 1
+        assert abs(float(out[0][0]) - refs[k][0]) <= 1e-5 * abs(refs[k][0])
+        assert float((gbuf - refs[k][1]).norm() / refs[k][1].norm()) < 1e-4
+
+
+def test_replanning_between_known_shapes_keeps_a_captured_step_valid(small_conf):
+    """an eager call at another shape followed by the replay of a graph captured earlier must not touch
+    freed memory.  Shapes planned once keep their plan: alternating predict(B1, T1) and loss_and_grads(B2, T2)
+    allocates nothing (amt_plan_generation constant) and the captured step keeps reproducing the eager result; a
+    first-time LARGER shape does replace the workspace, and the generation counter says so."""
+    model = amt.OutputSequenceGenerator(small_conf, key=8, dtype="bfloat16", gamma=1.0)
+    audio, labels = synth.make_batch(3, 320 * 80, seed=7)
+    a, y = torch.from_numpy(audio).to("cuda", torch.bfloat16), torch.from_numpy(labels).cuda()
+    small_audio = torch.from_numpy(synth.make_batch(2, 320 * 48, seed=1)[0]).to("cuda", torch.bfloat16)
+    gbuf = torch.zeros(model.n_params, dtype=torch.float32, device="cuda")
+
+    def step():
+        return model.loss_and_grads(a, y, seed=9, train=True, grads_out=gbuf, sync=False)
+
+    model.predict(None, small_audio)           # plan (2, 48 frames, inference)
+    step(); torch.cuda.synchronize()           # plan (3, 80 frames, training)
+    ref = gbuf.clone()
+    gen = model.plan_generation()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    logits_ref = model.predict(None, small_audio)[0].clone()
+    for _ in range(3):
+        lg, _ = model.predict(None, small_audio)             # eager, other shape, other mode: re-plans (cached)
+        assert torch.equal(lg, logits_ref)
+        gbuf.fill_(-5.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert float((gbuf - ref).norm() / ref.norm()) < 1e-5
+        assert model.plan_generation() == gen
+    big = torch.from_numpy(synth.make_batch(6, 320 * 160, seed=2)[0]).to("cuda", torch.bfloat16)
+    big_y = torch.from_numpy(synth.make_batch(6, 320 * 160, seed=2)[1]).cuda()
+    model.loss_and_grads(big, big_y, seed=1, train=True)     # needs a larger workspace: the old one is replaced
+    assert model.plan_generation() != gen                    # ... and graphs captured before are stale: re-capture
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_team_run_equals_one_launch_per_block(dtype, monkeypatch):
+    """XCD-team form of the CNN stages (csrc/team.h, chain.hip: block_run_fwd, opt-in AMT_TEAM=1): the Blocks of a stage
+    in ONE launch, hand-offs through the XCD's L2.  Same tile body: logits, loss and every gradient bit-identical to
+    the one-launch-per-Block path; clips that do not fill the 8 teams, stages that straddle tiles and several clips
+    per team included; no hand-off timed out."""
+    conf = dict(np_model.MODEL_CONFIG)
+    conf["depths"] = [1, 1, 2, 2, 3, 4, 2]
+    conf["num_transformer_layers"] = 1
+    outs = {}
+    for B, S in ((3, 50), (11, 32)):
+        audio, labels = synth.make_batch(B, 320 * S, seed=13)
+        for team in ("0", "1"):
+            monkeypatch.setenv("AMT_TEAM", team)
+            model = amt.OutputSequenceGenerator(conf, key=21, dtype=dtype, gamma=1.0)
+            out = model.loss_and_grads(torch.from_numpy(audio), torch.from_numpy(labels), seed=3, train=True,
+                                       return_logits=True)
+            assert out.grads_valid and model.team_status() == 0
+            outs[team] = (out.loss, out.logits.clone(), out.grads_flat.clone())
+        assert torch.equal(outs["0"][1], outs["1"][1])                                     # forward: bit for bit
+        assert abs(outs["0"][0] - outs["1"][0]) <= 1e-6 * abs(outs["0"][0])                 # loss: an atomic sum
+        assert float((outs["0"][2] - outs["1"][2]).norm() / outs["0"][2].norm()) < 1e-5   # backward: fp32 atomics order
