@@ -197,8 +197,40 @@ def _layer_source(conf, li):
     return li // 2, _tnames(kind)
 
 
-def equinox_to_flat(p: Dict[str, np.ndarray], conf) -> np.ndarray:
-    """Equinox-view dict -> flat fp32 vector in device layout."""
+def validate_equinox(p: Dict[str, np.ndarray], conf, ensemble_select=None) -> "OrderedDict[str, np.ndarray]":
+    """Check a dict of reference leaves against ``equinox_shapes(conf)`` and return it with exactly those shapes.
+
+    The reference trains an ENSEMBLE: every array leaf of its checkpoints carries a leading ensemble axis
+    (train.py:259-264 vmaps the step over it; infer.py:213-224 selects ``x[ensemble_select]`` after restoring).
+    ``ensemble_select=None`` expects leaves without that axis; an integer selects that member from leaves that have
+    it (leaves that already have the plain shape are accepted as they are).  Anything else raises: a missing or
+    unexpected key, a leaf whose shape is neither the expected one nor (E,) + expected - so a transposed weight of
+    equal size, which a bare ``reshape(-1)`` would take silently, is an error here."""
+    shapes = equinox_shapes(conf)
+    missing = [k for k in shapes if k not in p]
+    extra = [k for k in p if k not in shapes]
+    if missing or extra:
+        raise KeyError(f"parameter dict does not match the model: missing {missing[:4]}{'...' if len(missing) > 4 else ''}, "
+                       f"unexpected {extra[:4]}{'...' if len(extra) > 4 else ''}")
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for k, shp in shapes.items():
+        v = np.asarray(p[k])
+        if tuple(v.shape) == tuple(shp):
+            out[k] = v
+        elif ensemble_select is not None and v.ndim == len(shp) + 1 and tuple(v.shape[1:]) == tuple(shp):
+            if not (-v.shape[0] <= ensemble_select < v.shape[0]):
+                raise IndexError(f"{k}: ensemble_select={ensemble_select} but the leaf holds {v.shape[0]} members")
+            out[k] = v[ensemble_select]
+        else:
+            hint = " (leading ensemble axis? pass ensemble_select)" if v.ndim == len(shp) + 1 and tuple(v.shape[1:]) == tuple(shp) else ""
+            raise ValueError(f"{k}: shape {tuple(v.shape)}, expected {tuple(shp)}{hint}")
+    return out
+
+
+def equinox_to_flat(p: Dict[str, np.ndarray], conf, ensemble_select=None) -> np.ndarray:
+    """Equinox-view dict -> flat fp32 vector in device layout.  Every leaf is shape-checked first
+    (``validate_equinox``); ``ensemble_select`` strips the reference checkpoints' leading ensemble axis."""
+    p = validate_equinox(p, conf, ensemble_select)
     inter = int(conf["dims"][-1] * conf["transformer_hidden_expansion"])
     perm = glu_row_perm(inter)
     segs = device_layout(conf)

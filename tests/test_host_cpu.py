@@ -97,3 +97,56 @@ def test_synthetic_inputs_follow_the_data_contract():
     assert np.allclose((a.astype(np.float64) ** 2).mean(axis=(1, 2)), 1.0, atol=2e-3)
     assert np.array_equal(a, a.astype(np.float16).astype(np.float32))
     assert y.min() >= 0.005 and y.max() <= 0.995 and np.all(y[:, :, 88:] == np.float32(0.005))
+
+
+def test_checkpoint_leaves_are_validated_and_the_ensemble_axis_is_handled(tmp_path):
+    """reference checkpoints carry a leading ensemble axis on every leaf (infer.py:213-224) and a
+    wrong-layout leaf of equal size must not be accepted silently."""
+    import numpy as np
+    from audio_to_midi_amd import convert_orbax, infer
+    from audio_to_midi_amd import params as P
+    from oracle import np_model
+    conf = dict(np_model.MODEL_CONFIG)
+    conf["depths"] = [1, 1, 1, 1, 1, 2, 1]
+    conf["num_transformer_layers"] = 1
+    p = P.init_equinox(conf, seed=5)
+    flat = P.equinox_to_flat(p, conf)
+    # ensemble axis: member k is selected, plain leaves pass through, a missing selection is an error
+    ens = {k: np.stack([v, 3 * v]) for k, v in p.items()}
+    assert np.array_equal(P.equinox_to_flat(ens, conf, ensemble_select=0), flat)
+    assert np.array_equal(P.equinox_to_flat(ens, conf, ensemble_select=1), 3 * flat)
+    with pytest.raises(ValueError, match="ensemble"):
+        P.equinox_to_flat(ens, conf)
+    with pytest.raises(IndexError):
+        P.equinox_to_flat(ens, conf, ensemble_select=2)
+    # a transposed weight has the right SIZE and the wrong layout
+    bad = dict(p)
+    k = "layers.5.1.point_conv_1.weight"
+    bad[k] = np.transpose(bad[k], (1, 0, 2))
+    with pytest.raises(ValueError, match="point_conv_1"):
+        P.equinox_to_flat(bad, conf)
+    missing = dict(p); missing.pop("norm.bias")
+    with pytest.raises(KeyError):
+        P.equinox_to_flat(missing, conf)
+    extra = dict(p); extra["layers.9.0.conv.weight"] = np.zeros(3)
+    with pytest.raises(KeyError):
+        P.equinox_to_flat(extra, conf)
+    # the converter's pytree flattening: nested dicts / sequences as Orbax restores them, None leaves dropped
+    tree = {}
+    for name, v in ens.items():
+        node = tree
+        parts = name.split(".")
+        for q in parts[:-1]:
+            node = node.setdefault(q, {})
+        node[parts[-1]] = v
+    tree["layers"]["0"]["0"]["norm"]["eps"] = None
+    tree["layers"] = [tree["layers"][str(i)] for i in range(len(tree["layers"]))]      # a sequence node
+    leaves = convert_orbax.flatten_tree(tree)
+    assert set(leaves) == set(p)
+    assert np.array_equal(convert_orbax.leaves_to_flat(leaves, conf, ensemble_select=1), 3 * flat)
+    back = convert_orbax.flat_to_leaves(flat, conf)
+    assert all(back[k].shape == (1,) + p[k].shape and np.array_equal(back[k][0], p[k]) for k in p)
+    # flat file round trip
+    infer.save_checkpoint(str(tmp_path), flat, conf, step=7)
+    f2, c2, s2 = infer.load_checkpoint(str(tmp_path))
+    assert np.array_equal(f2, flat) and s2 == 7 and c2["depths"] == conf["depths"]
