@@ -95,7 +95,7 @@ AMT_DEV void block_fwd_tile(const BlockFwdArgs& a_in, const long n0, const long 
   T* Hs = Rs + TT * LDX;                               // [TT][LDH]  gelu(u)
   T* Us = Hs + TT * LDH;                               // [TT][LDH]  u (staged for a coalesced copy-out; SAVE only)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // (& 255: the team form runs two tiles per workgroup, 256 threads each)
   const int r = lane & 15, g = lane >> 4;
   const long N = Nlim;
   const T* X = reinterpret_cast<const T*>(a.X);
@@ -266,12 +266,17 @@ __global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
 // XCD-team form (team.h): the n Blocks of a CNN stage in ONE launch.  Clip b belongs to one XCD's team; Block j of
 // every clip of the team is evaluated tile by tile (the same tile body as above), then the team meets at its barrier:
 // the halo rows of Block j + 1 come from the neighbouring workgroups' stores, which are in the XCD's L2.
-template <typename T, int C, int TT>
-__global__ __launch_bounds__(256) void block_run_fwd_kernel(BlockRunFwdArgs r) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+// NG wave groups of 256 threads per workgroup, each on a tile of its own (own LDS panels): with one workgroup per compute
+// unit, two 16-row tiles side by side hide each other's latencies the way two co-resident workgroups of the
+// one-launch-per-Block kernel do (one 32-row tile per 256 threads ran 8.2 us against 6.1 us, profiles/r02_notes.md).
+template <typename T, int C, int TT, int NG>
+__global__ __launch_bounds__(256 * NG) void block_run_fwd_kernel(BlockRunFwdArgs r) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem_all[];
+  constexpr size_t LDS_TILE = sizeof(T) * (size_t)TT * (2 * (C + 8) + 2 * (2 * C + 8));
+  const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  unsigned char* chain_smem = chain_smem_all + (size_t)grp * LDS_TILE;
   // The kernel-argument segment lives in HOST memory (HIP default): a scalar load from it is a PCIe round trip.  An
-  // ordinary kernel pays that once, before its first instruction; reading item j at the top of every Block made every
-  // team barrier look 6-7 us long (profiles/r02_notes.md).  So: one cooperative copy of all items into LDS, up front.
+  // ordinary kernel pays that once, before its first instruction; here all items are copied into LDS up front.
   __shared__ BlockRunFwdItem s_it[BLOCK_RUN_MAX];
 #if defined(__HIP_DEVICE_COMPILE__)
   {
@@ -279,14 +284,10 @@ __global__ __launch_bounds__(256) void block_run_fwd_kernel(BlockRunFwdArgs r) {
     KernArg64 ka = (KernArg64)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int W0 = (int)(offsetof(BlockRunFwdArgs, it) / 8), WPI = (int)(sizeof(BlockRunFwdItem) / 8);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(s_it);
-    for (int i = threadIdx.x; i < r.n * WPI; i += 256) dst[i] = ka[W0 + i];
+    for (int i = threadIdx.x; i < r.n * WPI; i += 256 * NG) dst[i] = ka[W0 + i];
   }
 #endif
-#ifdef AMT_CHAIN_TIMING
-  unsigned long long t_left = 0, c_left = 0, c_spin = 0;
-  __shared__ unsigned long long s_dbg_loop;
-#endif
-  __shared__ __attribute__((aligned(16))) unsigned char s_warm[4096];   // landing zone of team_warm, never read
+  __shared__ __attribute__((aligned(16))) unsigned char s_warm[1024 * 4 * NG];   // landing zone of team_warm, never read
   constexpr size_t WBYTES = chain_packed_elems(2 * C, C) * sizeof(T);    // == chain_packed_elems(C, 2 * C): W1 and W2
   const TeamTicket ticket = team_register(r.st);   // (its barrier orders the copy above before the first read below)
   {   // the first Block's weights, while the other workgroups are still arriving (assumes the usual 8 even teams: speed only)
@@ -300,84 +301,39 @@ __global__ __launch_bounds__(256) void block_run_fwd_kernel(BlockRunFwdArgs r) {
 #pragma unroll 1
     for (int j = 0; j < r.n; ++j) {
       BlockFwdArgs a;
-#ifdef AMT_TEAM_KERNARG_ITEMS   // experiment: items straight from the kernel-argument segment (global_* accesses, host-memory scalar loads)
-      const BlockRunFwdItem it = r.it[j];
-      a.X = j == 0 ? r.X0 : r.it[j - 1].Y;
-      a.wdw = it.wdw; a.bdw = it.bdw; a.lnw = it.lnw; a.lnb = it.lnb; a.W1 = it.W1; a.b1 = it.b1; a.W2 = it.W2; a.b2 = it.b2;
-      a.gamma = it.gamma; a.LN = it.LN; a.mean = it.mean; a.rstd = it.rstd; a.U = it.U; a.Hh = it.Hh; a.Z = it.Z; a.Y = it.Y;
-#else
       const BlockRunFwdItem& it = s_it[j];
       a.X = j == 0 ? r.X0 : team_uniform(s_it[j - 1].Y);
       a.wdw = team_uniform(it.wdw); a.bdw = team_uniform(it.bdw); a.lnw = team_uniform(it.lnw); a.lnb = team_uniform(it.lnb);
       a.W1 = team_uniform(it.W1); a.b1 = team_uniform(it.b1); a.W2 = team_uniform(it.W2); a.b2 = team_uniform(it.b2);
       a.gamma = team_uniform(it.gamma); a.LN = team_uniform(it.LN); a.mean = team_uniform(it.mean); a.rstd = team_uniform(it.rstd);
       a.U = team_uniform(it.U); a.Hh = team_uniform(it.Hh); a.Z = team_uniform(it.Z); a.Y = team_uniform(it.Y);
-#endif
       a.B = r.B; a.L = r.L; a.C = C; a.dbg_slot = r.dbg_base + j;
-#ifdef AMT_CHAIN_TIMING
-      if (!(r.dbg_base & 8192))
-#endif
       if (j + 1 < r.n) {   // the next Block's weights depend on nothing: into L2 now, each line requested by one member
         team_warm(team_uniform(s_it[j + 1].W1), WBYTES, t.rank, t.size, s_warm);
         team_warm(team_uniform(s_it[j + 1].W2), WBYTES, t.rank, t.size, s_warm);
       }
-#ifdef AMT_CHAIN_TIMING
-      asm volatile("" :: "s"(a.Y), "s"(a.W1), "s"(a.X) : "memory");
-      const unsigned long long c_items = __builtin_readcyclecounter();   // the LDS reads of this Block's pointers are done
-#endif
 #pragma unroll 1
       for (int clip = t.index; clip < r.B; clip += t.n_teams)
 #pragma unroll 1
-        for (int tile = t.rank; tile < tiles_per_clip; tile += t.size) {
+        for (int base = t.rank * NG; base < tiles_per_clip; base += t.size * NG) {
           // opaque copies: without them the compiler strength-reduces every address of the tile body over these
-          // two loops (dozens of 64-bit induction pointers in VGPRs: 256 registers + scratch at C = 256)
-          // (the parameter pointers too: hoisting a Block's weight / bias loads out of the tile loop keeps them live
-          // across the whole body)
-          int cl = clip, tl = tile;
-#ifdef AMT_CHAIN_TIMING
-          if (r.dbg_base & 32768) tl = tiles_per_clip - 1 - tile;   // experiment: reversed tile assignment
-          const unsigned long long c_loop = __builtin_readcyclecounter();   // top of the tile loop body
-          if (threadIdx.x == 0 && blockIdx.x < 256) s_dbg_loop = c_loop;
-#endif
+          // two loops (dozens of 64-bit induction pointers in VGPRs) and hoists a Block's weight / bias loads out of
+          // the tile loop, which keeps them live across the whole body
+          int cl = clip, tl = base;
           BlockFwdArgs at = a;
-#ifdef AMT_TEAM_KERNARG_ITEMS
-          asm volatile("" : "+s"(cl), "+s"(tl));
-#else
           asm volatile("" : "+s"(cl), "+s"(tl), "+s"(at.X), "+s"(at.wdw), "+s"(at.bdw), "+s"(at.lnw), "+s"(at.lnb), "+s"(at.W1),
                        "+s"(at.b1), "+s"(at.W2), "+s"(at.b2), "+s"(at.gamma));
-#endif
-#ifdef AMT_CHAIN_TIMING
-          if (r.dbg_base & 2048)   // timing experiment only (wrong results): plain loads of X
-            block_fwd_tile<T, C, TT, true, false>(at, (long)cl * r.L + (long)tl * TT, (long)(cl + 1) * r.L, chain_smem);
-          else
-#endif
-          block_fwd_tile<T, C, TT, true, true>(at, (long)cl * r.L + (long)tl * TT, (long)(cl + 1) * r.L, chain_smem);
-#ifdef AMT_CHAIN_TIMING
-          if (threadIdx.x == 0 && blockIdx.x < 256) amt_stamps[a.dbg_slot & 127][blockIdx.x][4] = s_dbg_loop;
-#endif
+          tl += grp;
+          // a wave group without a tile of its own (odd tile count) runs the body on an empty tile: every row is padding,
+          // nothing is stored, and it keeps meeting the other group at the body's workgroup barriers
+          const long nlim = (long)(cl + 1) * r.L;
+          const long n0 = tl < tiles_per_clip ? (long)cl * r.L + (long)tl * TT : nlim;
+          block_fwd_tile<T, C, TT, true, true>(at, n0, nlim, chain_smem);
           __syncthreads();   // the tile's LDS panels are rewritten by the next tile
         }
-#ifdef AMT_CHAIN_TIMING
-      if (threadIdx.x == 0 && blockIdx.x < 256) {
-        amt_stamps[a.dbg_slot & 127][blockIdx.x][8] = wall_clock64();
-        amt_stamps[a.dbg_slot & 127][blockIdx.x][11] = c_items;
-        if (j > 0) { amt_stamps[(a.dbg_slot - 1) & 127][blockIdx.x][9] = t_left; amt_stamps[(a.dbg_slot - 1) & 127][blockIdx.x][10] = c_left; if (r.dbg_base & 16384) amt_stamps[(a.dbg_slot - 1) & 127][blockIdx.x][5] = c_spin; }
-      }
-#endif
       if (j + 1 < r.n && !team_barrier(r.st, t)) break;
-#ifdef AMT_CHAIN_TIMING
-      t_left = wall_clock64();   // stored after the NEXT Block's tiles: no vector-memory instruction between here and the tile
-      c_left = __builtin_readcyclecounter();
-      if (r.dbg_base & 16384) {   // experiment: 2000 s_nop 3 (no memory, no LDS) right after the barrier
-        for (int i = 0; i < 2000; ++i) asm volatile("s_nop 3");
-        c_spin = __builtin_readcyclecounter();
-      }
-#endif
     }
   }
-#ifdef AMT_CHAIN_TIMING
-  if (threadIdx.x == 0 && blockIdx.x < 256 && C == 128) amt_stamps[126][blockIdx.x][0] = (unsigned long long)(t.rank | (t.xcc << 8) | (t.size << 16)) + (1ull << 32);
-#endif
   team_leave(r.st, t);
 }
 
@@ -422,39 +378,32 @@ int team_state_timeout(const TeamState* st) {
   return (int)v;
 }
 
-template <typename T, int C, int TT>
+template <typename T, int C, int TT, int NG>
 static void block_run_fwd_launch_tt(hipStream_t s, const BlockRunFwdArgs& r, int grid) {
-  constexpr size_t lds = sizeof(T) * (size_t)TT * (2 * (C + 8) + 2 * (2 * C + 8));
-  static_assert(lds <= 156 * 1024, "LDS budget");
+  constexpr size_t lds = NG * sizeof(T) * (size_t)TT * (2 * (C + 8) + 2 * (2 * C + 8));
+  static_assert(lds <= 150 * 1024, "LDS budget");
   static bool once = (lds > 64 * 1024
-                          ? (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block_run_fwd_kernel<T, C, TT>),
+                          ? (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block_run_fwd_kernel<T, C, TT, NG>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                           : (void)0,
                       true);
   (void)once;
-#ifdef AMT_CHAIN_TIMING
-  BlockRunFwdArgs rr = r;
-  if (const char* e = getenv("AMT_DBG_NOSTORE")) rr.dbg_base |= atoi(e);   // 256: no u/h, 512: no z, 1024: no LN (timing only)
-  hipLaunchKernelGGL((block_run_fwd_kernel<T, C, TT>), dim3(grid), dim3(256), lds, s, rr);
-  return;
-#endif
-  hipLaunchKernelGGL((block_run_fwd_kernel<T, C, TT>), dim3(grid), dim3(256), lds, s, r);
+  hipLaunchKernelGGL((block_run_fwd_kernel<T, C, TT, NG>), dim3(grid), dim3(256 * NG), lds, s, r);
 }
 
-// Tile length of the team form: a clip's rows are shared by the ~grid / 8 workgroups of one XCD, and every tile pays the
-// same latency chain (operand round trip, LayerNorm, two GEMM stages, stores) and streams the Block's weights once.  With
-// the one-launch-per-Block tile (16 rows at C = 128) a 10-s clip has 63 tiles for 32 workgroups: two dependent tiles per
-// Block and workgroup.  Twice the tile = one tile each, half the weight stream per row.  Results do not depend on the tile.
+// How a clip's rows are shared by the ~grid / 8 workgroups of one XCD: two wave groups per workgroup, each on its own
+// tile of the one-launch-per-Block length (a 10-s clip at C = 128: 63 tiles of 16 rows for 32 x 2 groups), as long as
+// two tiles' LDS panels fit; otherwise one group.  Results do not depend on the choice (rows are independent).
 template <typename T, int C>
 static void block_run_fwd_launch(hipStream_t s, const BlockRunFwdArgs& r, int grid) {
-  constexpr int TT0 = BlockTile<C>::TT;
-  constexpr bool fits2 = sizeof(T) * (size_t)(2 * TT0) * (2 * (C + 8) + 2 * (2 * C + 8)) <= 156 * 1024;
-  const int members = grid / TEAM_MAX > 0 ? grid / TEAM_MAX : 1;
-  const int tiles0 = (r.L + TT0 - 1) / TT0;
+  constexpr int TT = BlockTile<C>::TT;
+  // (C = 256: two groups leave 256 registers per wave and the body spills)
+  constexpr bool fits2 = C <= 128 && 2 * sizeof(T) * (size_t)TT * (2 * (C + 8) + 2 * (2 * C + 8)) <= 150 * 1024;
+  static const int ng_env = getenv("AMT_TEAM_NG") ? atoi(getenv("AMT_TEAM_NG")) : 0;   // experiments: force 1 or 2
   if constexpr (fits2) {
-    if (tiles0 > members) { block_run_fwd_launch_tt<T, C, 2 * TT0>(s, r, grid); return; }
+    if (ng_env != 1) { block_run_fwd_launch_tt<T, C, TT, 2>(s, r, grid); return; }
   }
-  block_run_fwd_launch_tt<T, C, TT0>(s, r, grid);
+  block_run_fwd_launch_tt<T, C, TT, 1>(s, r, grid);
 }
 
 bool block_run_fwd(hipStream_t s, DType dt, const BlockRunFwdArgs& r) {

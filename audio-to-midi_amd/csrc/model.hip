@@ -320,7 +320,7 @@ struct amt_ctx {
   float* amax = nullptr;        // [layers][prev q,k,v,- | cur q,k,v,-]: delayed per-tensor scaling state
   uint64_t* seed_word = nullptr;   // device word added to every dropout seed (amt_seed_word / amt_advance_seed)
   TeamState* team = nullptr;    // XCD-team protocol words (team.h); null: team launches disabled (AMT_TEAM=0)
-  bool fuse_ffn = false;        // AMT_FUSE_FFN=1: whole second half of a layer in one launch (measured slower)
+  bool fuse_ffn = true;         // AMT_FUSE_FFN=0: second half of a layer as chain + two tiled GEMM launches
 
   const float* P(size_t off) const { return params + off; }
   const void* WC(size_t off) const { return static_cast<const char*>(wc) + off * esz; }
@@ -1219,7 +1219,10 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   c->use_side = getenv("AMT_SIDE_STREAM") != nullptr;
   c->fuse = !(getenv("AMT_FUSE") && atoi(getenv("AMT_FUSE")) == 0);
   c->nochain = getenv("AMT_NOCHAIN") ? atoi(getenv("AMT_NOCHAIN")) : 0;
-  c->fuse_ffn = getenv("AMT_FUSE_FFN") && atoi(getenv("AMT_FUSE_FFN")) != 0;
+  // whole second half of a layer (output projection, LN2, W1 / GLU, W2, dropout, residual) in one launch.  Round 1
+  // measured it slower and left it off; with 16-token forward tiles and the boundary cost understood (it is the write-back
+  // of what a kernel stored, profiles/r02_notes.md: the chain saves two boundaries per layer) it is 3.86 vs 3.97 ms/step.
+  c->fuse_ffn = !(getenv("AMT_FUSE_FFN") && atoi(getenv("AMT_FUSE_FFN")) == 0);
   // XCD-team launches (team.h): opt-in while they are not faster than one launch per Block (profiles/r02_notes.md)
   if (getenv("AMT_TEAM") && atoi(getenv("AMT_TEAM")) != 0) {
     c->team = team_state_create();

@@ -153,8 +153,8 @@ AMT_DEV Team team_assemble(TeamState* st, const TeamTicket& k) {
 }
 AMT_DEV Team team_form(TeamState* st) { return team_assemble(st, team_register(st)); }
 
-// Warm `bytes` at `base` into this XCD's L2: member `rank` of `size` touches every size-th 4 KiB piece (16 B per
-// thread), by LDS-DMA into a dummy LDS region (`dummy`: 4 KiB, never read), so no register waits for the data.
+// Warm `bytes` at `base` into this XCD's L2: member `rank` of `size` touches every size-th piece (16 B per
+// thread), by LDS-DMA into a dummy LDS region (`dummy`: 1 KiB per wave, never read), so no register waits for the data.
 // Why: the members of a team stream the SAME weights in lockstep.  Cold, every line is one L2 miss with 31 requests
 // queued behind it, and whatever else goes through that L2 queues too - instruction fetches included: the other
 // members stood still for the ~6 us the first member's stream took (profiles/r02_notes.md).  Operands that depend on
@@ -164,7 +164,8 @@ AMT_DEV void team_warm(const void* base, size_t bytes, int rank, int size, void*
   typedef __attribute__((address_space(3))) void* LdsPtr;
   const char* p = static_cast<const char*>(base);
   char* d = static_cast<char*>(dummy) + (threadIdx.x >> 6) * 1024;
-  for (size_t off = ((size_t)rank * 256 + threadIdx.x) * 16; off + 16 <= bytes; off += (size_t)size * 4096)
+  const size_t piece = (size_t)blockDim.x * 16;   // bytes one workgroup touches per step
+  for (size_t off = (size_t)rank * piece + (size_t)threadIdx.x * 16; off + 16 <= bytes; off += (size_t)size * piece)
     __builtin_amdgcn_global_load_lds((GlobalPtr)(p + off), (LdsPtr)d, 16, 0, 0);
 }
 
