@@ -1221,6 +1221,125 @@ __global__ __launch_bounds__(256) void lnout_bwd_fused_kernel(LnOutBwdArgs a, Wg
   AMT_STAMP_RT(7);
 }
 
+// ------------------------------------------------------------------ transformer layer, second half, backward (whole)
+// One launch for gemm_nt<glu_bwd> + gemm_nt<store> + lnout_bwd_fused (kernels.h: FfnBwdArgs).  Every stage repeats its
+// unfused launch: same K order into one accumulator, du and dhn rounded to T where the unfused path stores them.
+template <typename T, int TT>
+__global__ __launch_bounds__(256) void ffn_bwd_fused_kernel(FfnBwdArgs a, WgradGroup riders) {
+  constexpr int H = 256, I = 512, I2 = 1024, LDX = H + 8, LDU = I2 + 8;
+  using SO = ChainSplit<H, TT>;                        // every stage is cut into 256 output features per pass
+  constexpr int KCA = ChainChunk<T, SO::RB, H>::KC;    // dg halves: K = 256
+  constexpr int KCB = ChainChunk<T, SO::RB, I2>::KC;   // dhn:       K = 1024
+  constexpr int KCO = ChainChunk<T, SO::RB, H>::KC;    // dao:       K = 256
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  if ((int)blockIdx.x >= a.n_chain) {
+    wgrad_group_dispatch<T>(riders, (int)blockIdx.x - a.n_chain, chain_smem);
+    return;
+  }
+  T* Ds = reinterpret_cast<T*>(chain_smem);   // [TT][LDX]  dyd, then dhn, then dh
+  T* Os = Ds + TT * LDX;                      // [TT][LDX]  dao (staged for the copy-out)
+  float* part = reinterpret_cast<float*>(Os); // [4][2 * 256] before Os is used
+  T* Us = Os + TT * LDX;                      // [TT][LDU]  u, overwritten in place by du
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const long N = a.N, n0 = (long)blockIdx.x * TT;
+  const T* W2t = reinterpret_cast<const T*>(a.W2t);
+  const T* W1t = reinterpret_cast<const T*>(a.W1t);
+  const T* Wo = reinterpret_cast<const T*>(a.Wot);
+  const int mO = (wave % SO::WF) * SO::RB * 16, tO = (wave / SO::WF) * SO::NT * 16;
+
+  Frag<T> wa[KCA][SO::RB], wb[KCB][SO::RB];
+  chain_load_w<T, SO::RB, KCA, H>(wa, W2t, mO, 0, lane);
+  chain_copy_in<T, TT, H, LDX>(Ds, reinterpret_cast<const T*>(a.dYD), n0, N, tid);
+  chain_copy_in<T, TT, I2, LDU>(Us, reinterpret_cast<const T*>(a.U), n0, N, tid);
+  __syncthreads();
+
+  // ---- dg = dyd . W2 (two halves of 256 columns) ; du = GLU'(dg, u), in place over u
+  auto glu_bwd_half = [&](int half, Frag<T> (&wpre)[KCA][SO::RB]) {
+    f32x4 acc[SO::RB][SO::NT];
+    chain_zero(acc);
+    chain_stage<T, SO::RB, SO::NT, KCA, H>(acc, wpre, W2t, 256 * half + mO, Ds, LDX, tO, lane);
+    // the next stage's first weights are requested before the epilogue (exp, LDS traffic) runs
+    if (half == 0) chain_load_w<T, SO::RB, KCA, H>(wpre, W2t, 256 + mO, 0, lane);
+    else chain_load_w<T, SO::RB, KCB, I2>(wb, W1t, mO, 0, lane);
+#pragma unroll
+    for (int rb = 0; rb < SO::RB; ++rb) {
+      const int j = 256 * half + mO + 16 * rb + 4 * g;   // dg column; u lives in the permuted (16 x u1 | 16 x u2) layout
+      const int pm = (j >> 4) * 32 + (j & 15);
+#pragma unroll
+      for (int ti = 0; ti < SO::NT; ++ti) {
+        T* up = Us + (tO + 16 * ti + r) * LDU + pm;
+        float u1[4], u2[4], d1[4], d2[4];
+        load4f(up, u1);
+        load4f(up + 16, u2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = acc[rb][ti][i];
+          d1[i] = v * u2[i] * gelu_tanh_grad(u1[i]);
+          d2[i] = v * gelu_tanh(u1[i]);
+        }
+        store4f(up, d1);
+        store4f(up + 16, d2);
+      }
+    }
+  };
+  glu_bwd_half(0, wa);
+  glu_bwd_half(1, wa);
+  __syncthreads();
+  chain_copy_out<T, TT, I2, LDU>(Us, reinterpret_cast<T*>(a.dU), n0, N, tid);   // for the W1 weight gradient
+
+  // ---- dhn = du . W1 (K = 1024) -> Ds (dyd is dead)
+  Frag<T> wo[KCO][SO::RB];
+  {
+    f32x4 acc[SO::RB][SO::NT];
+    chain_zero(acc);
+    chain_stage<T, SO::RB, SO::NT, KCB, I2>(acc, wb, W1t, mO, Us, LDU, tO, lane);
+    chain_load_w<T, SO::RB, KCO, H>(wo, Wo, mO, 0, lane);
+#pragma unroll
+    for (int rb = 0; rb < SO::RB; ++rb)
+#pragma unroll
+      for (int ti = 0; ti < SO::NT; ++ti) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[rb][ti][i];
+        store4f(Ds + (tO + 16 * ti + r) * LDX + mO + 16 * rb + 4 * g, v);
+      }
+  }
+  __syncthreads();
+
+  // ---- dh = dy + LN2'(dhn) ; dln2 w / b column sums (as lnout_bwd_fused)
+  float cs[2][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { cs[0][i] = 0.f; cs[1][i] = 0.f; }
+  chain_ln_bwd_rows<T, TT, LDX>(Ds, Ds, reinterpret_cast<const T*>(a.Hres), a.mean, a.rstd, a.ln_w,
+                                reinterpret_cast<const T*>(a.dY), reinterpret_cast<T*>(a.dH), nullptr, 0, 0, 0, 1.f, cs,
+                                n0, N, tid);
+  fold_columns<32, 16>(*reinterpret_cast<float (*)[16]>(&cs[0][0]), part + wave * 2 * H, H, lane);
+  __syncthreads();
+  {
+    float* rec = a.rec + (size_t)blockIdx.x * a.rec_stride;
+    for (int t = tid; t < 2 * H; t += 256)
+      rec[t] = (part[t] + part[2 * H + t]) + (part[4 * H + t] + part[6 * H + t]);
+  }
+  // ---- dao = dh . Wo
+  f32x4 acc[SO::RB][SO::NT];
+  chain_zero(acc);
+  chain_stage<T, SO::RB, SO::NT, KCO, H>(acc, wo, Wo, mO, Ds, LDX, tO, lane);
+  __syncthreads();                                   // every thread has read its record values from `part`
+#pragma unroll
+  for (int rb = 0; rb < SO::RB; ++rb)
+#pragma unroll
+    for (int ti = 0; ti < SO::NT; ++ti) {
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = acc[rb][ti][i];
+      store4f(Os + (tO + 16 * ti + r) * LDX + mO + 16 * rb + 4 * g, v);
+    }
+  __syncthreads();
+  chain_copy_out<T, TT, H, LDX>(Os, reinterpret_cast<T*>(a.dAO), n0, N, tid);
+}
+
 template <typename K> static void chain_set_lds(K kernel, size_t bytes) {
   if (bytes > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -1247,8 +1366,23 @@ static void lnout_bwd_fused_launch(hipStream_t s, const LnOutBwdArgs& a, const W
   hipLaunchKernelGGL((lnout_bwd_fused_kernel<T, TT>), dim3(a.n_chain + n_rider_wgs), dim3(256), lds, s, a, rg);
 }
 
-static int chain_ln_records(DType dt, int N, float* dlnw, float* dlnb, PartialSink* sink, float** rec) {
-  const int TT = dt == DT_F32 ? 16 : 32, nb = (N + TT - 1) / TT;
+// 16-token tiles (250 workgroups at cfg2, 50 KiB of LDS: riders share the compute units); 32-token tiles for bf16 ran
+// 51 us per launch against 43 us for the three launches it replaces
+constexpr int kFfnBwdTile = 16;
+template <typename T>
+static void ffn_bwd_fused_launch(hipStream_t s, const FfnBwdArgs& a, const WgradGroup& rg, int n_rider_wgs) {
+  constexpr int TT = kFfnBwdTile;
+  constexpr size_t lds_chain = sizeof(T) * (size_t)TT * (2 * (256 + 8) + (1024 + 8));
+  constexpr size_t lds = lds_chain > TnLds<T>::BYTES ? lds_chain : TnLds<T>::BYTES;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static_assert(sizeof(T) * TT * (256 + 8) >= sizeof(float) * 8 * 256, "column-sum slices fit in one panel");
+  static bool once = (chain_set_lds(ffn_bwd_fused_kernel<T, TT>, lds), true);
+  (void)once;
+  hipLaunchKernelGGL((ffn_bwd_fused_kernel<T, TT>), dim3(a.n_chain + n_rider_wgs), dim3(256), lds, s, a, rg);
+}
+
+static int chain_ln_records(DType dt, int N, float* dlnw, float* dlnb, PartialSink* sink, float** rec, int tile = 0) {
+  const int TT = tile > 0 ? tile : (dt == DT_F32 ? 16 : 32), nb = (N + TT - 1) / TT;
   size_t o = sink->take((size_t)nb * 512);
   sink->add(o, nb, 512, 256, dlnw);
   sink->add(o + 256, nb, 512, 256, dlnb);
@@ -1286,6 +1420,23 @@ void lnout_bwd_fused(hipStream_t s, DType dt, const LnOutBwdArgs& a_in, float* d
                (N * 256 * 5.0 + 256.0 * 256) * es + rby);
   if (dt == DT_F32) lnout_bwd_fused_launch<float>(s, a, rg, n_rider_wgs);
   else lnout_bwd_fused_launch<bf16>(s, a, rg, n_rider_wgs);
+}
+
+void ffn_bwd_fused(hipStream_t s, DType dt, const FfnBwdArgs& a_in, float* dlnw, float* dlnb, PartialSink* sink,
+                   const WgradArgs* riders, int n_riders) {
+  FfnBwdArgs a = a_in;
+  a.n_chain = chain_ln_records(dt, a.N, dlnw, dlnb, sink, &a.rec, kFfnBwdTile);
+  WgradGroup rg;
+  double rfl = 0, rby = 0;
+  const int n_rider_wgs = wgrad_group_prepare(dt, riders, n_riders, sink, &rg, &rfl, &rby);
+  if (sink->dry) return;
+  a.rec_stride = 512;
+  const double N = a.N, es = dt == DT_F32 ? 4 : 2;
+  ProfScope ps(s, n_rider_wgs > 0 ? "ffn_bwd_fused+wgrad" : "ffn_bwd_fused",
+               2.0 * N * (512.0 * 256 + 256.0 * 1024 + 256.0 * 256) + rfl,
+               (N * (256 * 5.0 + 2.0 * 1024) + 512.0 * 256 + 256.0 * 1024 + 256.0 * 256) * es + rby);
+  if (dt == DT_F32) ffn_bwd_fused_launch<float>(s, a, rg, n_rider_wgs);
+  else ffn_bwd_fused_launch<bf16>(s, a, rg, n_rider_wgs);
 }
 
 }  // namespace amt

@@ -260,6 +260,26 @@ struct LnOutBwdArgs {
 void lnout_bwd_fused(hipStream_t s, DType dt, const LnOutBwdArgs& a, float* dlnw, float* dlnb, PartialSink* sink,
                      const WgradArgs* riders = nullptr, int n_riders = 0);
 
+// Backward of the WHOLE second half of a transformer layer in one launch (the backward counterpart of the full
+// ffn_fwd_fused; replaces gemm_nt<glu_bwd> + gemm_nt<store> + lnout_bwd_fused):
+//   dg = dyd . W2 ; du = GLU'(dg, u) (permuted layout, written for the W1 weight gradient) ; dhn = du . W1 ;
+//   dh = dy + LN2'(dhn) ; dao = dh . Wo ; dln2 w/b records.
+// dYD = dy with the FFN-output dropout mask applied (== dY without dropout).  W2t [512][256], W1t [256][1024],
+// Wot [256][256]: fragment-PACKED.  The boundary a launch ends with costs the write-back of what it stored
+// (profiles/r02_notes.md): this chain keeps dhn on the chip and ends two launches earlier.
+struct FfnBwdArgs {
+  const void* dYD; const void* dY; const void* U;
+  const void* W2t; const void* W1t; const void* Wot;
+  const void* Hres; const float* mean; const float* rstd; const float* ln_w;
+  void* dU; void* dH; void* dAO;
+  float* rec; int rec_stride;      // set by the launcher
+  int N;
+  int n_chain;                     // workgroups of the chain; the rest run the riders (launcher)
+  int dbg_slot;
+};
+void ffn_bwd_fused(hipStream_t s, DType dt, const FfnBwdArgs& a, float* dlnw, float* dlnb, PartialSink* sink,
+                   const WgradArgs* riders = nullptr, int n_riders = 0);
+
 // ----------------------------------------------------------------------------- attention
 struct AttnArgs {
   const void* QC; int ldqc;   // q = QC[:, 0:256] (un-roped)

@@ -49,6 +49,7 @@ struct LayerP {
   size_t c_wqc, c_wqct, c_wkv, c_wkvt, c_wo, c_wot, c_w1, c_w1t, c_w2, c_w2t;
   size_t c_wop, c_w1p, c_w2p, c_wqcp, c_wkvp;   // fragment-packed copies for the chain kernels
   size_t c_wotp, c_wqctp, c_wkvtp;              // packed transposes (backward chains)
+  size_t c_w2tp, c_w1tp;                        // packed transposes of the FFN weights (ffn_bwd_fused)
 };
 
 struct Layout {
@@ -214,6 +215,8 @@ Layout build_layout(const amt_config& c) {
     need_cur = NEED_FFN_CHAIN;
     l.c_w1p = cpacked(l.w1, L.I2, H);
     l.c_w2p = cpacked(l.w2, H, c.ffn_inter);
+    l.c_w2tp = cpacked_t(l.w2, c.ffn_inter, H);
+    l.c_w1tp = cpacked_t(l.w1, H, L.I2);
     need_cur = NEED_ALWAYS;
     L.layers.push_back(l);
   }
@@ -833,20 +836,30 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     // FFN
     wgrad(dyd, H, ls.g, L.I2 / 2, N, H, L.I2 / 2, lp.w2, L.I2 / 2, (long)lp.b2, 0);
     void* du = A.alloc((size_t)N * L.I2 * es);
-    {
-      GemmArgs g = gargs(dyd, H, c->WC(lp.c_w2t), H, N, L.I2 / 2, H, nullptr, du, L.I2);
-      g.U = ls.u; g.ldu = L.I2;
-      RUN(gemm_nt(s, dt, EPI_GLU_BWD, g));
-    }
-    wgrad(du, L.I2, ls.hn, H, N, L.I2, H, lp.w1, H, (long)lp.b1, 0);
-    void* dhn2 = A.alloc((size_t)N * H * es);
-    {
+    const bool ffn_bwd_chain = chain_ok && c->fuse_ffn && !(c->nochain & 16) && !(c->nochain & 2048);
+    void* dhn2 = nullptr;
+    if (!ffn_bwd_chain) {
+      {
+        GemmArgs g = gargs(dyd, H, c->WC(lp.c_w2t), H, N, L.I2 / 2, H, nullptr, du, L.I2);
+        g.U = ls.u; g.ldu = L.I2;
+        RUN(gemm_nt(s, dt, EPI_GLU_BWD, g));
+      }
+      dhn2 = A.alloc((size_t)N * H * es);
       GemmArgs g = gargs(du, L.I2, c->WC(lp.c_w1t), L.I2, N, H, L.I2, nullptr, dhn2, H);
       RUN(gemm_nt(s, dt, EPI_STORE, g));
     }
+    wgrad(du, L.I2, ls.hn, H, N, L.I2, H, lp.w1, H, (long)lp.b1, 0);
     void* dh = A.alloc((size_t)N * H * es);
     void* dao = A.alloc((size_t)N * H * es);
-    if (chain_ok && !(c->nochain & 16)) {
+    if (ffn_bwd_chain) {
+      // the whole second half of the layer in one launch (chain.hip: ffn_bwd_fused)
+      FfnBwdArgs fb;
+      memset(&fb, 0, sizeof(fb));
+      fb.dYD = dyd; fb.dY = dy; fb.U = ls.u; fb.W2t = c->WC(lp.c_w2tp); fb.W1t = c->WC(lp.c_w1tp); fb.Wot = c->WC(lp.c_wotp);
+      fb.Hres = ls.h; fb.mean = ls.m2; fb.rstd = ls.r2; fb.ln_w = c->P(lp.ln2_w); fb.dU = du; fb.dH = dh; fb.dAO = dao; fb.N = N;
+      ffn_bwd_fused(s, dt, fb, G(lp.ln2_w), G(lp.ln2_b), &sink, riders_a.data(), (int)riders_a.size());
+      wgrad(dh, H, ls.ao, H, N, H, H, lp.wo, H, -1, 0);
+    } else if (chain_ok && !(c->nochain & 16)) {
       LnOutBwdArgs la;
       memset(&la, 0, sizeof(la));
       la.dHN = dhn2; la.Hres = ls.h; la.mean = ls.m2; la.rstd = ls.r2; la.ln_w = c->P(lp.ln2_w); la.dY = dy;
