@@ -765,7 +765,7 @@ template <typename T> struct FfnTileFwd { static constexpr int TT = 16; };
 // the 128 KiB output projection in the chain the kernel takes ~6 us and W1 / W2 stay tiled GEMMs,
 // whose 64 x 64 tiles move 3.5x fewer weight bytes per CU (profiles/r01_notes.md).
 template <typename T, int TT, bool FULL>
-__global__ __launch_bounds__(256) void ffn_fwd_fused_kernel(FfnFwdArgs a) {
+AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem) {
   a.seed = eff_seed(a.seed, a.seed_dev);   // kernel argument + the context's device seed word (common.h)
   constexpr int H = 256, I = 512, I2 = 1024, LDX = H + 8, LDG = I + 8;
   using SO = ChainSplit<H, TT>;        // Wo and W2 stages: 256 output features
@@ -776,7 +776,6 @@ __global__ __launch_bounds__(256) void ffn_fwd_fused_kernel(FfnFwdArgs a) {
   constexpr int KCO = ChainChunk<T, SO::RB, H, 32>::KC, KC1 = ChainChunk<T, S1::RB, H, 32>::KC,
                 KC2 = ChainChunk<T, SO::RB, I, 32>::KC;
   static_assert(S1::RB % 2 == 0, "a wave owns whole (u1 | u2) row-block pairs");
-  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
   T* As = reinterpret_cast<T*>(chain_smem);   // [TT][LDX]  attention output, then LN2(h)
   T* Xs = As + TT * LDX;                      // [TT][LDX]  x, then y (staged for the copy-out)
   T* Hs = Xs + TT * LDX;                      // [TT][LDX]  h
@@ -921,6 +920,12 @@ __global__ __launch_bounds__(256) void ffn_fwd_fused_kernel(FfnFwdArgs a) {
   AMT_STAMP_RT(7);
 }
 
+template <typename T, int TT, bool FULL>
+__global__ __launch_bounds__(256) void ffn_fwd_fused_kernel(FfnFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  ffn_fwd_body<T, TT, FULL>(a, chain_smem);
+}
+
 template <typename T, bool FULL, int TT>
 static void ffn_fwd_fused_launch_tt(hipStream_t s, const FfnFwdArgs& a) {
   constexpr size_t lds = sizeof(T) * (size_t)TT * (3 * (256 + 8) + (FULL ? 512 + 8 : 0));
@@ -957,13 +962,14 @@ void ffn_fwd_fused(hipStream_t s, DType dt, const FfnFwdArgs& a) {
 
 
 // ------------------------------------------------------------------ transformer layer, first half, forward
+// XLDS != nullptr: the tile's x rows are already in LDS (panel [TT][H + 8] left by the chain that produced them in the
+// same launch: ffn_qkv_fwd_fused) and are copied from there instead of from a.X.
 template <typename T, int TT>
-__global__ __launch_bounds__(256) void qkv_fwd_fused_kernel(QkvFwdArgs a) {
+AMT_DEV void qkv_fwd_body(const QkvFwdArgs& a, unsigned char* chain_smem, const T* XLDS) {
   constexpr int H = 256, QC = 320, CK = 64, KV = 512, LDX = H + 8, LDQ = QC + 8, LDK = KV + 8;
   using SQ = ChainSplit<QC, TT>;
   using SK = ChainSplit<KV, TT>;
   constexpr int KCQ = ChainChunk<T, SQ::RB, H, 32>::KC, KCK = ChainChunk<T, SK::RB, CK>::KC;
-  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
   T* Xs = reinterpret_cast<T*>(chain_smem);   // [TT][LDX]  x, then LN1(x) in place
   T* Qs = Xs + TT * LDX;                      // [TT][LDQ]  qc
   T* Ks = Qs + TT * LDQ;                      // [TT][LDK]  kv
@@ -980,7 +986,15 @@ __global__ __launch_bounds__(256) void qkv_fwd_fused_kernel(QkvFwdArgs a) {
   AMT_STAMP(0);
   Frag<T> wq[KCQ][SQ::RB], wk[KCK][SK::RB];
   chain_load_w<T, SQ::RB, KCQ, H>(wq, Wq, mQ, 0, lane);
-  chain_copy_in<T, TT, H, LDX>(Xs, reinterpret_cast<const T*>(a.X), n0, N, tid);
+  if (XLDS == nullptr) {
+    chain_copy_in<T, TT, H, LDX>(Xs, reinterpret_cast<const T*>(a.X), n0, N, tid);
+  } else {                                   // rows past N hold zeros there as well (masked when they were computed)
+    constexpr int CPR = H / 8;
+    for (int id = tid; id < TT * CPR; id += 256) {
+      const int p = id / CPR, c = id % CPR;
+      chunk_store(Xs + p * LDX + 8 * c, chunk_load(XLDS + p * LDX + 8 * c));
+    }
+  }
   __syncthreads();
   AMT_STAMP(1);
   chain_ln_rows<T, TT, H, LDX>(Xs, Xs, a.ln_w, a.ln_b, a.mean, a.rstd, n0, N, tid);
@@ -1031,6 +1045,27 @@ __global__ __launch_bounds__(256) void qkv_fwd_fused_kernel(QkvFwdArgs a) {
 }
 
 template <typename T, int TT>
+__global__ __launch_bounds__(256) void qkv_fwd_fused_kernel(QkvFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  qkv_fwd_body<T, TT>(a, chain_smem, nullptr);
+}
+
+// Layer boundary in one launch: the second half of layer l (ffn_fwd_body, FULL) followed, for the same token tile, by the
+// first half of layer l + 1 up to its attention core (qkv_fwd_body).  Both are per-token chains, the tile's y rows go
+// from one to the other through LDS, and one kernel boundary per layer - with the write-back of what the first kernel
+// stored (profiles/r02_notes.md) - leaves the dependent chain.
+template <typename T, int TT>
+__global__ __launch_bounds__(256) void ffn_qkv_fwd_fused_kernel(FfnFwdArgs fa, QkvFwdArgs qa) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  constexpr int LDX = 256 + 8;
+  ffn_fwd_body<T, TT, true>(fa, chain_smem);
+  __syncthreads();                                   // the copy-out of y has read its panel; every panel is free
+  // y sits in the SECOND [TT][LDX] panel of the FFN body; the q/kv body keeps x in the first: copy, then go on
+  const T* ys = reinterpret_cast<const T*>(chain_smem) + TT * LDX;
+  qkv_fwd_body<T, TT>(qa, chain_smem, ys);
+}
+
+template <typename T, int TT>
 static void qkv_fwd_fused_launch_tt(hipStream_t s, const QkvFwdArgs& a) {
   constexpr size_t lds = sizeof(T) * (size_t)TT * ((256 + 8) + (320 + 8) + (512 + 8));
   static_assert(lds <= 160 * 1024, "LDS budget");
@@ -1046,6 +1081,32 @@ template <typename T>
 static void qkv_fwd_fused_launch(hipStream_t s, const QkvFwdArgs& a) {
   if (a.N < 8192) qkv_fwd_fused_launch_tt<T, FfnTileFwd<T>::TT>(s, a);
   else qkv_fwd_fused_launch_tt<T, FfnTile<T>::TT>(s, a);
+}
+
+template <typename T>
+static void ffn_qkv_fwd_fused_launch(hipStream_t s, const FfnFwdArgs& fa, const QkvFwdArgs& qa) {
+  constexpr int TT = FfnTileFwd<T>::TT;
+  constexpr size_t lds_f = sizeof(T) * (size_t)TT * (3 * (256 + 8) + 512 + 8);
+  constexpr size_t lds_q = sizeof(T) * (size_t)TT * ((256 + 8) + (320 + 8) + (512 + 8));
+  constexpr size_t lds = lds_f > lds_q ? lds_f : lds_q;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool once = (lds > 64 * 1024
+                          ? (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_qkv_fwd_fused_kernel<T, TT>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                          : (void)0,
+                      true);
+  (void)once;
+  hipLaunchKernelGGL((ffn_qkv_fwd_fused_kernel<T, TT>), dim3((fa.N + TT - 1) / TT), dim3(256), lds, s, fa, qa);
+}
+
+bool ffn_qkv_fwd_fused(hipStream_t s, DType dt, const FfnFwdArgs& fa, const QkvFwdArgs& qa) {
+  if (fa.N != qa.N || fa.N >= 8192 || fa.W1 == nullptr) return false;   // the 16-token forward tile only (training sizes)
+  const double N = fa.N, es = dt == DT_F32 ? 4 : 2;
+  ProfScope ps(s, "ffn_qkv_fwd_fused", 2.0 * N * (256.0 * 256 + 1024.0 * 256 + 256.0 * 512 + 320.0 * 256 + 512.0 * 64),
+               (N * (256.0 * 7 + 1024 + 512 + 320 + 512) + 256.0 * 256 + 1024.0 * 256 + 256.0 * 512 + 320.0 * 256 + 512.0 * 64) * es);
+  if (dt == DT_F32) ffn_qkv_fwd_fused_launch<float>(s, fa, qa);
+  else ffn_qkv_fwd_fused_launch<bf16>(s, fa, qa);
+  return true;
 }
 
 void qkv_fwd_fused(hipStream_t s, DType dt, const QkvFwdArgs& a) {

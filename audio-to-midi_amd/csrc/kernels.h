@@ -224,6 +224,9 @@ struct QkvFwdArgs {
   int dbg_slot;
 };
 void qkv_fwd_fused(hipStream_t s, DType dt, const QkvFwdArgs& a);
+// ffn_fwd_fused (full) of layer l and qkv_fwd_fused of layer l + 1 in ONE launch (same token tiles, y handed over
+// through LDS): same outputs as the two launches.  false: not served for this size, launch the two separately.
+bool ffn_qkv_fwd_fused(hipStream_t s, DType dt, const FfnFwdArgs& fa, const QkvFwdArgs& qa);
 
 // Backward of the first half of a transformer layer after the attention core, in one launch
 // (replaces gemm_nt (k/v-up^T) + gemm_nt (q/kv-down^T) + layernorm_bwd [+ the next layer's dropout_apply]):

@@ -541,17 +541,20 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
   }
   c->fn_y = cur;
   const size_t mark1 = A.off;
+  bool qkv_done = false;   // the current layer's first half was computed by the previous layer's boundary launch
   for (size_t li = 0; li < L.layers.size(); ++li) {
     const LayerP& lp = L.layers[li];
     LayerSave& ls = c->lsave[li];
     const bool local = (li % 2 == 0);   // model.py:609-611: local layer first, then global
     if (!save) A.off = mark1;
     ls.x = cur;
-    ls.xn = A.alloc((size_t)N * H * es);
-    ls.m1 = (float*)A.alloc((size_t)N * sizeof(float));
-    ls.r1 = (float*)A.alloc((size_t)N * sizeof(float));
-    ls.qc = A.alloc((size_t)N * L.QC * es);
-    ls.kv = A.alloc((size_t)N * L.KVW * es);
+    if (!qkv_done) {   // (otherwise allocated - and computed - by the previous layer's boundary launch)
+      ls.xn = A.alloc((size_t)N * H * es);
+      ls.m1 = (float*)A.alloc((size_t)N * sizeof(float));
+      ls.r1 = (float*)A.alloc((size_t)N * sizeof(float));
+      ls.qc = A.alloc((size_t)N * L.QC * es);
+      ls.kv = A.alloc((size_t)N * L.KVW * es);
+    }
     ls.ao = A.alloc((size_t)N * H * es);
     ls.lse = local ? nullptr : (float*)A.alloc((size_t)B * cfg.n_heads * S * sizeof(float));
     ls.hn = A.alloc((size_t)N * H * es);
@@ -560,11 +563,19 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
     ls.u = A.alloc((size_t)N * L.I2 * es);
     ls.g = A.alloc((size_t)N * (L.I2 / 2) * es);
     const bool chain_ok = c->fuse && H == 256 && cfg.ffn_inter == 512 && cfg.n_heads * cfg.head_dim == 256;
-    if (chain_ok && !(c->nochain & 4)) {
+    auto qkv_args = [&](size_t l, const void* x) {
+      const LayerP& q = L.layers[l];
+      const LayerSave& t = c->lsave[l];
       QkvFwdArgs qa;
       memset(&qa, 0, sizeof(qa));
-      qa.X = cur; qa.ln_w = c->P(lp.ln1_w); qa.ln_b = c->P(lp.ln1_b); qa.Wqc = c->WC(lp.c_wqcp); qa.Wkv = c->WC(lp.c_wkvp);
-      qa.XN = ls.xn; qa.mean = ls.m1; qa.rstd = ls.r1; qa.QC = ls.qc; qa.KV = ls.kv; qa.N = N; qa.dbg_slot = 96 + (int)li;
+      qa.X = x; qa.ln_w = c->P(q.ln1_w); qa.ln_b = c->P(q.ln1_b); qa.Wqc = c->WC(q.c_wqcp); qa.Wkv = c->WC(q.c_wkvp);
+      qa.XN = t.xn; qa.mean = t.m1; qa.rstd = t.r1; qa.QC = t.qc; qa.KV = t.kv; qa.N = N; qa.dbg_slot = 96 + (int)l;
+      return qa;
+    };
+    if (qkv_done) {
+      qkv_done = false;                 // xn, qc, kv of this layer came out of the previous layer's boundary launch
+    } else if (chain_ok && !(c->nochain & 4)) {
+      const QkvFwdArgs qa = qkv_args(li, cur);
       RUN(qkv_fwd_fused(s, dt, qa));
     } else {
       RUN(layernorm_fwd(s, dt, cur, c->P(lp.ln1_w), c->P(lp.ln1_b), ls.xn, ls.m1, ls.r1, N, H));
@@ -595,7 +606,23 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
         fa.W1 = c->WC(lp.c_w1p); fa.b1 = c->P(lp.b1); fa.W2 = c->WC(lp.c_w2p); fa.b2 = c->P(lp.b2);
         fa.U = ls.u; fa.G = ls.g; fa.Y = y;
         fa.seed = seed; fa.seed_dev = c->seed_word; fa.stream = stream_ffn((int)li); fa.drop_thresh24 = dp.thr; fa.inv_keep = dp.inv_keep;
-        RUN(ffn_fwd_fused(s, dt, fa));
+        // layer boundary: this layer's second half and the next layer's LN1 + q/kv projections in one launch
+        // (training sizes; the inference path recycles its buffers per layer and keeps the two launches)
+        if (save && li + 1 < L.layers.size() && N < 8192 && !(c->nochain & 4) && !(c->nochain & 4096)) {
+          LayerSave& nx = c->lsave[li + 1];
+          nx.xn = A.alloc((size_t)N * H * es);
+          nx.m1 = (float*)A.alloc((size_t)N * sizeof(float));
+          nx.r1 = (float*)A.alloc((size_t)N * sizeof(float));
+          nx.qc = A.alloc((size_t)N * L.QC * es);
+          nx.kv = A.alloc((size_t)N * L.KVW * es);
+          const QkvFwdArgs qa = qkv_args(li + 1, y);
+          if (!dry && !A.overflow) {
+            if (!ffn_qkv_fwd_fused(s, dt, fa, qa)) { ffn_fwd_fused(s, dt, fa); qkv_fwd_fused(s, dt, qa); }
+          }
+          qkv_done = true;
+        } else {
+          RUN(ffn_fwd_fused(s, dt, fa));
+        }
         cur = y;
         continue;
       }
