@@ -21,12 +21,14 @@ def classify(name):
     m = re.search(r"gemm_nt_kernel<.*ELi(\d+)E", name)   # demangler-confused names: GLU_BWD (Li6)
     if m:
         return f"gemm_nt<bf16,glu_bwd,{m.group(1)}>"
-    if "ffn_fwd_fused_kernel" in name:
+    if "ffn_fwd_fused_kernel" in name and "ffn_qkv" not in name:
         return "attn_out_fused" if "Lb0" in name else "ffn_fwd_fused"
-    for key, cls in (("gemm_tn_group_kernel", "gemm_tn_wgrad_group<bf16>"), ("dwblock_bwd_kernel", "dwblock_bwd"),
+    for key, cls in (("ffn_qkv_fwd_fused_kernel", "ffn_qkv_fwd_fused"), ("ffn_bwd_fused_kernel", "ffn_bwd_fused+wgrad"),
+                     ("block_run_fwd_kernel", "block_run_fwd"),
+                     ("gemm_tn_group_kernel", "gemm_tn_wgrad_group<bf16>"), ("dwblock_bwd_kernel", "dwblock_bwd"),
                      ("block_fwd_fused_kernel", "block_fwd_fused"), ("block_bwd_fused_kernel", "block_bwd_fused+wgrad"),
-                     ("qkv_fwd_fused_kernel", "qkv_fwd_fused"), ("qkv_bwd_fused_kernel", "qkv_bwd_fused"),
-                     ("lnout_bwd_fused_kernel", "lnout_bwd_fused"), ("block_small_fwd_kernel", "block_small_fwd"),
+                     ("qkv_fwd_fused_kernel", "qkv_fwd_fused"), ("qkv_bwd_fused_kernel", "qkv_bwd_fused+wgrad"),
+                     ("lnout_bwd_fused_kernel", "lnout_bwd_fused+wgrad"), ("block_small_fwd_kernel", "block_small_fwd"),
                      ("block_small_bwd_kernel", "block_small_bwd"), ("block_small_bwd_full_kernel", "block_small_bwd_full"),
                      ("attn_global_fwd_fp8_kernel", "attn_global_fwd_fp8"),
                      ("attn_global_bwd_kernel", "attn_global_bwd"), ("attn_global_fwd_kernel", "attn_global_fwd"),
