@@ -401,12 +401,12 @@ int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* si
   return g.prefix[n];
 }
 
-void gemm_tn_wgrad_group(hipStream_t s, DType dt, const WgradArgs* probs, int n, PartialSink* sink) {
+void gemm_tn_wgrad_group(hipStream_t s, DType dt, const WgradArgs* probs, int n, PartialSink* sink, int target_wgs) {
   if (n <= 0) return;
-  if (n == 1) { gemm_tn_wgrad(s, dt, probs[0], sink); return; }
+  if (n == 1 && target_wgs <= 0) { gemm_tn_wgrad(s, dt, probs[0], sink); return; }
   WgradGroup g;
   double fl = 0, by = 0;
-  const int nwg = wgrad_group_prepare(dt, probs, n, sink, &g, &fl, &by);
+  const int nwg = wgrad_group_prepare(dt, probs, n, sink, &g, &fl, &by, target_wgs);
   if (nwg <= 0) return;
   ProfScope ps(s, dt == DT_F32 ? "gemm_tn_wgrad_group<f32>" : "gemm_tn_wgrad_group<bf16>", fl, by);
   if (dt == DT_F32) hipLaunchKernelGGL((gemm_tn_group_kernel<float>), dim3(nwg), dim3(256), TnLds<float>::BYTES, s, g);

@@ -56,7 +56,8 @@ struct PartialSink;
 void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a, PartialSink* sink = nullptr);
 // up to 8 independent problems in one launch
 struct WgradGroup { int n; int prefix[9]; int tiles[8]; int tiles_k[8]; int rps[8]; WgradArgs p[8]; };
-void gemm_tn_wgrad_group(hipStream_t s, DType dt, const WgradArgs* probs, int n, PartialSink* sink = nullptr);
+// target_wgs > 0: aim for about that many workgroups (default: AMT_WGRAD_TARGET_WGS / 336)
+void gemm_tn_wgrad_group(hipStream_t s, DType dt, const WgradArgs* probs, int n, PartialSink* sink = nullptr, int target_wgs = 0);
 // fills the group (one-tile / long-N problems get per-split records from `sink`); returns the number of
 // workgroups, 0 while planning.  Used by gemm_tn_wgrad_group and by chain kernels that carry the
 // previous scope's weight gradients in extra workgroups of their own launch.

@@ -323,6 +323,7 @@ struct amt_ctx {
   float* amax = nullptr;        // [layers][prev q,k,v,- | cur q,k,v,-]: delayed per-tensor scaling state
   uint64_t* seed_word = nullptr;   // device word added to every dropout seed (amt_seed_word / amt_advance_seed)
   TeamState* team = nullptr;    // XCD-team protocol words (team.h); null: team launches disabled (AMT_TEAM=0)
+  bool cnn_wgrad_late = false;  // AMT_CNN_WGRAD_LATE=1: CNN weight gradients as one batch of launches after the pass (measured slower)
   bool fuse_ffn = true;         // AMT_FUSE_FFN=0: second half of a layer as chain + two tiled GEMM launches
 
   const float* P(size_t off) const { return params + off; }
@@ -695,6 +696,14 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   int dbg_bwd = 0;   // micro-benchmark builds only (AMT_CHAIN_TIMING)
   auto G = [&](size_t off) { return grads + off; };
   std::vector<WgradArgs> pending, pending_skinny;
+  // CNN weight gradients "late" (round-2 experiment, opt-in AMT_CNN_WGRAD_LATE=1): riders make every Block-backward
+  // launch end with its rider workgroups (26.9 us against 14.2 us for the chain, profiles/r01_notes.md).  Here every CNN
+  // weight gradient is queued instead, its operands (du, dy) stay in buffers of their own (~220 MB at cfg2) and the
+  // batch runs after the pass as 9 grouped launches.  Measured: Block backward 29.4 -> 22.1 us per launch, but the
+  // 64 x 64-tile weight-gradient kernel reaches only 87-100 TFLOP/s on the batch (9 x 36-41 us): 3.85-3.91 ms/step
+  // against 3.77 with riders (profiles/r02_notes.md).  Riders stay the default.
+  std::vector<WgradArgs> cnn_late;
+  bool late_mode = false;
   auto wgrad = [&](const void* Gm, int ldg, const void* Am, int lda, int n, int M, int Kp, size_t w_off, int ldw,
                    long b_off, int m_store, const float* row_scale = nullptr) {
     WgradArgs w;
@@ -702,6 +711,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     w.row_scale = row_scale;
     w.G = Gm; w.ldg = ldg; w.A = Am; w.lda = lda; w.N = n; w.M = M; w.Kp = Kp;
     w.dW = G(w_off); w.ldw = ldw; w.dbias = b_off >= 0 ? G((size_t)b_off) : nullptr; w.M_store = m_store;
+    if (late_mode) { cnn_late.push_back(w); return; }             // CNN stages: one batch of launches after the pass
     const int tiles = ((M + 63) / 64) * ((Kp + 63) / 64);
     if (tiles == 1 && n >= 16384) pending_skinny.push_back(w);   // per-split records (gemm.hip)
     else pending.push_back(w);                                    // grouped launch
@@ -815,6 +825,16 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   mark = A.off;
   A.off = mark + 2 * c->scratch_max;     // both scratch regions are part of the plan
   if (A.off > A.peak) A.peak = A.off;
+  // buffers that live until the end of the pass (operands of the late CNN weight gradients), behind the scratch regions
+  size_t keep_off = mark + 2 * c->scratch_max;
+  auto keep_alloc = [&](size_t bytes) -> void* {
+    const size_t o = (keep_off + 255) & ~(size_t)255;
+    keep_off = o + bytes;
+    if (keep_off > A.peak) A.peak = keep_off;
+    if (A.dry) return reinterpret_cast<void*>(o + 4096);
+    if (keep_off > A.cap) { A.overflow = true; if (A.stop) *A.stop = true; return A.base; }
+    return A.base + o;
+  };
   begin_scope();
 
   // loss + dlogits
@@ -969,6 +989,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   }
   if (phase == 2) { live = true; sink.dry = dry || A.overflow; deferred.clear(); }   // phase 1 ran the deferred problems itself (none of them takes sink records)
   // CNN stages, last to first
+  late_mode = c->cnn_wgrad_late && !side_on;
   int Lcur = S;
   for (int si = cfg.n_stages - 1; si >= 0; --si) {
     const StageP& st = L.stages[si];
@@ -984,7 +1005,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       if (C <= 8 && c->fuse && !(c->nochain & 512)) {
         // stages 0 / 1: the whole Block backward, weight gradients included, in one launch
         di = (di + 1) % 4;
-        void* dx = dbuf[di];
+        void* dx = late_mode ? keep_alloc((size_t)Nn * C * es) : dbuf[di];
         SmallBwdArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.dY = dy; sa.X = bs.x; sa.U = bs.u; sa.Hh = bs.h; sa.Z = bs.z; sa.LN = bs.ln; sa.mean = bs.mean; sa.rstd = bs.rstd;
@@ -1002,11 +1023,11 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       // gamma-scaled copy of pw2^T, the pw2 weight/bias gradients are row-scaled in their epilogue
       // and dgamma = sum dy * z is formed in the fused tail kernel.
       wgrad(dy, C, bs.h, 2 * C, Nn, C, 2 * C, bp.pw2_w, 2 * C, (long)bp.pw2_b, 0, c->P(bp.gamma));
-      void* du = A.alloc((size_t)Nn * 2 * C * es);
+      void* du = late_mode ? keep_alloc((size_t)Nn * 2 * C * es) : A.alloc((size_t)Nn * 2 * C * es);
       if (c->fuse && C >= 16 && !(c->nochain & 2)) {
         wgrad(du, 2 * C, bs.ln, C, Nn, 2 * C, C, bp.pw1_w, C, (long)bp.pw1_b, 0);
         di = (di + 1) % 4;
-        void* dx = dbuf[di];
+        void* dx = late_mode ? keep_alloc((size_t)Nn * C * es) : dbuf[di];   // late: the next Block's dy operand must survive
         BlockBwdArgs ba;
         memset(&ba, 0, sizeof(ba));
         ba.dY = dy; ba.X = bs.x; ba.U = bs.u; ba.Z = bs.z; ba.W2tg = c->WC(bp.c_pw2tgp); ba.W1t = c->WC(bp.c_pw1tp);
@@ -1031,7 +1052,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       }
       wgrad(du, 2 * C, bs.ln, C, Nn, 2 * C, C, bp.pw1_w, C, (long)bp.pw1_b, 0);
       di = (di + 1) % 4;
-      void* dx = dbuf[di];
+      void* dx = late_mode ? keep_alloc((size_t)Nn * C * es) : dbuf[di];
       dwblock_bwd(s, dt, dln, bs.x, dy, bs.z, c->P(bp.dw_w), c->P(bp.dw_b), bs.mean, bs.rstd, c->P(bp.ln_w), dx,
                   G(bp.ln_w), G(bp.ln_b), G(bp.dw_w), G(bp.dw_b), G(bp.gamma), B, Lcur, C, &sink);
       dcur = dx;
@@ -1047,7 +1068,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
         RUN(gemm_nt(s, dt, EPI_STORE, g));
       }
       di = (di + 1) % 4;
-      void* dx = dbuf[di];
+      void* dx = late_mode ? keep_alloc((size_t)B * Lin * Cin * es) : dbuf[di];
       layernorm_bwd(s, dt, dln, sv.x, sv.mean, sv.rstd, c->P(st.ln_w), nullptr, dx, G(st.ln_w), G(st.ln_b), B * Lin,
                         Cin, &sink);
       dcur = dx;
@@ -1059,6 +1080,14 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     }
   }
   flush_deferred();
+  late_mode = false;
+  {   // the CNN weight gradients, 8 problems per launch, many token splits (the launches are large and independent)
+    static const int late_target = getenv("AMT_LATE_WGRAD_WGS") ? atoi(getenv("AMT_LATE_WGRAD_WGS")) : 1024;
+    for (size_t i = 0; i < cnn_late.size(); i += 8) {
+      const int cnt = (int)std::min<size_t>(8, cnn_late.size() - i);
+      gemm_tn_wgrad_group(s, dt, cnn_late.data() + i, cnt, &sink, late_target);
+    }
+  }
   // train.py:319-322: grads / grad_scale, all-finite flag (the flag was set to 1 when the pass began)
   // join: the main stream waits for the side work of the last two scopes (older ones were waited for
   // when their regions were reused)
@@ -1268,6 +1297,7 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
     c->team = team_state_create();
     if (c->team == nullptr) { g_create_error = "hipMalloc(team state)"; delete c; return 1; }
   }
+  c->cnn_wgrad_late = getenv("AMT_CNN_WGRAD_LATE") && atoi(getenv("AMT_CNN_WGRAD_LATE")) != 0;
   if (c->nochain == 0) {   // keep only the conversions the selected execution mode reads (debug mask: keep all)
     const bool chain_tr = c->fuse && cfg->dims[cfg->n_stages - 1] == 256 && cfg->ffn_inter == 512 &&
                           cfg->n_heads * cfg->head_dim == 256 && cfg->kv_compress == 64;
