@@ -752,8 +752,9 @@ void block_bwd_fused(hipStream_t s, DType dt, const BlockBwdArgs& a_in, float* d
 // ------------------------------------------------------------------ transformer layer, second half, forward
 // One workgroup per tile of TT tokens; all 256 hidden features of a token stay in the workgroup, so
 // the LayerNorm between the output projection and the FFN is a row pass over an LDS panel.
-// (backward chains: 16-token tiles with bf16 gave wrong gradients in an experiment - not investigated; 32 / 16 are the
-// tested pairs)
+// (backward chains: round 1 saw wrong bf16 gradients with 16-token tiles; round 2: the kernels are fine with 16 - the
+// record count in chain_ln_records still assumed 32 - but with their riders they are slower: qkv_bwd_fused+wgrad 29.8
+// against 25.2 us, 3.84 against 3.77 ms/step)
 template <typename T> struct FfnTile { static constexpr int TT = sizeof(T) == 2 ? 32 : 16; };
 // forward chains: 16-token tiles for both dtypes (250 instead of 125 workgroups at cfg2: qkv_fwd_fused 11.4 -> 10.1 us,
 // attn_out_fused 8.8 -> 8.0 us); the backward chains keep 32 (they are bound by their riders, profiles/r01_notes.md)
@@ -1443,7 +1444,7 @@ static void ffn_bwd_fused_launch(hipStream_t s, const FfnBwdArgs& a, const Wgrad
 }
 
 static int chain_ln_records(DType dt, int N, float* dlnw, float* dlnb, PartialSink* sink, float** rec, int tile = 0) {
-  const int TT = tile > 0 ? tile : (dt == DT_F32 ? 16 : 32), nb = (N + TT - 1) / TT;
+  const int TT = tile > 0 ? tile : (dt == DT_F32 ? 16 : 32), nb = (N + TT - 1) / TT;   // default == FfnTile<T>::TT
   size_t o = sink->take((size_t)nb * 512);
   sink->add(o, nb, 512, 256, dlnw);
   sink->add(o + 256, nb, 512, 256, dlnb);

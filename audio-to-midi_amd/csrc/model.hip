@@ -70,7 +70,8 @@ size_t align8(size_t x) { return (x + 7) & ~(size_t)7; }
 
 // who reads a compute copy: amt_create drops the conversions nobody reads in the selected mode
 // (convert_batch runs after every optimizer step: 69 -> ~35 us with the default chains)
-enum ConvNeed { NEED_ALWAYS = 0, NEED_UNFUSED_BLOCK, NEED_FUSED_BLOCK, NEED_UNFUSED_TR, NEED_FUSED_TR, NEED_FFN_CHAIN };
+enum ConvNeed { NEED_ALWAYS = 0, NEED_UNFUSED_BLOCK, NEED_FUSED_BLOCK, NEED_UNFUSED_TR, NEED_FUSED_TR, NEED_FFN_CHAIN,
+                NEED_FFN_TILED };   // row-major W1 / W2 copies: only the tiled-GEMM form of the FFN reads them
 
 bool validate(const amt_config& c, std::string& err) {
   if (c.n_stages < 1 || c.n_stages > AMT_MAX_STAGES) { err = "n_stages out of range"; return false; }
@@ -197,7 +198,7 @@ Layout build_layout(const amt_config& c) {
     cpair(l.wqc, L.QC, H, l.c_wqc, l.c_wqct);
     cpair(l.wkv, L.KVW, c.kv_compress, l.c_wkv, l.c_wkvt);
     cpair(l.wo, H, HD, l.c_wo, l.c_wot);
-    need_cur = NEED_ALWAYS;
+    need_cur = NEED_FFN_TILED;
     cpair(l.w1, L.I2, H, l.c_w1, l.c_w1t);
     cpair(l.w2, H, c.ffn_inter, l.c_w2, l.c_w2t);
     need_cur = NEED_FUSED_TR;
@@ -563,7 +564,8 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
     ls.r2 = (float*)A.alloc((size_t)N * sizeof(float));
     ls.u = A.alloc((size_t)N * L.I2 * es);
     ls.g = A.alloc((size_t)N * (L.I2 / 2) * es);
-    const bool chain_ok = c->fuse && H == 256 && cfg.ffn_inter == 512 && cfg.n_heads * cfg.head_dim == 256;
+    const bool chain_ok = c->fuse && H == 256 && cfg.ffn_inter == 512 && cfg.n_heads * cfg.head_dim == 256 &&
+                          cfg.kv_compress == 64;   // == the predicate the weight copies are derived under (amt_create)
     auto qkv_args = [&](size_t l, const void* x) {
       const LayerP& q = L.layers[l];
       const LayerSave& t = c->lsave[l];
@@ -1306,7 +1308,7 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
       const int need = c->L.conv_need[i];
       const bool use = need == NEED_ALWAYS || (need == NEED_UNFUSED_BLOCK && !c->fuse) || (need == NEED_FUSED_BLOCK && c->fuse) ||
                        (need == NEED_UNFUSED_TR && !chain_tr) || (need == NEED_FUSED_TR && chain_tr) ||
-                       (need == NEED_FFN_CHAIN && chain_tr && c->fuse_ffn);
+                       (need == NEED_FFN_CHAIN && chain_tr && c->fuse_ffn) || (need == NEED_FFN_TILED && !(chain_tr && c->fuse_ffn));
       if (use) kept.push_back(c->L.conv[i]);
     }
     c->L.conv.swap(kept);
