@@ -116,6 +116,14 @@ AMT_DEV void block_fwd_tile(const BlockFwdArgs& a_in, const long n0, const long 
   // after the row phase (in flight during stage 1): holding both sets across the row phase pushed the
   // kernel past 256 registers = one wave per SIMD, and such launches paid ~6 us more between
   // dependent kernels in the training step (profiles/r01_notes.md).
+  uint32_t warm = 0;   // cooperative L2 warm-up (chain.h); the team form requests the weights one Block ahead instead
+  if constexpr (C >= 128 && !TEAM) {
+    const int q = blockIdx.x >> 3, ns = max(1, (int)(gridDim.x >> 3));
+    constexpr size_t WBYTES = chain_packed_elems(H2, C) * sizeof(T);
+    constexpr int MAXLD = (int)((WBYTES + 8 * 4096 - 1) / (8 * 4096)) + 1;
+    chain_l2_warm<MAXLD>(W1, WBYTES, q, ns, tid, warm);
+    chain_l2_warm<MAXLD>(W2, WBYTES, q, ns, tid, warm);
+  }
   Frag<T> wa[KC1][S1::RB], wb[KC2][S2::RB];
   AMT_DBG_IF(4096) chain_load_w<T, S1::RB, KC1, C>(wa, W1, m1, 0, lane);
   float bb1[S1::RB][4], bb2[S2::RB][4], gm[S2::RB][4];
@@ -249,6 +257,7 @@ AMT_DEV void block_fwd_tile(const BlockFwdArgs& a_in, const long n0, const long 
 #endif
   if constexpr (SAVE) chain_copy_out<T, TT, C, LDX>(Xs, reinterpret_cast<T*>(a.Z), n0, N, tid);
   chain_copy_out<T, TT, C, LDX>(Rs, reinterpret_cast<T*>(a.Y), n0, N, tid);
+  if (warm == 0x9e3779b9u && a.L < 0) a.mean[0] = 0.f;   // keeps the warm-up loads alive; never true
   AMT_STAMP(5);
   AMT_STAMP_RT(7);
 #ifdef AMT_CHAIN_TIMING
@@ -501,6 +510,14 @@ __global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a, Wg
 
   AMT_STAMP_RT(6);
   AMT_STAMP(0);
+  uint32_t warm = 0;   // cooperative L2 warm-up of the two 1x1 weights (chain.h) where they are big enough to matter
+  if constexpr (C >= 128) {
+    const int q = blockIdx.x >> 3, ns = max(1, a.n_chain >> 3);
+    constexpr size_t WBYTES = chain_packed_elems(H2, C) * sizeof(T);
+    constexpr int MAXLD = (int)((WBYTES + 8 * 4096 - 1) / (8 * 4096)) + 1;   // enough 4-KiB rounds for >= 8 slices
+    chain_l2_warm<MAXLD>(WA, WBYTES, q, ns, tid, warm);
+    chain_l2_warm<MAXLD>(WB, WBYTES, q, ns, tid, warm);
+  }
   Frag<T> wa[KCA][SA::RB], wb[KCB][SB::RB];
   chain_load_w<T, SA::RB, KCA, C>(wa, WA, mA, 0, lane);
   chain_load_w<T, SB::RB, KCB, H2>(wb, WB, mB, 0, lane);   // registers are idle until the row phases
@@ -681,6 +698,7 @@ __global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a, Wg
   const int nrec = a.Z != nullptr ? 11 * C : 10 * C;
   for (int t = tid; t < nrec; t += 256)
     rec[t] = (part[t] + part[11 * C + t]) + (part[22 * C + t] + part[33 * C + t]);
+  if (warm == 0x9e3779b9u && a.L < 0) rec[0] = 0.f;   // keeps the warm-up loads alive; never true
   AMT_STAMP(5);
   AMT_STAMP_RT(7);
 }
@@ -988,6 +1006,12 @@ AMT_DEV void qkv_fwd_body(const QkvFwdArgs& a, unsigned char* chain_smem, const 
 
   AMT_STAMP_RT(6);
   AMT_STAMP(0);
+  uint32_t warm = 0;   // cooperative L2 warm-up (chain.h)
+  {
+    const int q = blockIdx.x >> 3, ns = max(1, (int)(gridDim.x >> 3));
+    chain_l2_warm<4>(Wq, sizeof(T) * (size_t)QC * H, q, ns, tid, warm);
+    chain_l2_warm<2>(Wk, sizeof(T) * (size_t)KV * CK, q, ns, tid, warm);
+  }
   Frag<T> wq[KCQ][SQ::RB], wk[KCK][SK::RB];
   chain_load_w<T, SQ::RB, KCQ, H>(wq, Wq, mQ, 0, lane);
   if (XLDS == nullptr) {
@@ -1044,6 +1068,7 @@ AMT_DEV void qkv_fwd_body(const QkvFwdArgs& a, unsigned char* chain_smem, const 
   __syncthreads();
   AMT_STAMP(4);
   chain_copy_out<T, TT, KV, LDK>(Ks, reinterpret_cast<T*>(a.KV), n0, N, tid);
+  if (warm == 0x9e3779b9u && a.N < 0) a.mean[0] = 0.f;   // keeps the warm-up loads alive; never true
   AMT_STAMP(5);
   AMT_STAMP_RT(7);
 }
@@ -1149,6 +1174,12 @@ __global__ __launch_bounds__(256) void qkv_bwd_fused_kernel(QkvBwdArgs a, WgradG
 
   AMT_STAMP_RT(6);
   AMT_STAMP(0);
+  uint32_t warm = 0;   // cooperative L2 warm-up (chain.h), as in the FFN chains
+  {
+    const int q = blockIdx.x >> 3, ns = max(1, a.n_chain >> 3);
+    chain_l2_warm<2>(Wk, sizeof(T) * (size_t)CK * KV, q, ns, tid, warm);
+    chain_l2_warm<4>(Wq, sizeof(T) * chain_packed_elems(H, QC), q, ns, tid, warm);
+  }
   Frag<T> wk[KCC][SC::RB], wq[KCX][SX::RB];
   chain_load_w<T, SC::RB, KCC, KV>(wk, Wk, mC, 0, lane);
   chain_load_w<T, SX::RB, KCX, QC>(wq, Wq, mX, 0, lane);
@@ -1219,6 +1250,7 @@ __global__ __launch_bounds__(256) void qkv_bwd_fused_kernel(QkvBwdArgs a, WgradG
   float* rec = a.rec + (size_t)blockIdx.x * a.rec_stride;
   for (int t = tid; t < 2 * H; t += 256)
     rec[t] = (part[t] + part[2 * H + t]) + (part[4 * H + t] + part[6 * H + t]);
+  if (warm == 0x9e3779b9u && a.N < 0) rec[0] = 0.f;   // keeps the warm-up loads alive; never true
   AMT_STAMP(5);
   AMT_STAMP_RT(7);
 }
