@@ -867,7 +867,8 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     std::vector<WgradArgs> riders_a, riders_b;
     for (const WgradArgs& w : deferred) {
       const int tiles = ((w.M + 63) / 64) * ((w.Kp + 63) / 64);
-      (tiles < 24 ? riders_a : riders_b).push_back(w);
+      static const int split_tiles = getenv("AMT_RIDER_SPLIT") ? atoi(getenv("AMT_RIDER_SPLIT")) : 24;
+      (tiles < split_tiles ? riders_a : riders_b).push_back(w);
     }
     deferred.clear();
     const void* dy = dcur;
