@@ -351,6 +351,8 @@ int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* si
   memset(&g, 0, sizeof(g));
   if (n <= 0) return 0;
   g.n = n;
+  static const int xcd_order = getenv("AMT_WGRAD_XCD") ? atoi(getenv("AMT_WGRAD_XCD")) : 0;   // measured: 0 (profiles/r02_notes.md)
+  g.xcd = xcd_order;
   int total_tiles = 0;
   bool skinny[8];
   for (int i = 0; i < n; ++i) {

@@ -154,9 +154,20 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
 // several independent weight-gradient problems in one grid: b -> (problem, tile, token split)
 template <typename T>
 AMT_DEV void wgrad_group_dispatch(const WgradGroup& g, int b, unsigned char* smem) {
+  // Workgroups go to the XCDs round robin (b, b + 8, ... share one), work items are numbered problem by problem, split by
+  // split, tile by tile: give every XCD a CONTIGUOUS range of items, i.e. whole token splits, whose tiles then find each
+  // other's operand panels in their own L2 (the L2s do not share: a panel read on 8 XCDs crosses the fabric 8 times).
+  if (g.xcd == 1) {
+    const int R = g.prefix[g.n], per = R >> 3, rem = R & 7, c = b & 7;
+    b = c * per + (c < rem ? c : rem) + (b >> 3);
+  }
   int i = 0;
   while (i + 1 < g.n && b >= g.prefix[i + 1]) ++i;
-  const int local = b - g.prefix[i];
+  int local = b - g.prefix[i];
+  if (g.xcd == 2) {   // the same, problem by problem: every XCD keeps its eighth of every problem
+    const int R = g.prefix[i + 1] - g.prefix[i], per = R >> 3, rem = R & 7, c = local & 7;
+    local = c * per + (c < rem ? c : rem) + (local >> 3);
+  }
   tn_body<T>(g.p[i], g.tiles_k[i], g.rps[i], local % g.tiles[i], local / g.tiles[i], smem);
 }
 

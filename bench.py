@@ -320,19 +320,27 @@ def main():
                 traffic = json.load(f).get(top["name"], {}).get("hbm_bytes_per_launch")
         except OSError:
             pass
-        if top["flops"] > 0:
-            ach = top["flops"] / top["total_ms"] / 1e9
-            roofline = {"bound": "mfma", "kernel": top["name"], "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 5), "traffic": traffic,
-                        "avg_launch_us": round(1e3 * top["total_ms"] / top["launches"], 2),
-                        "flops_per_launch": top["flops"] / top["launches"],
-                        "algorithmic_bytes_per_launch": top["bytes"] / top["launches"]}
+        # Which roofline bounds the class: its arithmetic intensity (algorithmic flops / algorithmic bytes, both from
+        # the launch sites' ProfScope accounting) against the ridge PEAK_MFMA / PEAK_HBM =
+        # 312 flop/byte.  Below the ridge the HBM roof is the lower one, so the class is priced against HBM; the
+        # fraction of the other roof is reported beside it.
+        tf = top["flops"] / top["total_ms"] / 1e9
+        gbs = top["bytes"] / top["total_ms"] / 1e6
+        ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+        ai = top["flops"] / top["bytes"] if top["bytes"] else float("inf")
+        common = {"kernel": top["name"], "traffic": traffic,
+                  "avg_launch_us": round(1e3 * top["total_ms"] / top["launches"], 2),
+                  "flops_per_launch": top["flops"] / top["launches"],
+                  "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
+                  "arithmetic_intensity": round(ai, 1), "ridge": round(ridge, 1),
+                  "frac_mfma": round(tf / PEAK_BF16_TFLOPS, 5), "frac_hbm": round(gbs / PEAK_HBM_GBS, 5),
+                  "achieved_tflops": round(tf, 2), "achieved_gbs": round(gbs, 1)}
+        if ai >= ridge:
+            roofline = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / PEAK_BF16_TFLOPS, 5), **common}
         else:
-            ach = top["bytes"] / top["total_ms"] / 1e6
-            roofline = {"bound": "hbm", "kernel": top["name"], "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
-                        "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5), "traffic": traffic,
-                        "avg_launch_us": round(1e3 * top["total_ms"] / top["launches"], 2),
-                        "bytes_per_launch": top["bytes"] / top["launches"]}
+            roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(gbs / PEAK_HBM_GBS, 5), **common}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
