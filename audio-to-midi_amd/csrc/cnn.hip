@@ -550,14 +550,14 @@ void dwblock_bwd(hipStream_t s, DType dt, const void* dLN, const void* X, const 
 // broadcast from LDS.  Every tensor the backward pass needs is written exactly as the unfused
 // path writes it (LN output, u, h = gelu(u), z, y, mean, rstd), with the same roundings.
 template <typename T, int C>
-__global__ __launch_bounds__(256) void block_small_fwd_kernel(
+__global__ __launch_bounds__(256, 2) void block_small_fwd_kernel(
     const T* __restrict__ X, const float* __restrict__ wdw, const float* __restrict__ bdw,
     const float* __restrict__ lnw, const float* __restrict__ lnb, const T* __restrict__ w1, const float* __restrict__ b1,
     const T* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ gamma, T* __restrict__ LN,
     float* __restrict__ mean, float* __restrict__ rstd, T* __restrict__ U, T* __restrict__ Hh, T* __restrict__ Z,
     T* __restrict__ Y, int B, int L) {
   constexpr int H2 = 2 * C;
-  __shared__ float sw1[H2 * C], sw2[C * H2], sb1[H2], sb2[C], sg[C], sdw[7 * C], sbd[C], slw[C], slb[C];
+  __shared__ __attribute__((aligned(16))) float sw1[H2 * C], sw2[C * H2], sb1[H2], sb2[C], sg[C], sdw[7 * C], sbd[C], slw[C], slb[C];
   for (int t = threadIdx.x; t < H2 * C; t += 256) { sw1[t] = to_f(w1[t]); sw2[t] = to_f(w2[t]); }
   for (int t = threadIdx.x; t < H2; t += 256) sb1[t] = b1[t];
   for (int t = threadIdx.x; t < 7 * C; t += 256) sdw[t] = wdw[t];
@@ -570,6 +570,12 @@ __global__ __launch_bounds__(256) void block_small_fwd_kernel(
   for (long row = (long)blockIdx.x * 256 + threadIdx.x; row < N; row += (long)gridDim.x * 256) {
     const int b = (int)(row / L), l = (int)(row % L);
     const long rb = (long)b * L;
+    // The weights are read from LDS where they are used (same address in every lane: a broadcast).  `wz` is an opaque
+    // zero: without it the compiler keeps all 312 weights of C = 8 in registers across the loop (256 VGPRs + 188
+    // AGPRs, one wave per SIMD, and the 500 workgroups of stage 1 then run in two rounds).
+    int wz = 0;
+    asm volatile("" : "+v"(wz));
+    wz <<= 2;
     float x[7][C];
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
@@ -579,13 +585,13 @@ __global__ __launch_bounds__(256) void block_small_fwd_kernel(
     }
     float d[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) d[c] = sbd[c];
+    for (int c = 0; c < C; ++c) d[c] = sbd[wz + c];
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
       int ll = l + k - 3;
       float m = (ll >= 0 && ll < L) ? 1.f : 0.f;
 #pragma unroll
-      for (int c = 0; c < C; ++c) d[c] += sdw[k * C + c] * (x[k][c] * m);
+      for (int c = 0; c < C; ++c) d[c] += sdw[wz + k * C + c] * (x[k][c] * m);
     }
     float mu = 0.f;
 #pragma unroll
@@ -597,24 +603,24 @@ __global__ __launch_bounds__(256) void block_small_fwd_kernel(
     const float rs = 1.f / sqrtf(q * (1.f / C) + kLnEps);
     float ln[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) ln[c] = to_f(from_f<T>(d[c] * rs * slw[c] + slb[c]));
+    for (int c = 0; c < C; ++c) ln[c] = to_f(from_f<T>(d[c] * rs * slw[wz + c] + slb[wz + c]));
     float u[H2], h[H2];
 #pragma unroll
     for (int j = 0; j < H2; ++j) {
-      float a = sb1[j];
+      float a = sb1[wz + j];
 #pragma unroll
-      for (int c = 0; c < C; ++c) a += sw1[j * C + c] * ln[c];
+      for (int c = 0; c < C; ++c) a += sw1[wz + j * C + c] * ln[c];
       u[j] = to_f(from_f<T>(a));
       h[j] = to_f(from_f<T>(gelu_tanh(u[j])));
     }
     float z[C], y[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      float a = sb2[c];
+      float a = sb2[wz + c];
 #pragma unroll
-      for (int j = 0; j < H2; ++j) a += sw2[c * H2 + j] * h[j];
+      for (int j = 0; j < H2; ++j) a += sw2[wz + c * H2 + j] * h[j];
       z[c] = to_f(from_f<T>(a));
-      y[c] = x[3][c] + sg[c] * z[c];
+      y[c] = x[3][c] + sg[wz + c] * z[c];
     }
     storevf<C>(LN + row * C, ln);
     storevf<C>(Z + row * C, z);
@@ -700,8 +706,11 @@ template <int C> struct SmallBwd {
                        O_LNB = O_LNW + C, O_TAPS = O_LNB + C, O_DWB = O_TAPS + 7 * C, O_G = O_DWB + C, REC = O_G + C;
 };
 
-template <typename T, int C>
-__global__ __launch_bounds__(256) void block_small_bwd_full_kernel(
+// ONE: the grid has one workgroup per tile (no tile loop): the per-thread gradient accumulators are then plain
+// temporaries of the phase that produces them instead of values carried around a loop, which is what lets C = 8 fit
+// two waves per SIMD (512 workgroups resident at once instead of two rounds of 256).
+template <typename T, int C, bool ONE>
+__global__ __launch_bounds__(256, ONE ? 2 : 1) void block_small_bwd_full_kernel(
     const T* __restrict__ dY, const T* __restrict__ X, const T* __restrict__ U, const T* __restrict__ Hh,
     const T* __restrict__ Z, const T* __restrict__ LNs, const float* __restrict__ mean, const float* __restrict__ rstd,
     const T* __restrict__ w2tg, const T* __restrict__ w1t, const float* __restrict__ wdw, const float* __restrict__ bdw,
@@ -715,7 +724,7 @@ __global__ __launch_bounds__(256) void block_small_bwd_full_kernel(
   T (*ln_t)[FW] = h_t + 256;
   T (*dy_t)[FW] = ln_t + 256;
   T (*dDs)[C] = reinterpret_cast<T (*)[C]>(dy_t + 256);
-  __shared__ float s2[H2 * C], s1[C * H2], sdw[7 * C], sbd[C], slw[C], sg[C];
+  __shared__ __attribute__((aligned(16))) float s2[H2 * C], s1[C * H2], sdw[7 * C], sbd[C], slw[C], sg[C];
   for (int t = threadIdx.x; t < H2 * C; t += 256) { s2[t] = to_f(w2tg[t]); s1[t] = to_f(w1t[t]); }
   for (int t = threadIdx.x; t < 7 * C; t += 256) sdw[t] = wdw[t];
   if (threadIdx.x < C) { sbd[threadIdx.x] = bdw[threadIdx.x]; slw[threadIdx.x] = lnw[threadIdx.x]; sg[threadIdx.x] = gamma[threadIdx.x]; }
@@ -728,7 +737,7 @@ __global__ __launch_bounds__(256) void block_small_bwd_full_kernel(
     for (int k = 0; k < 7; ++k) aw[k][c] = 0.f;
   }
   f32x4 aw1 = f32x4{0.f, 0.f, 0.f, 0.f}, aw2 = aw1;
-  for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+  for (int t = blockIdx.x; t < total_tiles; t += ONE ? total_tiles : (int)gridDim.x) {
     const int b = t / tiles_per_clip, l0 = (t % tiles_per_clip) * TL;
     const long rb = (long)b * L;
     const int l = l0 - 3 + p;
@@ -737,88 +746,102 @@ __global__ __launch_bounds__(256) void block_small_bwd_full_kernel(
     const int lcl = l < 0 ? 0 : (l >= L ? L - 1 : l);
     const long row = rb + lcl;
     __syncthreads();   // weights staged / previous tile's tiles consumed
+    int wz = 0;        // opaque zero: the weights are read from LDS at their uses, not kept in registers (block_small_fwd)
+    asm volatile("" : "+v"(wz));
+    wz <<= 2;
     float dy[C];
     {
-      float u[H2], hh[H2], z[C], ln[C], x[7][C];
+      // Written in consumption order (what is loaded only to be staged or summed is finished first): the LDS stores keep
+      // the compiler from moving the loads much, and the order the source gives decides the register peak.
+      const float fin = inner ? 1.f : 0.f, fv = valid ? 1.f : 0.f;
+      float t0[8], t1[8];
       loadvf<C>(dY + row * C, dy);
-      loadvf<C>(Z + row * C, z);
-      loadvf<C>(LNs + row * C, ln);
-      if constexpr (H2 == 8) {
-        loadvf<8>(U + row * H2, u);
-        loadvf<8>(Hh + row * H2, hh);
-      } else {
-        float t0[8], t1[8];
-        loadvf<8>(U + row * H2, t0); loadvf<8>(U + row * H2 + 8, t1);
+      {   // h = gelu(u): only an operand tile of the pw2 weight gradient
+        float hh[H2];
+        if constexpr (H2 == 8) {
+          loadvf<8>(Hh + row * H2, hh);
+        } else {
+          loadvf<8>(Hh + row * H2, t0); loadvf<8>(Hh + row * H2 + 8, t1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { u[i] = t0[i]; u[8 + i] = t1[i]; }
-        loadvf<8>(Hh + row * H2, t0); loadvf<8>(Hh + row * H2 + 8, t1);
+          for (int i = 0; i < 8; ++i) { hh[i] = t0[i]; hh[8 + i] = t1[i]; }
+        }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { hh[i] = t0[i]; hh[8 + i] = t1[i]; }
+        for (int i = 0; i < 8; ++i) { t0[i] = i < H2 ? hh[i] : 0.f; t1[i] = (8 + i) < H2 ? hh[(8 + i) < H2 ? 8 + i : 0] : 0.f; }
+        storevf<8>(&h_t[p][0], t0); storevf<8>(&h_t[p][8], t1);
       }
+      {   // LN output: operand tile of the pw1 weight gradient (a ones column yields the pw1 bias gradient)
+        float ln[C];
+        loadvf<C>(LNs + row * C, ln);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { t0[i] = i < C ? ln[i < C ? i : 0] : (i == C ? 1.f : 0.f); t1[i] = (8 + i) == C ? 1.f : 0.f; }
+        storevf<8>(&ln_t[p][0], t0); storevf<8>(&ln_t[p][8], t1);
+      }
+      {   // z: layer-scale gradient; dy: pw2 bias gradient and operand tile
+        float z[C];
+        loadvf<C>(Z + row * C, z);
+#pragma unroll
+        for (int c = 0; c < C; ++c) { adb2[c] += fin * dy[c]; ag[c] += fin * dy[c] * z[c]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { t0[i] = i < C ? fin * dy[i < C ? i : 0] : 0.f; t1[i] = 0.f; }
+        storevf<8>(&dy_t[p][0], t0); storevf<8>(&dy_t[p][8], t1);
+      }
+      float dl[C];
+      {
+        float u[H2], du[H2];
+        if constexpr (H2 == 8) {
+          loadvf<8>(U + row * H2, u);
+        } else {
+          loadvf<8>(U + row * H2, t0); loadvf<8>(U + row * H2 + 8, t1);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { u[i] = t0[i]; u[8 + i] = t1[i]; }
+        }
+#pragma unroll
+        for (int j = 0; j < H2; ++j) {
+          float a = 0.f;
+#pragma unroll
+          for (int c = 0; c < C; ++c) a += s2[wz + j * C + c] * dy[c];
+          du[j] = to_f(from_f<T>(a * gelu_tanh_grad(u[j])));
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          float a = 0.f;
+#pragma unroll
+          for (int j = 0; j < H2; ++j) a += s1[wz + c * H2 + j] * du[j];
+          dl[c] = to_f(from_f<T>(a));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { t0[i] = i < H2 ? fin * du[i] : 0.f; t1[i] = (8 + i) < H2 ? fin * du[(8 + i) < H2 ? 8 + i : 0] : 0.f; }
+        storevf<8>(&du_t[p][0], t0); storevf<8>(&du_t[p][8], t1);
+      }
+      const float mu = mean[row], rs = rstd[row];
+      float d[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) d[c] = sbd[wz + c];
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
         const int ll = lcl + k - 3;
         const int lc = ll < 0 ? 0 : (ll >= L ? L - 1 : ll);
-        loadvf<C>(X + (rb + lc) * C, x[k]);
-      }
-      const float mu = mean[row], rs = rstd[row];
-      const float fin = inner ? 1.f : 0.f, fv = valid ? 1.f : 0.f;
-      float du[H2], dl[C];
-#pragma unroll
-      for (int j = 0; j < H2; ++j) {
-        float a = 0.f;
-#pragma unroll
-        for (int c = 0; c < C; ++c) a += s2[j * C + c] * dy[c];
-        du[j] = to_f(from_f<T>(a * gelu_tanh_grad(u[j])));
-      }
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        float a = 0.f;
-#pragma unroll
-        for (int j = 0; j < H2; ++j) a += s1[c * H2 + j] * du[j];
-        dl[c] = to_f(from_f<T>(a));
-      }
-      float d[C];
-#pragma unroll
-      for (int c = 0; c < C; ++c) d[c] = sbd[c];
-#pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        const int ll = lcl + k - 3;
         const float m = (ll >= 0 && ll < L) ? 1.f : 0.f;
+        float x[C];
+        loadvf<C>(X + (rb + lc) * C, x);
 #pragma unroll
-        for (int c = 0; c < C; ++c) d[c] += sdw[k * C + c] * (x[k][c] * m);
+        for (int c = 0; c < C; ++c) d[c] += sdw[wz + k * C + c] * (x[c] * m);
       }
       float q1 = 0.f, q2 = 0.f, gy[C], o[C];
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         d[c] = (d[c] - mu) * rs;
-        gy[c] = dl[c] * slw[c];
+        gy[c] = dl[c] * slw[wz + c];
         q1 += gy[c];
         q2 += gy[c] * d[c];
         alw[c] += fin * dl[c] * d[c];
         alb[c] += fin * dl[c];
-        adb2[c] += fin * dy[c];
-        ag[c] += fin * dy[c] * z[c];
       }
       q1 *= (1.f / C);
       q2 *= (1.f / C);
 #pragma unroll
       for (int c = 0; c < C; ++c) o[c] = fv * rs * (gy[c] - q1 - d[c] * q2);
       storevf<C>(&dDs[p][0], o);
-      // operand tiles of the two weight-gradient products (halo / out-of-clip rows contribute nothing)
-      float t0[8], t1[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { t0[i] = i < H2 ? fin * du[i] : 0.f; t1[i] = (8 + i) < H2 ? fin * du[(8 + i) < H2 ? 8 + i : 0] : 0.f; }
-      storevf<8>(&du_t[p][0], t0); storevf<8>(&du_t[p][8], t1);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { t0[i] = i < H2 ? hh[i] : 0.f; t1[i] = (8 + i) < H2 ? hh[(8 + i) < H2 ? 8 + i : 0] : 0.f; }
-      storevf<8>(&h_t[p][0], t0); storevf<8>(&h_t[p][8], t1);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { t0[i] = i < C ? ln[i < C ? i : 0] : (i == C ? 1.f : 0.f); t1[i] = (8 + i) == C ? 1.f : 0.f; }
-      storevf<8>(&ln_t[p][0], t0); storevf<8>(&ln_t[p][8], t1);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { t0[i] = i < C ? fin * dy[i < C ? i : 0] : 0.f; t1[i] = 0.f; }
-      storevf<8>(&dy_t[p][0], t0); storevf<8>(&dy_t[p][8], t1);
     }
     __syncthreads();
     {
@@ -837,7 +860,7 @@ __global__ __launch_bounds__(256) void block_small_bwd_full_kernel(
         const float mx = (lx >= 0 && lx < L) ? 1.f : 0.f;
         loadvf<C>(X + (rb + lxc) * C, x);
 #pragma unroll
-        for (int c = 0; c < C; ++c) { o[c] += sdw[k * C + c] * tq[c]; aw[k][c] += dd[c] * (x[c] * mx); }
+        for (int c = 0; c < C; ++c) { o[c] += sdw[wz + k * C + c] * tq[c]; aw[k][c] += dd[c] * (x[c] * mx); }
       }
       if (inner) storevf<C>(dX + row * C, o);
 #pragma unroll
@@ -888,17 +911,22 @@ __global__ __launch_bounds__(256) void block_small_bwd_full_kernel(
   }
 }
 
-template <typename T, int C>
-static void block_small_bwd_full_t(hipStream_t s, const SmallBwdArgs& a, float* rec, int nb, int tiles_per_clip, int total) {
+template <typename T, int C, bool ONE>
+static void block_small_bwd_full_launch(hipStream_t s, const SmallBwdArgs& a, float* rec, int nb, int tiles_per_clip, int total) {
   const size_t lds = (size_t)(4 * 256 * 16 + 256 * C) * sizeof(T);
   if (lds > 48 * 1024) {
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(block_small_bwd_full_kernel<T, C>),
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(block_small_bwd_full_kernel<T, C, ONE>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), true);
     (void)once;
   }
-  hipLaunchKernelGGL((block_small_bwd_full_kernel<T, C>), dim3(nb), dim3(256), lds, s, (const T*)a.dY, (const T*)a.X,
+  hipLaunchKernelGGL((block_small_bwd_full_kernel<T, C, ONE>), dim3(nb), dim3(256), lds, s, (const T*)a.dY, (const T*)a.X,
                      (const T*)a.U, (const T*)a.Hh, (const T*)a.Z, (const T*)a.LN, a.mean, a.rstd, (const T*)a.w2tg,
                      (const T*)a.w1t, a.wdw, a.bdw, a.lnw, a.gamma, (T*)a.dX, rec, a.B, a.L, tiles_per_clip, total);
+}
+template <typename T, int C>
+static void block_small_bwd_full_t(hipStream_t s, const SmallBwdArgs& a, float* rec, int nb, int tiles_per_clip, int total) {
+  if (nb == total) block_small_bwd_full_launch<T, C, true>(s, a, rec, nb, tiles_per_clip, total);
+  else block_small_bwd_full_launch<T, C, false>(s, a, rec, nb, tiles_per_clip, total);
 }
 
 void block_small_bwd_full(hipStream_t s, DType dt, const SmallBwdArgs& a, PartialSink* sink) {
