@@ -198,6 +198,34 @@ AMT_DEV void chain_ln_rows(const T* Xs, T* Ys, const float* __restrict__ w, cons
   }
 }
 
+// The same, output rows to global memory (row-major, C features; rows >= N are not written): the LayerNorm of rows a
+// chain holds in LDS, for a consumer that is another launch (kernels.h: TailLn).
+template <typename T, int TT, int C, int LD>
+AMT_DEV void chain_ln_rows_out(const T* Xs, T* __restrict__ G, const float* __restrict__ w, const float* __restrict__ b,
+                               float* __restrict__ mean, float* __restrict__ rstd, long n0, long N, int tid) {
+  constexpr int LPR = C / 8, RPP = 256 / LPR;
+  static_assert(TT % RPP == 0, "row phase covers the tile in whole passes");
+  const int sub = tid % LPR, prow = tid / LPR;
+  float wv[8], bv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { wv[i] = w[sub * 8 + i]; bv[i] = b[sub * 8 + i]; }
+#pragma unroll
+  for (int pp = 0; pp < TT / RPP; ++pp) {
+    const int p = pp * RPP + prow;
+    float x[8];
+    load8f(Xs + p * LD + sub * 8, x);
+    float mu, rs;
+    ln_stats<8, LPR>(x, mu, rs);
+    float y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = ln_apply(x[i], rs, wv[i], bv[i]);
+    if (n0 + p < N) {
+      store8f(G + (n0 + p) * C + sub * 8, y);
+      if (sub == 0) { mean[n0 + p] = mu; rstd[n0 + p] = rs; }
+    }
+  }
+}
+
 // Cooperative L2 warm-up of a weight range.  Every workgroup of a chain kernel streams the SAME
 // weights, and the workgroups of one XCD (blockIdx % 8) run in lockstep, so a cold weight stream
 // advances at the miss rate of ONE compute unit's request window (~25 GB/s measured) while the other

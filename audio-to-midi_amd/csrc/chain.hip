@@ -257,6 +257,10 @@ AMT_DEV void block_fwd_tile(const BlockFwdArgs& a_in, const long n0, const long 
 #endif
   if constexpr (SAVE) chain_copy_out<T, TT, C, LDX>(Xs, reinterpret_cast<T*>(a.Z), n0, N, tid);
   chain_copy_out<T, TT, C, LDX>(Rs, reinterpret_cast<T*>(a.Y), n0, N, tid);
+  if constexpr (!TEAM) {   // the LayerNorm the next operator opens with, on the y rows while they are here (kernels.h: TailLn)
+    if (a.tail.w != nullptr)
+      chain_ln_rows_out<T, TT, C, LDX>(Rs, reinterpret_cast<T*>(a.tail.Y), a.tail.w, a.tail.b, a.tail.mean, a.tail.rstd, n0, N, tid);
+  }
   if (warm == 0x9e3779b9u && a.L < 0) a.mean[0] = 0.f;   // keeps the warm-up loads alive; never true
   AMT_STAMP(5);
   AMT_STAMP_RT(7);
@@ -470,8 +474,11 @@ void block_fwd_fused(hipStream_t s, DType dt, const BlockFwdArgs& a) {
 // A tile is TT consecutive positions of ONE clip: TL = TT - 6 interior rows + 3 halo rows each side
 // (the two GEMM stages are evaluated for the halo rows too: 6 / TT extra work instead of an exchange).
 // du is written to HBM for the weight-gradient launch; everything else stays in LDS.
+#ifndef AMT_BB16_TT
+#define AMT_BB16_TT 256
+#endif
 template <typename T, int C> struct BlockBwdTile {   // == DwTile<C>::ROWS of the unfused kernel
-  static constexpr int TT = C <= 32 ? 128 : (C <= 64 ? 64 : (sizeof(T) == 4 && C == 256 ? 16 : 32));
+  static constexpr int TT = (C == 16 && sizeof(T) == 2) ? AMT_BB16_TT : (C <= 32 ? 128 : (C <= 64 ? 64 : (sizeof(T) == 4 && C == 256 ? 16 : 32)));
 };
 
 template <typename T, int C, int TT>
@@ -720,7 +727,7 @@ static void block_bwd_fused_launch(hipStream_t s, const BlockBwdArgs& a, const W
 
 int block_bwd_fused_tile_len(DType dt, int C) {
   if (dt == DT_F32) return (C <= 32 ? 128 : (C <= 64 ? 64 : (C == 256 ? 16 : 32))) - 6;
-  return (C <= 32 ? 128 : (C <= 64 ? 64 : 32)) - 6;
+  return (C == 16 ? AMT_BB16_TT : (C <= 32 ? 128 : (C <= 64 ? 64 : 32))) - 6;
 }
 
 void block_bwd_fused(hipStream_t s, DType dt, const BlockBwdArgs& a_in, float* dlnw, float* dlnb, float* dwdw,

@@ -555,9 +555,11 @@ __global__ __launch_bounds__(256, 2) void block_small_fwd_kernel(
     const float* __restrict__ lnw, const float* __restrict__ lnb, const T* __restrict__ w1, const float* __restrict__ b1,
     const T* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ gamma, T* __restrict__ LN,
     float* __restrict__ mean, float* __restrict__ rstd, T* __restrict__ U, T* __restrict__ Hh, T* __restrict__ Z,
-    T* __restrict__ Y, int B, int L) {
+    T* __restrict__ Y, int B, int L, TailLn tail) {
   constexpr int H2 = 2 * C;
   __shared__ __attribute__((aligned(16))) float sw1[H2 * C], sw2[C * H2], sb1[H2], sb2[C], sg[C], sdw[7 * C], sbd[C], slw[C], slb[C];
+  __shared__ __attribute__((aligned(16))) float stw[C], stb[C];
+  if (tail.w != nullptr && threadIdx.x < C) { stw[threadIdx.x] = tail.w[threadIdx.x]; stb[threadIdx.x] = tail.b[threadIdx.x]; }
   for (int t = threadIdx.x; t < H2 * C; t += 256) { sw1[t] = to_f(w1[t]); sw2[t] = to_f(w2[t]); }
   for (int t = threadIdx.x; t < H2; t += 256) sb1[t] = b1[t];
   for (int t = threadIdx.x; t < 7 * C; t += 256) sdw[t] = wdw[t];
@@ -627,6 +629,17 @@ __global__ __launch_bounds__(256, 2) void block_small_fwd_kernel(
     storevf<C>(Y + row * C, y);
     mean[row] = mu;
     rstd[row] = rs;
+    if (tail.w != nullptr) {   // LayerNorm of the stored y row (kernels.h: TailLn), the roundings of ln_fwd_kernel
+      float t[C], tm, tr;
+#pragma unroll
+      for (int c = 0; c < C; ++c) t[c] = to_f(from_f<T>(y[c]));
+      ln_stats<C, 1>(t, tm, tr);
+#pragma unroll
+      for (int c = 0; c < C; ++c) t[c] = ln_apply(t[c], tr, stw[wz + c], stb[wz + c]);
+      storevf<C>(reinterpret_cast<T*>(tail.Y) + row * C, t);
+      tail.mean[row] = tm;
+      tail.rstd[row] = tr;
+    }
     if constexpr (H2 == 8) {
       storevf<8>(U + row * H2, u);
       storevf<8>(Hh + row * H2, h);
@@ -961,14 +974,16 @@ void block_small_bwd_full(hipStream_t s, DType dt, const SmallBwdArgs& a, Partia
 void block_small_fwd(hipStream_t s, DType dt, const void* X, const float* wdw, const float* bdw, const float* lnw,
                      const float* lnb, const void* w1, const float* b1, const void* w2, const float* b2,
                      const float* gamma, void* LN, float* mean, float* rstd, void* U, void* Hh, void* Z, void* Y, int B,
-                     int L, int C) {
+                     int L, int C, const TailLn* tail) {
   const long N = (long)B * L;
   const int grid = (int)std::min<long>((N + 255) / 256, 2048);
+  TailLn tl{};
+  if (tail != nullptr) tl = *tail;
   ProfScope ps(s, "block_small_fwd", 2.0 * N * (7 * C + 4 * C * C), 8.0 * N * C * (dt == DT_F32 ? 4 : 2));
 #define AMT_LAUNCH_SF(TT, CC_)                                                                                         \
   hipLaunchKernelGGL((block_small_fwd_kernel<TT, CC_>), dim3(grid), dim3(256), 0, s, (const TT*)X, wdw, bdw, lnw, lnb,  \
                      (const TT*)w1, b1, (const TT*)w2, b2, gamma, (TT*)LN, mean, rstd, (TT*)U, (TT*)Hh, (TT*)Z, (TT*)Y, \
-                     B, L)
+                     B, L, tl)
   if (dt == DT_F32) { if (C == 4) AMT_LAUNCH_SF(float, 4); else AMT_LAUNCH_SF(float, 8); }
   else { if (C == 4) AMT_LAUNCH_SF(bf16, 4); else AMT_LAUNCH_SF(bf16, 8); }
 #undef AMT_LAUNCH_SF

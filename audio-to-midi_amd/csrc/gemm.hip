@@ -370,7 +370,8 @@ int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* si
     by += ((double)a.N * a.M + (double)a.N * a.Kp) * es + (double)a.M * a.Kp * 4;
     if (skinny[i]) {
       const int Mst = a.M_store > 0 ? a.M_store : a.M;
-      int rps = 256;
+      static const int skinny_rps = getenv("AMT_SKINNY_RPS") ? atoi(getenv("AMT_SKINNY_RPS")) : 256;
+      int rps = skinny_rps;
       int splits = (a.N + rps - 1) / rps;
       if (splits > 1024) { splits = 1024; rps = ((a.N + splits - 1) / splits + 127) / 128 * 128; splits = (a.N + rps - 1) / rps; }
       const size_t rec = (size_t)Mst * a.Kp + (a.dbias ? Mst : 0);

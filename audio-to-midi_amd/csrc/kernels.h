@@ -125,12 +125,16 @@ void dwln_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const floa
 // dX = dRes + conv^T(dD) ; dwdw[k][c] += sum dD[l][c] X[l+k-3][c] ; dbdw[c] += sum dD
 void dwconv_bwd(hipStream_t s, DType dt, const void* dD, const void* X, const float* wdw, const void* dRes,
                 void* dX, float* dwdw, float* dbdw, int B, int L, int C, PartialSink* sink = nullptr);
+// LayerNorm of a Block's OUTPUT rows, evaluated by the launch that produces them (the LayerNorm a Downsample or the final
+// norm opens with, model.py:107-118, 759-762: row-local, so the tile that holds y can finish it): Y = LN(y), mean, rstd
+// exactly as layernorm_fwd writes them.  w == nullptr: off.
+struct TailLn { const float* w; const float* b; void* Y; float* mean; float* rstd; };
 // Whole Block forward per position for C in {4, 8} (dwconv + LN + pw1 + GELU + pw2 + gamma + residual);
 // w1 [2C][C], w2 [C][2C] are the T compute copies.  Writes LN, mean, rstd, U, H = gelu(U), Z, Y.
 void block_small_fwd(hipStream_t s, DType dt, const void* X, const float* wdw, const float* bdw, const float* lnw,
                      const float* lnb, const void* w1, const float* b1, const void* w2, const float* b2,
                      const float* gamma, void* LN, float* mean, float* rstd, void* U, void* Hh, void* Z, void* Y, int B,
-                     int L, int C);
+                     int L, int C, const TailLn* tail = nullptr);
 // dU = (w2tg . dY) * gelu'(U), dLN = w1t . dU per position (C in {4, 8}); w2tg [2C][C], w1t [C][2C] (T)
 void block_small_bwd(hipStream_t s, DType dt, const void* dY, const void* U, const void* w2tg, const void* w1t, void* dU,
                      void* dLN, long N, int C);
@@ -154,6 +158,7 @@ struct BlockFwdArgs {
   void* LN; float* mean; float* rstd; void* U; void* Hh; void* Z; void* Y;
   int B, L, C;
   int dbg_slot;   // micro-benchmark only (AMT_CHAIN_TIMING)
+  TailLn tail;
 };
 void block_fwd_fused(hipStream_t s, DType dt, const BlockFwdArgs& a);
 

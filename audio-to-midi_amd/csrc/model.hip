@@ -324,7 +324,7 @@ struct amt_ctx {
   float* amax = nullptr;        // [layers][prev q,k,v,- | cur q,k,v,-]: delayed per-tensor scaling state
   uint64_t* seed_word = nullptr;   // device word added to every dropout seed (amt_seed_word / amt_advance_seed)
   TeamState* team = nullptr;    // XCD-team protocol words (team.h); null: team launches disabled (AMT_TEAM=0)
-  bool cnn_wgrad_late = false;  // AMT_CNN_WGRAD_LATE=1: CNN weight gradients as one batch of launches after the pass (measured slower)
+  int cnn_late_max_c = 0;       // AMT_CNN_WGRAD_LATE=C: weight gradients of the CNN stages with <= C channels as one batch of launches after the pass (1 = all)
   bool fuse_ffn = true;         // AMT_FUSE_FFN=0: second half of a layer as chain + two tiled GEMM launches
 
   const float* P(size_t off) const { return params + off; }
@@ -431,6 +431,12 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
 
   void* cur = nullptr;
   int dbg_slot = 0;   // micro-benchmark builds only (AMT_CHAIN_TIMING)
+  // The LayerNorm a Downsample (or the final norm) opens with is evaluated by the launch of the stage's last Block on
+  // the y rows it holds (kernels.h: TailLn): one launch less per stage.  AMT_TAIL_LN=0 / debug-mask bit 8192: off.
+  static const bool tail_ln_env = !(getenv("AMT_TAIL_LN") && atoi(getenv("AMT_TAIL_LN")) == 0);
+  const bool tail_ln = c->fuse && tail_ln_env && !(c->nochain & 8192);
+  bool tail_done = false;
+  void* fn_y_tail = nullptr;
   for (int si = 0; si < cfg.n_stages; ++si) {
     const StageP& st = L.stages[si];
     StageSave& sv = c->ssave[si];
@@ -444,10 +450,13 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
       const int Lin = Lcur, Cin = st.Cin;
       Lcur = Lin / 2;
       sv.x = cur;
-      sv.ln = A.alloc((size_t)B * Lin * Cin * es);
-      sv.mean = (float*)A.alloc((size_t)B * Lin * sizeof(float));
-      sv.rstd = (float*)A.alloc((size_t)B * Lin * sizeof(float));
-      RUN(layernorm_fwd(s, dt, cur, c->P(st.ln_w), c->P(st.ln_b), sv.ln, sv.mean, sv.rstd, B * Lin, Cin));
+      if (!tail_done) {
+        sv.ln = A.alloc((size_t)B * Lin * Cin * es);
+        sv.mean = (float*)A.alloc((size_t)B * Lin * sizeof(float));
+        sv.rstd = (float*)A.alloc((size_t)B * Lin * sizeof(float));
+        RUN(layernorm_fwd(s, dt, cur, c->P(st.ln_w), c->P(st.ln_b), sv.ln, sv.mean, sv.rstd, B * Lin, Cin));
+      }
+      tail_done = false;
       void* y = out_buf((size_t)B * Lcur * C);
       GemmArgs g = gargs(sv.ln, 2 * Cin, c->WC(st.c_w), 2 * Cin, B * Lcur, C, 2 * Cin, c->P(st.conv_b), y, C);
       RUN(gemm_nt(s, dt, EPI_STORE, g));
@@ -500,11 +509,28 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
       bs.u = A.alloc((size_t)N * 2 * C * es);
       bs.h = A.alloc((size_t)N * 2 * C * es);
       bs.z = A.alloc((size_t)N * C * es);
+      TailLn tl{};
+      if (tail_ln && j + 1 == st.blocks.size() && (C <= 8 || !(c->nochain & 1))) {
+        if (si + 1 < cfg.n_stages) {          // the next stage's Downsample norm
+          const StageP& nx = L.stages[si + 1];
+          StageSave& nsv = c->ssave[si + 1];
+          nsv.ln = A.alloc((size_t)N * C * es);
+          nsv.mean = (float*)A.alloc((size_t)N * sizeof(float));
+          nsv.rstd = (float*)A.alloc((size_t)N * sizeof(float));
+          tl = TailLn{c->P(nx.ln_w), c->P(nx.ln_b), nsv.ln, nsv.mean, nsv.rstd};
+        } else if (C == L.H) {                // the final norm (model.py:759-762)
+          c->fn_mean = (float*)A.alloc((size_t)N * sizeof(float));
+          c->fn_rstd = (float*)A.alloc((size_t)N * sizeof(float));
+          fn_y_tail = A.alloc((size_t)N * C * es);
+          tl = TailLn{c->P(L.fn_w), c->P(L.fn_b), fn_y_tail, c->fn_mean, c->fn_rstd};
+        }
+        tail_done = tl.w != nullptr;
+      }
       if (C <= 8) {   // per-position kernel: the 1x1 convs are too narrow for an MFMA tile
         void* y = out_buf((size_t)N * C);
         RUN(block_small_fwd(s, dt, cur, c->P(bp.dw_w), c->P(bp.dw_b), c->P(bp.ln_w), c->P(bp.ln_b), c->WC(bp.c_pw1),
                             c->P(bp.pw1_b), c->WC(bp.c_pw2), c->P(bp.pw2_b), c->P(bp.gamma), bs.ln, bs.mean, bs.rstd,
-                            bs.u, bs.h, bs.z, y, B, Lcur, C));
+                            bs.u, bs.h, bs.z, y, B, Lcur, C, &tl));
         cur = y;
         continue;
       }
@@ -512,7 +538,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
         void* y = out_buf((size_t)N * C);
         BlockFwdArgs fa{cur, c->P(bp.dw_w), c->P(bp.dw_b), c->P(bp.ln_w), c->P(bp.ln_b), c->WC(bp.c_pw1p), c->P(bp.pw1_b),
                         c->WC(bp.c_pw2p), c->P(bp.pw2_b), c->P(bp.gamma), bs.ln, bs.mean, bs.rstd, bs.u, bs.h, bs.z, y,
-                        B, Lcur, C, dbg_slot++};
+                        B, Lcur, C, dbg_slot++, tl};
         if (!save) { fa.LN = nullptr; fa.mean = nullptr; fa.rstd = nullptr; fa.U = nullptr; fa.Hh = nullptr; fa.Z = nullptr; }
         RUN(block_fwd_fused(s, dt, fa));
         cur = y;
@@ -532,11 +558,14 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
   }
   // final LayerNorm; channels-last means the reference's transpose (model.py:762) is free
   const int S = Lcur, N = B * S, H = L.H;
-  if (!save) A.off = mark0;
   c->fn_x = cur;
-  c->fn_mean = (float*)A.alloc((size_t)N * sizeof(float));
-  c->fn_rstd = (float*)A.alloc((size_t)N * sizeof(float));
-  {
+  if (tail_done) {   // evaluated by the last Block's launch; its buffers sit above that Block's (dead in inference) saves
+    cur = fn_y_tail;
+    tail_done = false;
+  } else {
+    if (!save) A.off = mark0;
+    c->fn_mean = (float*)A.alloc((size_t)N * sizeof(float));
+    c->fn_rstd = (float*)A.alloc((size_t)N * sizeof(float));
     void* y = out_buf((size_t)N * H);
     RUN(layernorm_fwd(s, dt, cur, c->P(L.fn_w), c->P(L.fn_b), y, c->fn_mean, c->fn_rstd, N, H));
     cur = y;
@@ -992,13 +1021,14 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   }
   if (phase == 2) { live = true; sink.dry = dry || A.overflow; deferred.clear(); }   // phase 1 ran the deferred problems itself (none of them takes sink records)
   // CNN stages, last to first
-  late_mode = c->cnn_wgrad_late && !side_on;
+  auto late_for = [&](int si) { return si >= 0 && !side_on && L.stages[si].C <= c->cnn_late_max_c; };
   int Lcur = S;
   for (int si = cfg.n_stages - 1; si >= 0; --si) {
     const StageP& st = L.stages[si];
     const StageSave& sv = c->ssave[si];
     const int C = st.C;
     const int Nn = B * Lcur;
+    late_mode = late_for(si);
     for (int j = (int)st.blocks.size() - 1; j >= 0; --j) {
       const BlockP& bp = st.blocks[j];
       const BlockSave& bs = sv.blocks[j];
@@ -1071,7 +1101,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
         RUN(gemm_nt(s, dt, EPI_STORE, g));
       }
       di = (di + 1) % 4;
-      void* dx = late_mode ? keep_alloc((size_t)B * Lin * Cin * es) : dbuf[di];
+      void* dx = late_for(si - 1) ? keep_alloc((size_t)B * Lin * Cin * es) : dbuf[di];   // dy operand of the stage below
       layernorm_bwd(s, dt, dln, sv.x, sv.mean, sv.rstd, c->P(st.ln_w), nullptr, dx, G(st.ln_w), G(st.ln_b), B * Lin,
                         Cin, &sink);
       dcur = dx;
@@ -1300,7 +1330,8 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
     c->team = team_state_create();
     if (c->team == nullptr) { g_create_error = "hipMalloc(team state)"; delete c; return 1; }
   }
-  c->cnn_wgrad_late = getenv("AMT_CNN_WGRAD_LATE") && atoi(getenv("AMT_CNN_WGRAD_LATE")) != 0;
+  c->cnn_late_max_c = getenv("AMT_CNN_WGRAD_LATE") ? atoi(getenv("AMT_CNN_WGRAD_LATE")) : 0;
+  if (c->cnn_late_max_c == 1) c->cnn_late_max_c = 1 << 20;
   if (c->nochain == 0) {   // keep only the conversions the selected execution mode reads (debug mask: keep all)
     const bool chain_tr = c->fuse && cfg->dims[cfg->n_stages - 1] == 256 && cfg->ffn_inter == 512 &&
                           cfg->n_heads * cfg->head_dim == 256 && cfg->kv_compress == 64;
