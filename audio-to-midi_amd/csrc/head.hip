@@ -139,6 +139,33 @@ void copy_f32(hipStream_t s, const float* src, float* dst, size_t n) {
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(copy_f32_kernel, dim3(grid), dim3(256), 0, s, src, dst, n);
 }
+// Start of a training step in one launch: gradient accumulator = 0 (16-byte stores; 16-byte aligned, as the context
+// allocates it), loss accumulators = 0, all-finite flag = 1.
+__global__ void step_begin_kernel(f32x4* g, size_t n, float* loss_acc, int* valid) {
+  const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) g[i] = z;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float* gf = reinterpret_cast<float*>(g);
+    for (size_t i = n4 << 2; i < n; ++i) gf[i] = 0.f;
+    loss_acc[0] = 0.f; loss_acc[1] = 0.f; *valid = 1;
+  }
+}
+bool step_begin(hipStream_t s, float* grads, size_t n, float* loss_acc, int* valid) {
+  if ((reinterpret_cast<uintptr_t>(grads) & 15) != 0) return false;
+  hipLaunchKernelGGL(step_begin_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<f32x4*>(grads), n, loss_acc, valid);
+  return true;
+}
+// (loss, all-finite flag) of a step into the head / tail words of a gradient bucket (train.py: GradBucket), one launch
+__global__ void pack_tail_kernel(const float* loss, const int* valid, float* head_valid, float* tail_loss, float* tail_valid) {
+  const float v = valid[0] != 0 ? 1.f : 0.f;
+  if (tail_loss != nullptr) tail_loss[0] = loss[0];
+  if (tail_valid != nullptr) tail_valid[0] = v;
+  if (head_valid != nullptr) head_valid[0] = v;
+}
+void pack_tail(hipStream_t s, const float* loss, const int* valid, float* head_valid, float* tail_loss, float* tail_valid) {
+  hipLaunchKernelGGL(pack_tail_kernel, dim3(1), dim3(1), 0, s, loss, valid, head_valid, tail_loss, tail_valid);
+}
 void fill_f32(hipStream_t s, float* p, float v, size_t n) {
   if (n >= 65536 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {   // 16-byte stores for the big buffers
     const size_t n4 = n / 4;
@@ -332,11 +359,24 @@ __global__ __launch_bounds__(256) void adamw_compute_kernel(const float* __restr
   if (threadIdx.x == 0) atomicAdd(norm2, red[0] + red[1] + red[2] + red[3]);
 }
 
+// norm2[0]: sum of squares from pass 1; norm2[1]: count of workgroups of THIS launch that have read it (as a float bit
+// pattern of an unsigned counter).  The workgroup that reads last puts both back to zero, so the next step finds the
+// accumulator clean without a fill launch of its own - also under hipGraph replay and whatever the caller does between steps.
 __global__ void adamw_apply_kernel(float* __restrict__ p, const float* __restrict__ upd, size_t n,
-                                   const float* __restrict__ norm2, float clip, const int* __restrict__ gate_i,
+                                   float* __restrict__ norm2, float clip, const int* __restrict__ gate_i,
                                    const float* __restrict__ gate_f) {
+  __shared__ float s_nrm2;
+  if (threadIdx.x == 0) {
+    s_nrm2 = __hip_atomic_load(norm2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned* cnt = reinterpret_cast<unsigned*>(norm2 + 1);
+    if (atomicAdd(cnt, 1u) == gridDim.x - 1) {
+      __hip_atomic_store(norm2, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
   if (!adamw_gate_open(gate_i, gate_f)) return;
-  float nrm = sqrtf(norm2[0]);
+  float nrm = sqrtf(s_nrm2);
   float f = (clip > 0.f && nrm > clip) ? clip / nrm : 1.f;   // optax.clip_by_global_norm
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     p[i] += upd[i] * f;
@@ -350,7 +390,7 @@ void adamw_compute(hipStream_t s, const float* params, const float* grads, float
   hipLaunchKernelGGL(adamw_compute_kernel, dim3(2048), dim3(256), 0, s, params, grads, m, v, upd, lr_scale, n, lr, b1,
                      b2, eps, wd, bc1, bc2, norm2, gate_i, gate_f);
 }
-void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, const float* norm2, float clip,
+void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, float* norm2, float clip,
                  const int* gate_i, const float* gate_f) {
   ProfScope ps(s, "adamw_apply", 0, 12.0 * n);
   hipLaunchKernelGGL(adamw_apply_kernel, dim3(2048), dim3(256), 0, s, params, upd, n, norm2, clip, gate_i, gate_f);

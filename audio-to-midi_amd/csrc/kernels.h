@@ -346,9 +346,11 @@ void copy_pad_f32(hipStream_t s, const float* src, float* dst, size_t n, size_t 
 void adamw_compute(hipStream_t s, const float* params, const float* grads, float* m, float* v, float* upd,
                    const float* lr_scale, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
                    float* norm2, const int* gate_i = nullptr, const float* gate_f = nullptr);
-// pass 2: params += upd * min(1, clip / sqrt(norm2))
+// pass 2: params += upd * min(1, clip / sqrt(norm2)); norm2 = float[2] (sum, reader count), left zeroed for the next step
+bool step_begin(hipStream_t s, float* grads, size_t n, float* loss_acc, int* valid);   // false: not applicable (alignment)
+void pack_tail(hipStream_t s, const float* loss, const int* valid, float* head_valid, float* tail_loss, float* tail_valid);
 // gate_i / gate_f (device, either may be null): both passes are no-ops unless *gate_i != 0 and *gate_f >= 0.999
-void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, const float* norm2, float clip,
+void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, float* norm2, float clip,
                  const int* gate_i = nullptr, const float* gate_f = nullptr);
 
 // batched fp32 -> T weight conversion (plain copy or transpose), one launch for the whole model

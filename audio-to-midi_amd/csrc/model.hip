@@ -837,12 +837,16 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   c->ev_used = 0;
   if (dry) c->ev_needed = 0;
 
-  RUN(hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, grads_valid, 1));
   // Kernels, not hipMemsetAsync: under hipGraph replay (ROCm 7.2, MI355X) the captured memset nodes of
   // this step did not take effect from the second replay on (gradients accumulated over replays;
-  // scratch/graph_dbg2.py), kernel nodes keep their stream order.
-  RUN(fill_f32(s, grads, 0.f, L.n_params));
-  RUN(fill_f32(s, c->loss_acc, 0.f, 2));
+  // scratch/graph_dbg2.py), kernel nodes keep their stream order.  One launch for the three of them where it applies.
+  bool began = false;
+  RUN(began = step_begin(s, grads, L.n_params, c->loss_acc, grads_valid));
+  if (!began) {
+    RUN(hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, grads_valid, 1));
+    RUN(fill_f32(s, grads, 0.f, L.n_params));
+    RUN(fill_f32(s, c->loss_acc, 0.f, 2));
+  }
 
   // two ping-pong gradient buffers for the residual stream / CNN activations
   const size_t act_elems = (size_t)B * (T / 5) * 4;
@@ -1490,6 +1494,15 @@ uint64_t amt_plan_generation(const amt_ctx* c) { return c->plan_gen; }
 
 uint64_t* amt_seed_word(amt_ctx* c) { return c->seed_word; }
 
+int32_t amt_pack_tail(amt_ctx* c, const float* loss, const int32_t* grads_valid, float* head_valid, float* tail_loss,
+                      float* tail_valid, void* stream) {
+  if (loss == nullptr || grads_valid == nullptr) { c->err = "amt_pack_tail: null loss / grads_valid"; return 1; }
+  pack_tail(static_cast<hipStream_t>(stream), loss, grads_valid, head_valid, tail_loss, tail_valid);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { c->err = std::string("amt_pack_tail: ") + hipGetErrorString(e); return 1; }
+  return 0;
+}
+
 int32_t amt_advance_seed(amt_ctx* c, uint64_t delta, void* stream) {
   hipLaunchKernelGGL(advance_seed_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), c->seed_word, delta);
   hipError_t e = hipGetLastError();
@@ -1539,7 +1552,8 @@ int32_t amt_optimizer_init(amt_ctx* c, float layer_lr_decay) {
     HIPCHK(c, hipMalloc(&c->adam_v, n * sizeof(float)));
     HIPCHK(c, hipMalloc(&c->adam_upd, n * sizeof(float)));
     HIPCHK(c, hipMalloc(&c->lr_scale, n * sizeof(float)));
-    HIPCHK(c, hipMalloc(&c->norm2, sizeof(float)));
+    HIPCHK(c, hipMalloc(&c->norm2, 2 * sizeof(float)));   // [sum of squares, reader count]: adamw_apply leaves both zero
+    HIPCHK(c, hipMemset(c->norm2, 0, 2 * sizeof(float)));
     HIPCHK(c, hipMemset(c->adam_m, 0, n * sizeof(float)));
     HIPCHK(c, hipMemset(c->adam_v, 0, n * sizeof(float)));
   }
@@ -1568,7 +1582,6 @@ int32_t amt_adamw_step_gated(amt_ctx* c, const float* grads_flat, float lr_base,
   if (!c->adam_m || c->lr_scale_decay != layer_lr_decay) {
     if (amt_optimizer_init(c, layer_lr_decay)) return 1;
   }
-  fill_f32(s, c->norm2, 0.f, 1);
   adamw_compute(s, c->params, grads_flat, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, n, lr_base, b1, b2, eps,
                 weight_decay, step, c->norm2, valid_i32, valid_f32);
   adamw_apply(s, c->params, c->adam_upd, n, c->norm2, clip_norm, valid_i32, valid_f32);

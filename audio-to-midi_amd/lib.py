@@ -97,6 +97,7 @@ SIGNATURES = {
     "amt_plan_generation": (_u64, [_vp]),
     "amt_seed_word": (_vp, [_vp]),
     "amt_advance_seed": (_i32, [_vp, _u64, _vp]),
+    "amt_pack_tail": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amt_team_status": (_i32, [_vp]),
     "amt_adamw_step": (_i32, [_vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "amt_adamw_step_gated": (_i32, [_vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp, _vp]),

@@ -262,6 +262,19 @@ class OutputSequenceGenerator:
         from ``seed + seed_word``; capturing this call at the head of a step graph gives each replay fresh masks."""
         self._check(self._L.amt_advance_seed(self._h, int(delta), self._stream()), "amt_advance_seed")
 
+    def pack_tail(self, loss: torch.Tensor, valid: torch.Tensor, head_valid: Optional[torch.Tensor] = None,
+                  tail_loss: Optional[torch.Tensor] = None, tail_valid: Optional[torch.Tensor] = None):
+        """(loss float32[>=1], grads_valid int32[1]) -> control words of a gradient bucket, one launch (include/amt.h:
+        amt_pack_tail).  Each destination is a float32 view of ONE element (or None)."""
+        def p(t, dt):
+            if t is None:
+                return None
+            assert t.dtype == dt and t.is_contiguous() and t.numel() >= 1 and t.device == loss.device
+            return C.c_void_p(t.data_ptr())
+        self._check(self._L.amt_pack_tail(self._h, p(loss, torch.float32), p(valid, torch.int32), p(head_valid, torch.float32),
+                                          p(tail_loss, torch.float32), p(tail_valid, torch.float32), self._stream()),
+                    "amt_pack_tail")
+
     def seed_word(self) -> torch.Tensor:
         """The context's device seed word as an int64[1] tensor view (write to it to set the offset directly)."""
         ptr = self._L.amt_seed_word(self._h)

@@ -170,19 +170,16 @@ class HipTrainBackend:
         b = self.bucket
         loss, _, valid, _ = self.model.loss_and_grads(self.audio, self.labels, scale=self.scale, seed=seed, train=True,
                                                       grads_out=b.grads, sync=False)
-        b.tail[0] = loss[0]
-        b.tail[1] = valid[0].to(torch.float32)
-        b.head[0] = b.tail[1]
+        self.model.pack_tail(loss, valid, head_valid=b.head[0:1], tail_loss=b.tail[0:1], tail_valid=b.tail[1:2])
 
     def half(self, phase: int, seed: int):
         b = self.bucket
         self.model.loss_and_grads_phase(phase, self.audio, self.labels, b.grads, self.loss_buf, self.valid_buf,
                                         scale=self.scale, seed=seed, train=True)
         if phase == 1:      # captured with the half: no eager launches between the graphs and the collectives
-            b.tail[0] = self.loss_buf[0]
-            b.tail[1] = self.valid_buf[0].to(torch.float32)
+            self.model.pack_tail(self.loss_buf, self.valid_buf, tail_loss=b.tail[0:1], tail_valid=b.tail[1:2])
         else:
-            b.head[0] = self.valid_buf[0].to(torch.float32)
+            self.model.pack_tail(self.loss_buf, self.valid_buf, head_valid=b.head[0:1])
 
     def advance_seed(self):
         self.model.advance_seed(1)

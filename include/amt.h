@@ -148,6 +148,13 @@ uint64_t amt_plan_generation(const amt_ctx* ctx);
 uint64_t* amt_seed_word(amt_ctx* ctx);
 int32_t amt_advance_seed(amt_ctx* ctx, uint64_t delta, void* stream);
 
+/* (loss, all-finite flag) of the step just issued into the control words of a data-parallel gradient bucket
+ * [valid_all, pad x 3 | grads | loss, valid_first] (audio_to_midi_amd/train.py: GradBucket; the reference reduces loss and
+ * flag with the gradients, train.py:292-322): tail_loss[0] = loss[0], tail_valid[0] = head_valid[0] = 1.0 or 0.0.  Null
+ * destinations are skipped.  One launch on `stream`, graph-capturable; all pointers are device pointers. */
+int32_t amt_pack_tail(amt_ctx* ctx, const float* loss, const int32_t* grads_valid, float* head_valid, float* tail_loss,
+                      float* tail_valid, void* stream);
+
 /* In-launch XCD-team hand-offs (csrc/team.h) spin with a bound.  0 = none has ever given up in this context; non-zero =
  * a launch timed out (its outputs are undefined and every later team launch falls through): treat as fatal.
  * Host-synchronous read. */
