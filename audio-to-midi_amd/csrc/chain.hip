@@ -477,8 +477,11 @@ void block_fwd_fused(hipStream_t s, DType dt, const BlockFwdArgs& a) {
 #ifndef AMT_BB16_TT
 #define AMT_BB16_TT 256
 #endif
+#ifndef AMT_BB256_TT
+#define AMT_BB256_TT 16
+#endif
 template <typename T, int C> struct BlockBwdTile {   // == DwTile<C>::ROWS of the unfused kernel
-  static constexpr int TT = (C == 16 && sizeof(T) == 2) ? AMT_BB16_TT : (C <= 32 ? 128 : (C <= 64 ? 64 : (sizeof(T) == 4 && C == 256 ? 16 : 32)));
+  static constexpr int TT = (C == 16 && sizeof(T) == 2) ? AMT_BB16_TT : (C <= 32 ? 128 : (C <= 64 ? 64 : (C == 256 && (sizeof(T) == 4 || AMT_BB256_TT == 16) ? 16 : 32)));
 };
 
 template <typename T, int C, int TT>
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a, Wg
   T* DLs = Us + TT * LDH;                              // [TT][LDX]      dln, then dD in place
   T* Xt = DLs + TT * LDX;                              // [TT + 6][LDX]  block input, rows l0 - 6 .. (zero outside)
   float* part = reinterpret_cast<float*>(chain_smem);   // [4 waves][11 * C], over DYs/Us/DLs once they are dead
-  static_assert(sizeof(T) * TT * (2 * LDX + LDH) >= sizeof(float) * 44 * C, "column-sum slices fit over the dead panels");
+  static_assert(sizeof(T) * (TT * (2 * LDX + LDH) + (TT + 6) * LDX) >= sizeof(float) * 44 * C, "column-sum slices fit over the dead panels (Xt included: dead after row phase 2)");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -727,7 +730,7 @@ static void block_bwd_fused_launch(hipStream_t s, const BlockBwdArgs& a, const W
 
 int block_bwd_fused_tile_len(DType dt, int C) {
   if (dt == DT_F32) return (C <= 32 ? 128 : (C <= 64 ? 64 : (C == 256 ? 16 : 32))) - 6;
-  return (C == 16 ? AMT_BB16_TT : (C <= 32 ? 128 : (C <= 64 ? 64 : 32))) - 6;
+  return (C == 16 ? AMT_BB16_TT : (C <= 32 ? 128 : (C <= 64 ? 64 : (C == 256 ? AMT_BB256_TT : 32)))) - 6;
 }
 
 void block_bwd_fused(hipStream_t s, DType dt, const BlockBwdArgs& a_in, float* dlnw, float* dlnb, float* dwdw,

@@ -8,6 +8,7 @@ all-reduce XLA's GSPMD inserts implicitly in the reference.
 """
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass
 from typing import Callable, Optional, Tuple
 
@@ -42,6 +43,27 @@ def allreduce_bucket(bucket: torch.Tensor, dist=None) -> Tuple[torch.Tensor, flo
     tail = bucket[n:].tolist()
     valid = abs(tail[2] - 1.0) < 0.5 / max(world, 1)   # mean of 0/1 flags is 1 only if all are 1
     return bucket[:n], float(tail[0]), float(tail[1]), bool(valid)
+
+
+def create_learning_rate_schedule(base_learning_rate: float, warmup_steps: int, cosine_decay_steps: int) -> Callable[[int], float]:
+    """train.py:455-466: linear warm-up from 0 to ``base_learning_rate`` over ``warmup_steps`` updates, then a cosine decay
+    to 0 over ``cosine_decay_steps`` (optax.join_schedules of linear_schedule and cosine_decay_schedule).  The returned
+    function maps the update COUNT (0 for the first optimizer update, as optax counts) to the base learning rate; the
+    per-layer factors layer_lr_decay ** (max_depth - depth) (train.py:697-713) multiply it inside amt_adamw_step, which is
+    exact because both pieces of the schedule are linear in their base value.  Use:
+    ``model.adamw_step(grads, lr_base=schedule(step - 1), step=step)`` with ``step`` counting from 1."""
+    base = float(base_learning_rate)
+    warm, decay = int(warmup_steps), int(cosine_decay_steps)
+
+    def schedule(count: int) -> float:
+        c = int(count)
+        if c < warm:
+            return base * min(max(c / warm, 0.0), 1.0)
+        if decay <= 0:
+            return 0.0
+        return base * 0.5 * (1.0 + math.cos(math.pi * min(c - warm, decay) / decay))
+
+    return schedule
 
 
 @dataclass

@@ -133,3 +133,54 @@ def test_bce_known_answer():
     y = np.random.default_rng(0).uniform(0, 1, (7, 90))
     assert abs(nm.loss_from_output(np.zeros((7, 90)), y) - 7 * 90 * math.log(2)) < 1e-9
     assert abs(nm.loss_from_output(np.zeros((7, 90)), y, scale=4.0) - 4 * 7 * 90 * math.log(2)) < 1e-9
+
+
+def test_optimizer_oracle_core_equals_torch_adamw():
+    """oracle/optim.py pins: with one label, a constant learning rate and no clipping the reference's chain (train.py:
+    692-724: scale_by_adam(eps = 1e-3) -> add_decayed_weights -> scale_by_learning_rate) is torch.optim.AdamW
+    (decoupled weight decay, eps outside the square root)."""
+    from oracle import optim
+    rng = np.random.default_rng(3)
+    n = 257
+    p0 = rng.standard_normal(n)
+    chain = optim.AdamWChain(n, weight_decay=0.005, clip_norm=None)
+    tp = torch.tensor(p0, dtype=torch.float64, requires_grad=True)
+    opt = torch.optim.AdamW([tp], lr=3e-3, betas=(0.9, 0.999), eps=1e-3, weight_decay=0.005)
+    p = p0.copy()
+    for _ in range(5):
+        g = rng.standard_normal(n) * 0.1
+        p = chain.update(p, g, lr=3e-3)
+        tp.grad = torch.tensor(g, dtype=torch.float64)
+        opt.step()
+    assert np.abs(p - tp.detach().numpy()).max() < 1e-12
+
+
+def test_optimizer_oracle_schedule_clip_and_layer_decay_known_answers():
+    """Known answers for what torch has no counterpart of: the joined warm-up / cosine schedule (train.py:455-466), the
+    global-norm clip on the UPDATES (train.py:725) and the per-depth learning-rate factors (train.py:697-713); the
+    host-side schedule of the package (audio_to_midi_amd/train.py) must be the same function."""
+    from oracle import optim
+    import audio_to_midi_amd.train as atrain
+    base, warm, decay = 2e-4, 1000, 9000
+    sched = atrain.create_learning_rate_schedule(base, warm, decay)
+    assert optim.learning_rate(0, base, warm, decay) == 0.0                      # the first update does not move anything
+    assert math.isclose(optim.learning_rate(500, base, warm, decay), base / 2)
+    assert math.isclose(optim.learning_rate(1000, base, warm, decay), base)      # boundary: cosine at its start
+    assert math.isclose(optim.learning_rate(1000 + 4500, base, warm, decay), base / 2)
+    assert abs(optim.learning_rate(10_000, base, warm, decay)) < 1e-20
+    assert abs(optim.learning_rate(50_000, base, warm, decay)) < 1e-20           # stays at the end value
+    for c in (0, 1, 17, 999, 1000, 1001, 5500, 9999, 10_000, 12_345):
+        assert math.isclose(sched(c), optim.learning_rate(c, base, warm, decay), rel_tol=0, abs_tol=1e-18)
+    # layer decay: depths 0..39 for conv leaves, default label (-1) untouched
+    f = optim.lr_scale_from_depths(np.array([0, 39, 20, -1]), 0.7)
+    assert np.allclose(f, [0.7 ** 39, 1.0, 0.7 ** 19, 1.0])
+    # clip: the first Adam update of a constant gradient g is -lr * g / (|g| + eps) per element -> norm lr sqrt(n) |g| / (|g| + eps)
+    n, lr = 10_000, 0.05
+    chain = optim.AdamWChain(n, weight_decay=0.0, clip_norm=1.0)
+    p = chain.update(np.zeros(n), np.full(n, 3.0), lr=lr)
+    raw = lr * 3.0 / (3.0 + 1e-3) * math.sqrt(n)
+    assert raw > 1.0
+    assert math.isclose(float(np.linalg.norm(p)), 1.0, rel_tol=1e-12)            # scaled onto the ball
+    chain = optim.AdamWChain(n, weight_decay=0.0, clip_norm=1.0)
+    p = chain.update(np.zeros(n), np.full(n, 3.0), lr=lr / 10)
+    assert math.isclose(float(np.linalg.norm(p)), raw / 10, rel_tol=1e-12)       # inside: untouched
