@@ -11,8 +11,13 @@
 #ifdef AMT_CHAIN_TIMING
 __device__ unsigned long long amt_stamps[128][256][12];   // [launch slot][workgroup][phase]; 8 / 9: team barrier entered / left (100 MHz clock)
 // rider workgroups (wgrad.h: tn_body) stamp cycle counts into slot 127, indexed by blockIdx.x % 256 (last launch wins)
-#define AMT_WG_STAMP(k) do { if (threadIdx.x == 0) amt_stamps[127][blockIdx.x & 255][k] = __builtin_readcyclecounter(); } while (0)
-#define AMT_WG_NOTE(k, v) do { if (threadIdx.x == 0) amt_stamps[127][blockIdx.x & 255][k] = (unsigned long long)(v) + 1; } while (0)
+// (AMT_WG_FILTER = M * 1000 + Kp restricts the stamps to the riders of one problem shape, e.g. 256128: pw1 of a C = 128 Block)
+#ifndef AMT_WG_FILTER
+#define AMT_WG_FILTER 0
+#endif
+#define AMT_WG_ON (threadIdx.x == 0 && (AMT_WG_FILTER == 0 || a.M * 1000 + a.Kp == AMT_WG_FILTER))
+#define AMT_WG_STAMP(k) do { if (AMT_WG_ON) amt_stamps[127][blockIdx.x & 255][k] = __builtin_readcyclecounter(); } while (0)
+#define AMT_WG_NOTE(k, v) do { if (AMT_WG_ON) amt_stamps[127][blockIdx.x & 255][k] = (unsigned long long)(v) + 1; } while (0)
 #endif
 #include "chain.h"
 #include "kernels.h"
@@ -494,7 +499,14 @@ __global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a, Wg
   constexpr int KCA = ChainChunk<T, SA::RB, C>::KC, KCB = ChainChunk<T, SB::RB, H2>::KC;
   extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
   if ((int)blockIdx.x >= a.n_chain) {   // weight gradients of the previous scope ride on this launch
+#ifdef AMT_CHAIN_TIMING
+    if (threadIdx.x == 0) amt_stamps[a.dbg_slot & 127][((int)blockIdx.x - a.n_chain) & 255][10] = wall_clock64();
+#endif
     wgrad_group_dispatch<T>(riders, (int)blockIdx.x - a.n_chain, chain_smem);
+#ifdef AMT_CHAIN_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    if (threadIdx.x == 0) amt_stamps[a.dbg_slot & 127][((int)blockIdx.x - a.n_chain) & 255][11] = wall_clock64();
+#endif
     return;
   }
   T* DYs = reinterpret_cast<T*>(chain_smem);           // [TT][LDX]      dy (zero outside the clip)

@@ -397,6 +397,20 @@ int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* si
     splits = (a.N + rps - 1) / rps;
     g.rps[i] = rps;
     g.prefix[i + 1] = g.prefix[i] + g.tiles[i] * splits;
+    // Opt-in (AMT_WGRAD_REC_MIN_SPLITS=n): from n token splits on, every split writes its tile into a record of its own with
+    // plain stores instead of adding into the same 64 x 64 floats as the other splits, and reduce_partials sums the records
+    // once per step.  Measured at cfg2 with n = 3: Block-backward launches 27.95 -> 27.37 us, reduce_partials 31 -> 99 us
+    // (170 MB of records): slower overall, so the contended atomics are not what a rider waits for (profiles/r02_notes.md).
+    static const int rec_min = getenv("AMT_WGRAD_REC_MIN_SPLITS") ? atoi(getenv("AMT_WGRAD_REC_MIN_SPLITS")) : 0;   // measured: off (below)
+    if (sink && rec_min > 0 && splits >= rec_min && a.ldw == a.Kp) {
+      const int Mst = a.M_store > 0 ? a.M_store : a.M;
+      const size_t rec = (size_t)Mst * a.Kp + (a.dbias ? Mst : 0);
+      size_t o = sink->take((size_t)splits * rec);
+      sink->add(o, splits, (uint32_t)rec, (uint32_t)(Mst * a.Kp), a.dW);
+      if (a.dbias) sink->add(o + (size_t)Mst * a.Kp, splits, (uint32_t)rec, (uint32_t)Mst, a.dbias);
+      a.part = sink->dry ? nullptr : sink->ws + o;
+      a.part_stride = (int)rec;
+    }
   }
   if (flops) *flops = fl;
   if (bytes) *bytes = by;

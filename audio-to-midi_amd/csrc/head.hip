@@ -297,6 +297,23 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const PartDesc* __
                                                               const float* __restrict__ ws, float* __restrict__ grads) {
   const PartDesc d = descs[blockIdx.x];
   const float* src = ws + d.ws_off;
+  if (d.count >= 2048) {   // few records of many elements (weight-gradient tiles): blockIdx.y takes a slice of the ELEMENTS
+    const uint32_t per_e = ((d.count + gridDim.y - 1) / gridDim.y + 255) & ~255u;
+    const uint32_t e_end = min(d.count, (blockIdx.y + 1) * per_e);
+    for (uint32_t e = blockIdx.y * per_e + threadIdx.x; e < e_end; e += 256) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      uint32_t b = 0;
+      for (; b + 4 <= d.nblocks; b += 4) {
+        a0 += src[(size_t)b * d.stride + e];
+        a1 += src[(size_t)(b + 1) * d.stride + e];
+        a2 += src[(size_t)(b + 2) * d.stride + e];
+        a3 += src[(size_t)(b + 3) * d.stride + e];
+      }
+      for (; b < d.nblocks; ++b) a0 += src[(size_t)b * d.stride + e];
+      atomicAdd(&grads[d.dst_off + e], (a0 + a1) + (a2 + a3));   // one adder per element: uncontended
+    }
+    return;
+  }
   // blockIdx.y takes one of gridDim.y contiguous slices of the records
   const uint32_t per = (d.nblocks + gridDim.y - 1) / gridDim.y;
   const uint32_t b_beg = blockIdx.y * per;

@@ -4,6 +4,9 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef AMT_WGRAD_DEPTH
+#define AMT_WGRAD_DEPTH 1
+#endif
 #ifndef AMT_WG_STAMP
 #define AMT_WG_STAMP(k) do { } while (0)
 #define AMT_WG_NOTE(k, v) do { } while (0)
@@ -32,8 +35,7 @@ template <typename T> struct TnLds {
 template <typename T>
 AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx, int by, unsigned char* smem) {
   // TOK tokens per LDS stage (4 MFMA k-steps for bf16): every thread keeps 8 sixteen-byte loads in
-  // flight per stage, so a split of a few hundred tokens costs 2-4 memory round trips instead of
-  // one per 32 tokens.  One LDS buffer + register prefetch of the next stage.
+  // flight per stage.  One LDS buffer + register prefetch of the next AMT_WGRAD_DEPTH - 1 stages.
   constexpr int TOK = sizeof(T) == 2 ? 128 : 64;
   constexpr int NCH = TOK * 8 / 256;          // chunks per thread per operand per stage
   T (*Gs)[WLD] = reinterpret_cast<T (*)[WLD]>(smem);
@@ -61,24 +63,28 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
   for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
 
   const int lrow = tid >> 3, lc = tid & 7;   // thread covers rows lrow + 32 i, chunk lc
-  Chunk8<T> gr[NCH], ar[NCH];
-  auto load_tiles = [&](int nb) {
+  // DEPTH register sets: the loads of stages st + 1 .. st + DEPTH - 1 are in flight while stage st is multiplied.  With
+  // one set (round 1) a rider's stage took one full memory round trip under load (4.4 us measured in the Block-backward
+  // launches at cfg2, profiles/r02_notes.md): its 5 stages ran 22 us and every carrier launch ended with its riders.
+  constexpr int DEPTH = AMT_WGRAD_DEPTH;
+  Chunk8<T> gr[DEPTH][NCH], ar[DEPTH][NCH];
+  auto load_tiles = [&](Chunk8<T> (&g_)[NCH], Chunk8<T> (&a_)[NCH], int nb) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       int n = nb + lrow + 32 * i;
       bool ok = n < nend;
-      gr[i] = ok ? load_f_chunk(G + (size_t)n * a.ldg, m0 + 8 * lc, a.M) : chunk_zero<T>();
-      ar[i] = ok ? load_f_chunk(A + (size_t)n * a.lda, k0 + 8 * lc, a.Kp) : chunk_zero<T>();
+      g_[i] = ok ? load_f_chunk(G + (size_t)n * a.ldg, m0 + 8 * lc, a.M) : chunk_zero<T>();
+      a_[i] = ok ? load_f_chunk(A + (size_t)n * a.lda, k0 + 8 * lc, a.Kp) : chunk_zero<T>();
     }
   };
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](const Chunk8<T> (&g_)[NCH], const Chunk8<T> (&a_)[NCH]) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      chunk_store(&Gs[lrow + 32 * i][8 * lc], gr[i]);
-      chunk_store(&As[lrow + 32 * i][8 * lc], ar[i]);
+      chunk_store(&Gs[lrow + 32 * i][8 * lc], g_[i]);
+      chunk_store(&As[lrow + 32 * i][8 * lc], a_[i]);
       if (do_bias) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bsum[e] += chunk_get(gr[i], e);
+        for (int e = 0; e < 8; ++e) bsum[e] += chunk_get(g_[i], e);
       }
     }
   };
@@ -87,24 +93,32 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
   AMT_WG_STAMP(0);
   AMT_WG_NOTE(6, nsteps);
   AMT_WG_NOTE(7, a.M * 1000 + a.Kp);
-  if (nsteps > 0) load_tiles(nbeg);
-  for (int st = 0; st < nsteps; ++st) {
-    __syncthreads();                 // previous stage fully consumed
-    store_tiles();
-    __syncthreads();
-    if (st == 0) AMT_WG_STAMP(1);
-    if (st + 1 < nsteps) load_tiles(nbeg + (st + 1) * TOK);
 #pragma unroll
-    for (int kk = 0; kk < TOK / 32; ++kk) {
-      Frag<T> gf[2], af[2];
+  for (int d = 0; d < DEPTH; ++d)
+    if (d < nsteps) load_tiles(gr[d], ar[d], nbeg + d * TOK);
+  for (int st0 = 0; st0 < nsteps; st0 += DEPTH) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) gf[i] = frag_col16(&Gs[32 * kk + 8 * g][wm * 32 + i * 16], WLD, r);
+    for (int d = 0; d < DEPTH; ++d) {
+      const int st = st0 + d;
+      if (st < nsteps) {               // uniform over the workgroup
+        __syncthreads();               // previous stage fully consumed
+        store_tiles(gr[d], ar[d]);
+        __syncthreads();
+        if (st == 0) AMT_WG_STAMP(1);
+        if (st + DEPTH < nsteps) load_tiles(gr[d], ar[d], nbeg + (st + DEPTH) * TOK);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) af[j] = frag_col16(&As[32 * kk + 8 * g][wk * 32 + j * 16], WLD, r);
+        for (int kk = 0; kk < TOK / 32; ++kk) {
+          Frag<T> gf[2], af[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i) gf[i] = frag_col16(&Gs[32 * kk + 8 * g][wm * 32 + i * 16], WLD, r);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mma(acc[i][j], gf[i], af[j]);
+          for (int j = 0; j < 2; ++j) af[j] = frag_col16(&As[32 * kk + 8 * g][wk * 32 + j * 16], WLD, r);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma(acc[i][j], gf[i], af[j]);
+        }
+      }
     }
   }
 
