@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const PartDesc* __
                                                               const float* __restrict__ ws, float* __restrict__ grads) {
   const PartDesc d = descs[blockIdx.x];
   const float* src = ws + d.ws_off;
-  if (d.count >= 2048) {   // few records of many elements (weight-gradient tiles): blockIdx.y takes a slice of the ELEMENTS
+  if (d.count >= 2048 && d.nblocks <= 32) {   // few records of many elements (weight-gradient tiles, AMT_WGRAD_REC_MIN_SPLITS): blockIdx.y takes a slice of the ELEMENTS
     const uint32_t per_e = ((d.count + gridDim.y - 1) / gridDim.y + 255) & ~255u;
     const uint32_t e_end = min(d.count, (blockIdx.y + 1) * per_e);
     for (uint32_t e = blockIdx.y * per_e + threadIdx.x; e < e_end; e += 256) {
