@@ -545,29 +545,37 @@ __global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a, Wg
   chain_load_w<T, SB::RB, KCB, H2>(wb, WB, mB, 0, lane);   // registers are idle until the row phases
 
   // ---- staging: dy and u rows l0 - 3 .. l0 + TL + 2, x rows l0 - 6 .. l0 + TL + 5; rows outside the
-  // clip are loaded from a clamped row and zeroed (unconditional loads, see cnn.hip)
+  // clip are loaded from a clamped row and zeroed (unconditional loads, see cnn.hip).  Every load is issued here, but
+  // only dy is waited for before stage A: u (needed by its epilogue) and x (needed by the row phases) land in registers
+  // while the stage-A products run and go to LDS after them - at the start of a launch every workgroup of the chip is
+  // waiting for its first bytes at once and that round trip is the longest phase of the tile (profiles/r02_notes.md).
+  constexpr int NP = TT / RPP, NPX = (TT + 6 + RPP - 1) / RPP;
+  Chunk8<T> dyc[NP], uc0[NP], uc1[NP], xcr[NPX];
 #pragma unroll
-  for (int pp = 0; pp < TT / RPP; ++pp) {
-    const int p = pp * RPP + prow;
-    const int l = l0 - 3 + p;
+  for (int pp = 0; pp < NP; ++pp) {
+    const int l = l0 - 3 + pp * RPP + prow;
     const bool in = l >= 0 && l < L;
     const int lc = l < 0 ? 0 : (l >= L ? L - 1 : l);
-    Chunk8<T> dyc = chunk_load(dY + (rb + lc) * C + sub * 8);
-    if (!in) dyc = chunk_zero<T>();
-    chunk_store(DYs + p * LDX + sub * 8, dyc);
-    chunk_store(Us + p * LDH + sub * 8, chunk_load(U + (rb + lc) * H2 + sub * 8));
-    chunk_store(Us + p * LDH + C + sub * 8, chunk_load(U + (rb + lc) * H2 + C + sub * 8));
+    dyc[pp] = chunk_load(dY + (rb + lc) * C + sub * 8);
+    if (!in) dyc[pp] = chunk_zero<T>();
   }
 #pragma unroll
-  for (int pp = 0; pp < (TT + 6 + RPP - 1) / RPP; ++pp) {
-    const int p = pp * RPP + prow;
-    const int l = l0 - 6 + p;
+  for (int pp = 0; pp < NP; ++pp) {
+    const int l = l0 - 3 + pp * RPP + prow;
+    const int lc = l < 0 ? 0 : (l >= L ? L - 1 : l);
+    uc0[pp] = chunk_load(U + (rb + lc) * H2 + sub * 8);
+    uc1[pp] = chunk_load(U + (rb + lc) * H2 + C + sub * 8);
+  }
+#pragma unroll
+  for (int pp = 0; pp < NPX; ++pp) {
+    const int l = l0 - 6 + pp * RPP + prow;
     const bool in = l >= 0 && l < L;
     const int lc = l < 0 ? 0 : (l >= L ? L - 1 : l);
-    Chunk8<T> xc = chunk_load(X + (rb + lc) * C + sub * 8);
-    if (!in) xc = chunk_zero<T>();
-    if (p < TT + 6) chunk_store(Xt + p * LDX + sub * 8, xc);
+    xcr[pp] = chunk_load(X + (rb + lc) * C + sub * 8);
+    if (!in) xcr[pp] = chunk_zero<T>();
   }
+#pragma unroll
+  for (int pp = 0; pp < NP; ++pp) chunk_store(DYs + (pp * RPP + prow) * LDX + sub * 8, dyc[pp]);
   __syncthreads();
   AMT_STAMP(1);
 
@@ -576,6 +584,15 @@ __global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a, Wg
     f32x4 acc[SA::RB][SA::NT];
     chain_zero(acc);
     chain_stage<T, SA::RB, SA::NT, KCA, C>(acc, wa, WA, mA, DYs, LDX, tA, lane);
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+      chunk_store(Us + (pp * RPP + prow) * LDH + sub * 8, uc0[pp]);
+      chunk_store(Us + (pp * RPP + prow) * LDH + C + sub * 8, uc1[pp]);
+    }
+#pragma unroll
+    for (int pp = 0; pp < NPX; ++pp)
+      if (pp * RPP + prow < TT + 6) chunk_store(Xt + (pp * RPP + prow) * LDX + sub * 8, xcr[pp]);
+    __syncthreads();
 #pragma unroll
     for (int rbk = 0; rbk < SA::RB; ++rbk) {
       const int m = mA + 16 * rbk + 4 * g;
