@@ -172,6 +172,35 @@ AMT_DEV void chain_copy_in(T* Ps, const T* __restrict__ G, long n0, long N, int 
   }
 }
 
+// chain_copy_in in two halves: the loads are issued (into registers) where the launch starts, the LDS stores happen where
+// the panel is first needed - a panel that only an EPILOGUE reads is then on its way while the first products run.  At the
+// start of a launch every workgroup of the chip waits for its first bytes at once: that round trip is the longest single
+// wait of a tile (profiles/r02_notes.md), so only what the first stage multiplies should be waited for in front of it.
+template <typename T, int TT, int W> struct ChainCopyRegs { static constexpr int NR = (TT * (W / 8) + 255) / 256; Chunk8<T> v[NR]; };
+template <typename T, int TT, int W>
+AMT_DEV void chain_copy_load(ChainCopyRegs<T, TT, W>& regs, const T* __restrict__ G, int ldg, long n0, long N, int tid) {
+  constexpr int CPR = W / 8, TOTAL = TT * CPR;
+#pragma unroll
+  for (int i = 0; i < ChainCopyRegs<T, TT, W>::NR; ++i) {
+    const int id = tid + i * 256;
+    const int p = id / CPR, c = id % CPR;
+    if (TOTAL % 256 == 0 || id < TOTAL) {
+      const long row = n0 + p;
+      regs.v[i] = chunk_load(G + (row < N ? row : N - 1) * ldg + 8 * c);
+      if (row >= N) regs.v[i] = chunk_zero<T>();
+    }
+  }
+}
+template <typename T, int TT, int W, int LD>
+AMT_DEV void chain_copy_store(T* Ps, const ChainCopyRegs<T, TT, W>& regs, int tid) {
+  constexpr int CPR = W / 8, TOTAL = TT * CPR;
+#pragma unroll
+  for (int i = 0; i < ChainCopyRegs<T, TT, W>::NR; ++i) {
+    const int id = tid + i * 256;
+    if (TOTAL % 256 == 0 || id < TOTAL) chunk_store(Ps + (id / CPR) * LD + 8 * (id % CPR), regs.v[i]);
+  }
+}
+
 // Row LayerNorm over C = 8 * LPR features of the rows of an LDS panel (fp32 statistics, eqx LayerNorm):
 // Ys = LN(Xs) (may alias Xs row-for-row), mean / rstd to global for rows < N.
 template <typename T, int TT, int C, int LD>

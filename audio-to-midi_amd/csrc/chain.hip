@@ -862,7 +862,8 @@ AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem) {
   Frag<T> wo[KCO][SO::RB];
   chain_load_w<T, SO::RB, KCO, H>(wo, Wo, mO, 0, lane);
   chain_copy_in<T, TT, H, LDX>(As, reinterpret_cast<const T*>(a.AO), n0, N, tid);
-  chain_copy_in<T, TT, H, LDX>(Xs, reinterpret_cast<const T*>(a.X), n0, N, tid);
+  ChainCopyRegs<T, TT, H> xreg;     // x is read by the residual epilogue only: it lands while the products run
+  chain_copy_load<T, TT, H>(xreg, reinterpret_cast<const T*>(a.X), H, n0, N, tid);
   __syncthreads();
   AMT_STAMP(1);
 
@@ -872,6 +873,8 @@ AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem) {
     f32x4 acc[SO::RB][SO::NT];
     chain_zero(acc);
     chain_stage<T, SO::RB, SO::NT, KCO, H>(acc, wo, Wo, mO, As, LDX, tO, lane);
+    chain_copy_store<T, TT, H, LDX>(Xs, xreg, tid);
+    __syncthreads();
     if constexpr (FULL) chain_load_w<T, S1::RB, KC1, H>(w1a, W1, m1, 0, lane);   // in flight during the LayerNorm pass
 #pragma unroll
     for (int rb = 0; rb < SO::RB; ++rb) {
@@ -1187,7 +1190,7 @@ void qkv_fwd_fused(hipStream_t s, DType dt, const QkvFwdArgs& a) {
 
 // ------------------------------------------------------------------ transformer layer backward chains
 template <typename T, int TT>
-__global__ __launch_bounds__(256) void qkv_bwd_fused_kernel(QkvBwdArgs a, WgradGroup riders) {
+__global__ __launch_bounds__(256, 2) void qkv_bwd_fused_kernel(QkvBwdArgs a, WgradGroup riders) {   // two waves per SIMD: chain + rider workgroups share compute units
   a.seed = eff_seed(a.seed, a.seed_dev);   // kernel argument + the context's device seed word (common.h)
   constexpr int H = 256, QC = 320, CK = 64, KV = 512, LDX = H + 8, LDQ = QC + 8, LDK = KV + 8;
   using SC = ChainSplit<CK, TT>;     // dc: 64 features
@@ -1223,17 +1226,10 @@ __global__ __launch_bounds__(256) void qkv_bwd_fused_kernel(QkvBwdArgs a, WgradG
   chain_load_w<T, SC::RB, KCC, KV>(wk, Wk, mC, 0, lane);
   chain_load_w<T, SX::RB, KCX, QC>(wq, Wq, mX, 0, lane);
   chain_copy_in<T, TT, KV, LDK>(Ks, reinterpret_cast<const T*>(a.dKV), n0, N, tid);
-  {   // dq part of dqc (320-wide rows, the first 256 columns)
-    constexpr int CPR = H / 8, TOTAL = TT * CPR;
-#pragma unroll
-    for (int i = 0; i < (TOTAL + 255) / 256; ++i) {
-      const int id = tid + i * 256, p = id / CPR, c = id % CPR;
-      const long row = n0 + p;
-      Chunk8<T> v = chunk_load(reinterpret_cast<const T*>(a.dQC) + (row < N ? row : N - 1) * QC + 8 * c);
-      if (row >= N) v = chunk_zero<T>();
-      chunk_store(Qs + p * LDQ + 8 * c, v);
-    }
-  }
+  // dq part of dqc (320-wide rows, the first 256 columns): multiplied by the SECOND stage only, so it lands while the
+  // first one runs and goes to LDS behind its products (the barrier that follows the stage orders it)
+  ChainCopyRegs<T, TT, H> dqreg;
+  chain_copy_load<T, TT, H>(dqreg, reinterpret_cast<const T*>(a.dQC), QC, n0, N, tid);
   __syncthreads();
   AMT_STAMP(1);
 
@@ -1242,6 +1238,7 @@ __global__ __launch_bounds__(256) void qkv_bwd_fused_kernel(QkvBwdArgs a, WgradG
     f32x4 acc[SC::RB][SC::NT];
     chain_zero(acc);
     chain_stage<T, SC::RB, SC::NT, KCC, KV>(acc, wk, Wk, mC, Ks, LDK, tC, lane);
+    chain_copy_store<T, TT, H, LDQ>(Qs, dqreg, tid);
 #pragma unroll
     for (int rb = 0; rb < SC::RB; ++rb)
 #pragma unroll
@@ -1396,7 +1393,8 @@ __global__ __launch_bounds__(256) void ffn_bwd_fused_kernel(FfnBwdArgs a, WgradG
   Frag<T> wa[KCA][SO::RB], wb[KCB][SO::RB];
   chain_load_w<T, SO::RB, KCA, H>(wa, W2t, mO, 0, lane);
   chain_copy_in<T, TT, H, LDX>(Ds, reinterpret_cast<const T*>(a.dYD), n0, N, tid);
-  chain_copy_in<T, TT, I2, LDU>(Us, reinterpret_cast<const T*>(a.U), n0, N, tid);
+  ChainCopyRegs<T, TT, I2> ureg;   // u is read by the GLU' epilogue only: it lands while the first products run
+  chain_copy_load<T, TT, I2>(ureg, reinterpret_cast<const T*>(a.U), I2, n0, N, tid);
   __syncthreads();
 
   // ---- dg = dyd . W2 (two halves of 256 columns) ; du = GLU'(dg, u), in place over u
@@ -1404,6 +1402,10 @@ __global__ __launch_bounds__(256) void ffn_bwd_fused_kernel(FfnBwdArgs a, WgradG
     f32x4 acc[SO::RB][SO::NT];
     chain_zero(acc);
     chain_stage<T, SO::RB, SO::NT, KCA, H>(acc, wpre, W2t, 256 * half + mO, Ds, LDX, tO, lane);
+    if (half == 0) {
+      chain_copy_store<T, TT, I2, LDU>(Us, ureg, tid);
+      __syncthreads();
+    }
     // the next stage's first weights are requested before the epilogue (exp, LDS traffic) runs
     if (half == 0) chain_load_w<T, SO::RB, KCA, H>(wpre, W2t, 256 + mO, 0, lane);
     else chain_load_w<T, SO::RB, KCB, I2>(wb, W1t, mO, 0, lane);
