@@ -68,7 +68,29 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
   // launches at cfg2, profiles/r02_notes.md): its 5 stages ran 22 us and every carrier launch ended with its riders.
   constexpr int DEPTH = AMT_WGRAD_DEPTH;
   Chunk8<T> gr[DEPTH][NCH], ar[DEPTH][NCH];
+  // Whole 16-byte chunks everywhere (the usual case): UNCONDITIONAL loads from a clamped row / column and a select
+  // afterwards.  The guarded form below compiles into nested exec-mask branches with an `s_waitcnt vmcnt(0)` behind the
+  // first load of every chunk (the register shuffles of the partial-chunk arms), i.e. the 8 loads of a stage went out one
+  // round trip after the other: that, not the depth of the prefetch, was what a rider's stage waited for.
+  const bool whole = ((a.M | a.Kp | a.ldg | a.lda) & 7) == 0;      // uniform
+  const int gcol = m0 + 8 * lc, acol = k0 + 8 * lc;
+  const bool gin = gcol < a.M, ain = acol < a.Kp;
+  const T* Gc = G + (gin ? gcol : 0);
+  const T* Ac = A + (ain ? acol : 0);
   auto load_tiles = [&](Chunk8<T> (&g_)[NCH], Chunk8<T> (&a_)[NCH], int nb) {
+    if (whole) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int n = nb + lrow + 32 * i;
+        const bool ok = n < nend;
+        const size_t nc = (size_t)(ok ? n : nend - 1);
+        g_[i] = chunk_load(Gc + nc * a.ldg);
+        a_[i] = chunk_load(Ac + nc * a.lda);
+        if (!(ok && gin)) g_[i] = chunk_zero<T>();
+        if (!(ok && ain)) a_[i] = chunk_zero<T>();
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       int n = nb + lrow + 32 * i;
