@@ -560,12 +560,18 @@ __global__ __launch_bounds__(256, 2) void block_small_fwd_kernel(
   __shared__ __attribute__((aligned(16))) float sw1[H2 * C], sw2[C * H2], sb1[H2], sb2[C], sg[C], sdw[7 * C], sbd[C], slw[C], slb[C];
   __shared__ __attribute__((aligned(16))) float stw[C], stb[C];
   if (tail.w != nullptr && threadIdx.x < C) { stw[threadIdx.x] = tail.w[threadIdx.x]; stb[threadIdx.x] = tail.b[threadIdx.x]; }
-  for (int t = threadIdx.x; t < H2 * C; t += 256) { sw1[t] = to_f(w1[t]); sw2[t] = to_f(w2[t]); }
-  for (int t = threadIdx.x; t < H2; t += 256) sb1[t] = b1[t];
-  for (int t = threadIdx.x; t < 7 * C; t += 256) sdw[t] = wdw[t];
-  if (threadIdx.x < C) {
-    sb2[threadIdx.x] = b2[threadIdx.x]; sg[threadIdx.x] = gamma[threadIdx.x]; sbd[threadIdx.x] = bdw[threadIdx.x];
-    slw[threadIdx.x] = lnw[threadIdx.x]; slb[threadIdx.x] = lnb[threadIdx.x];
+  {   // every array has at most 256 entries: one UNCONDITIONAL load per thread and array from a clamped index, all issued
+      // back to back, then the LDS stores (guarded loads in loops compiled into one round trip after the other)
+    static_assert(H2 * C <= 256 && 7 * C <= 256, "one staging element per thread");
+    const int t = threadIdx.x;
+    const float r_w1 = to_f(w1[min(t, H2 * C - 1)]), r_w2 = to_f(w2[min(t, H2 * C - 1)]);
+    const float r_b1 = b1[min(t, H2 - 1)], r_dw = wdw[min(t, 7 * C - 1)];
+    const int tc = min(t, C - 1);
+    const float r_b2 = b2[tc], r_g = gamma[tc], r_bd = bdw[tc], r_lw = lnw[tc], r_lb = lnb[tc];
+    if (t < H2 * C) { sw1[t] = r_w1; sw2[t] = r_w2; }
+    if (t < H2) sb1[t] = r_b1;
+    if (t < 7 * C) sdw[t] = r_dw;
+    if (t < C) { sb2[t] = r_b2; sg[t] = r_g; sbd[t] = r_bd; slw[t] = r_lw; slb[t] = r_lb; }
   }
   __syncthreads();
   const long N = (long)B * L;
@@ -738,9 +744,15 @@ __global__ __launch_bounds__(256, ONE ? 2 : 1) void block_small_bwd_full_kernel(
   T (*dy_t)[FW] = ln_t + 256;
   T (*dDs)[C] = reinterpret_cast<T (*)[C]>(dy_t + 256);
   __shared__ __attribute__((aligned(16))) float s2[H2 * C], s1[C * H2], sdw[7 * C], sbd[C], slw[C], sg[C];
-  for (int t = threadIdx.x; t < H2 * C; t += 256) { s2[t] = to_f(w2tg[t]); s1[t] = to_f(w1t[t]); }
-  for (int t = threadIdx.x; t < 7 * C; t += 256) sdw[t] = wdw[t];
-  if (threadIdx.x < C) { sbd[threadIdx.x] = bdw[threadIdx.x]; slw[threadIdx.x] = lnw[threadIdx.x]; sg[threadIdx.x] = gamma[threadIdx.x]; }
+  {   // one unconditional load per thread and array, issued back to back (block_small_fwd_kernel)
+    static_assert(H2 * C <= 256 && 7 * C <= 256, "one staging element per thread");
+    const int t = threadIdx.x, tc = min(t, C - 1);
+    const float r_2 = to_f(w2tg[min(t, H2 * C - 1)]), r_1 = to_f(w1t[min(t, H2 * C - 1)]), r_dw = wdw[min(t, 7 * C - 1)];
+    const float r_bd = bdw[tc], r_lw = lnw[tc], r_g = gamma[tc];
+    if (t < H2 * C) { s2[t] = r_2; s1[t] = r_1; }
+    if (t < 7 * C) sdw[t] = r_dw;
+    if (t < C) { sbd[t] = r_bd; slw[t] = r_lw; sg[t] = r_g; }
+  }
   const int p = threadIdx.x, lane = p & 63, wave = p >> 6, r = lane & 15, g = lane >> 4;
   float alw[C], alb[C], ab[C], aw[7][C], ag[C], adb2[C];
 #pragma unroll
