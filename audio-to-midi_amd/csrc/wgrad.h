@@ -61,6 +61,20 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
   float bsum[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
+  // row scales (layer scale folded into the pw2 gradients) of this lane's 8 output rows and of the bias row it reduces:
+  // requested here, used in the epilogue (read there, each was a dependent L2 round trip in front of its atomic)
+  float rsc[2][4], rsb = 1.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rsc[i][e] = 1.f;
+  if (a.row_scale) {   // uniform
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rsc[i][e] = a.row_scale[min(m0 + wm * 32 + i * 16 + 4 * g + e, Mst - 1)];
+    rsb = a.row_scale[min(m0 + (tid & 63), Mst - 1)];
+  }
 
   const int lrow = tid >> 3, lc = tid & 7;   // thread covers rows lrow + 32 i, chunk lc
   // DEPTH register sets: the loads of stages st + 1 .. st + DEPTH - 1 are in flight while stage st is multiplied.  With
@@ -156,7 +170,7 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
         int m = m0 + wm * 32 + i * 16 + 4 * g + e;
         if (m < Mst && k < a.Kp) {
           float v = acc[i][j][e];
-          if (a.row_scale) v *= a.row_scale[m];
+          v *= rsc[i][e];
           if (a.part) a.part[(size_t)by * a.part_stride + (size_t)m * a.Kp + k] = v;
           else atomicAdd(&a.dW[(size_t)m * a.ldw + k], v);
         }
@@ -179,7 +193,7 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
       for (int q = 0; q < 32; ++q) s += red[q][tid];
       int m = m0 + tid;
       if (m < Mst) {
-        if (a.row_scale) s *= a.row_scale[m];
+        s *= rsb;
         if (a.part) a.part[(size_t)by * a.part_stride + (size_t)Mst * a.Kp + m] = s;
         else atomicAdd(&a.dbias[m], s);
       }
