@@ -131,7 +131,9 @@ AMT_DEV uint32_t gdrop_idx(int b, int H, int h, int S, int q, int key) {
 // group (= one wave per SIMD at 8 clips: 256 workgroups) the loop was bound by its own dependency chain
 // (MFMA -> softmax -> LDS round trip -> MFMA, three barriers per tile): 2.1 us per 64-key tile for ~1600
 // cycles of VALU issue.
-template <typename T, int NG>
+// DROP: attention dropout compiled in or out (a run-time test per score quad splits the softmax into 16 basic blocks per
+// key tile, which the scheduler cannot move work across)
+template <typename T, int NG, bool DROP>
 __global__ __launch_bounds__(256 * NG) void attn_global_fwd_kernel(AttnArgs a) {
   a.seed = eff_seed(a.seed, a.seed_dev);   // kernel argument + the context's device seed word (common.h)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256 * NG) void attn_global_fwd_kernel(AttnArgs a) {
         for (int e = 0; e < 4; ++e) {
           float p = __expf(sacc[st][e] - m_new);
           psum += p;
-          if (a.drop_thresh24) {
+          if (DROP) {
             int key = kt * 64 + 16 * st + 4 * g + e;
             bool keep = rng_keep(a.seed, a.stream, gdrop_idx(b, a.H, h, S, qrow, key), a.drop_thresh24);
             p = keep ? p * a.inv_keep : 0.f;
@@ -524,7 +526,7 @@ template <typename T> struct GBwdLds {
   static constexpr size_t GROUP_BYTES = (size_t)(64 * 2 + 128) * ALD * sizeof(T) + 128 * sizeof(float);
 };
 
-template <typename T, int NG>
+template <typename T, int NG, bool DROP>
 AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, int b, int h, unsigned char* smem_all) {
   const AttnArgs& a = ba.f;
   const int tid_all = threadIdx.x, half = NG > 1 ? (tid_all >> 8) : 0, tid = tid_all & 255;
@@ -599,7 +601,7 @@ AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, int b, int
           int key = kt * 64 + 16 * st + 4 * g + e;
           float p = (key < S) ? __expf(sacc[e] - lse) : 0.f;
           float dp = dpacc[e];
-          if (a.drop_thresh24) {
+          if (DROP) {
             bool keep = rng_keep(a.seed, a.stream, gdrop_idx(b, a.H, h, S, qrow, key), a.drop_thresh24);
             dp = keep ? dp * a.inv_keep : 0.f;
           }
@@ -649,7 +651,7 @@ AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, int b, int
   }
 }
 
-template <typename T, int NG>
+template <typename T, int NG, bool DROP>
 AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, int h, unsigned char* smem_all) {
   const AttnArgs& a = ba.f;
   const int tid_all = threadIdx.x, half = NG > 1 ? (tid_all >> 8) : 0, tid = tid_all & 255;
@@ -751,7 +753,7 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
           bool valid = (q < S) && (key < S);
           float p = valid ? __expf(sacc[e] - lse4[e]) : 0.f;
           float dp = dpacc[e], pdrop = p;
-          if (a.drop_thresh24) {
+          if (DROP) {
             bool keep = rng_keep(a.seed, a.stream, gdrop_idx(b, a.H, h, S, q, key), a.drop_thresh24);
             dp = keep ? dp * a.inv_keep : 0.f;
             pdrop = keep ? p * a.inv_keep : 0.f;
@@ -809,7 +811,7 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
 }
 
 // blocks [0, ntile) of a (clip, head) compute dQ, blocks [ntile, 2 ntile) dK/dV
-template <typename T, int NG>
+template <typename T, int NG, bool DROP>
 __global__ __launch_bounds__(256 * NG, 2 * NG) void attn_global_bwd_kernel(AttnBwdArgs ba, int ntile) {
   ba.f.seed = eff_seed(ba.f.seed, ba.f.seed_dev);   // kernel argument + the context's device seed word (common.h)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -819,8 +821,8 @@ __global__ __launch_bounds__(256 * NG, 2 * NG) void attn_global_bwd_kernel(AttnB
   const int bh = (jj / per) * 8 + xcd, role = jj % per;
   if (bh >= ba.f.B * ba.f.H) return;
   const int h = bh % ba.f.H, b = bh / ba.f.H;
-  if (role < ntile) attn_global_bwd_dq_body<T, NG>(ba, role, b, h, smem_raw);
-  else attn_global_bwd_dkv_body<T, NG>(ba, role - ntile, b, h, smem_raw);
+  if (role < ntile) attn_global_bwd_dq_body<T, NG, DROP>(ba, role, b, h, smem_raw);
+  else attn_global_bwd_dkv_body<T, NG, DROP>(ba, role - ntile, b, h, smem_raw);
 }
 
 template <typename K> static void set_max_lds(K kernel, size_t bytes) {
@@ -834,14 +836,17 @@ void attn_global_fwd(hipStream_t s, DType dt, const AttnArgs& a) {
                4.0 * a.B * a.S * a.H * 64 * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) {
     size_t lds = (size_t)2 * (64 * 2 + 64) * ALD * sizeof(float);
-    static bool once = (set_max_lds(attn_global_fwd_kernel<float, 2>, 128 * 1024), true);
+    static bool once = (set_max_lds(attn_global_fwd_kernel<float, 2, true>, 128 * 1024),
+                        set_max_lds(attn_global_fwd_kernel<float, 2, false>, 128 * 1024), true);
     (void)once;
-    hipLaunchKernelGGL((attn_global_fwd_kernel<float, 2>), grid, dim3(512), lds, s, a);
+    if (a.drop_thresh24) hipLaunchKernelGGL((attn_global_fwd_kernel<float, 2, true>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((attn_global_fwd_kernel<float, 2, false>), grid, dim3(512), lds, s, a);
   } else {
     // (four groups of two tiles each measured the same 13.9 us as two groups of four: what is left is the
     // first-tile latency, the merge and the launch itself)
     size_t lds = (size_t)2 * (64 * 2 + 64) * ALD * sizeof(bf16);
-    hipLaunchKernelGGL((attn_global_fwd_kernel<bf16, 2>), grid, dim3(512), lds, s, a);
+    if (a.drop_thresh24) hipLaunchKernelGGL((attn_global_fwd_kernel<bf16, 2, true>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((attn_global_fwd_kernel<bf16, 2, false>), grid, dim3(512), lds, s, a);
   }
 }
 
@@ -851,13 +856,16 @@ void attn_global_bwd(hipStream_t s, DType dt, const AttnBwdArgs& a) {
   ProfScope ps(s, "attn_global_bwd", 8.0 * a.f.B * a.f.H * (double)a.f.S * a.f.S * 64,
                8.0 * a.f.B * a.f.S * a.f.H * 64 * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) {
-    static bool once = (set_max_lds(attn_global_bwd_kernel<float, 1>, 96 * 1024), true);
+    static bool once = (set_max_lds(attn_global_bwd_kernel<float, 1, true>, 96 * 1024),
+                        set_max_lds(attn_global_bwd_kernel<float, 1, false>, 96 * 1024), true);
     (void)once;
-    hipLaunchKernelGGL((attn_global_bwd_kernel<float, 1>), grid, dim3(256), GBwdLds<float>::GROUP_BYTES, s, a, ntile);
+    if (a.f.drop_thresh24) hipLaunchKernelGGL((attn_global_bwd_kernel<float, 1, true>), grid, dim3(256), GBwdLds<float>::GROUP_BYTES, s, a, ntile);
+    else hipLaunchKernelGGL((attn_global_bwd_kernel<float, 1, false>), grid, dim3(256), GBwdLds<float>::GROUP_BYTES, s, a, ntile);
   } else {
     // NG = 2 (the forward's split) measured 47.5 us against 38.2 us for NG = 1 stand-alone: 128 VGPRs with 37
     // spilled, and this kernel is bound by VALU / LDS issue (~720 VALU + 95 LDS instructions per tile), not latency
-    hipLaunchKernelGGL((attn_global_bwd_kernel<bf16, 1>), grid, dim3(256), GBwdLds<bf16>::GROUP_BYTES, s, a, ntile);
+    if (a.f.drop_thresh24) hipLaunchKernelGGL((attn_global_bwd_kernel<bf16, 1, true>), grid, dim3(256), GBwdLds<bf16>::GROUP_BYTES, s, a, ntile);
+    else hipLaunchKernelGGL((attn_global_bwd_kernel<bf16, 1, false>), grid, dim3(256), GBwdLds<bf16>::GROUP_BYTES, s, a, ntile);
   }
 }
 
