@@ -1,6 +1,7 @@
 // Weight-gradient GEMM body shared by gemm.hip (stand-alone launches) and chain.hip (weight-gradient
 // workgroups that ride on a chain kernel's launch).
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -160,22 +161,37 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
 
   AMT_WG_STAMP(2);
   // acc[i][j][e] = dW[m0 + wm*32 + i*16 + 4g + e][k0 + wk*32 + j*16 + r]
+  {
+    // destination and the two uniform questions (record or atomic, whole tile or ragged) are settled once: asked per
+    // element they were three scalar-load waits and three branches in front of each of the 16 stores / atomics
+    const bool rec = a.part != nullptr;
+    float* const dst = rec ? a.part + (size_t)by * a.part_stride : a.dW;
+    const size_t ldd = rec ? (size_t)a.Kp : (size_t)a.ldw;
+    const bool full = (m0 + 64 <= Mst) && (k0 + 64 <= a.Kp);
+    const int Kp = a.Kp;
+    auto emit = [&](auto FULL, auto REC) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int k = k0 + wk * 32 + j * 16 + r;
+        for (int j = 0; j < 2; ++j) {
+          const int k = k0 + wk * 32 + j * 16 + r;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int m = m0 + wm * 32 + i * 16 + 4 * g + e;
-        if (m < Mst && k < a.Kp) {
-          float v = acc[i][j][e];
-          v *= rsc[i][e];
-          if (a.part) a.part[(size_t)by * a.part_stride + (size_t)m * a.Kp + k] = v;
-          else atomicAdd(&a.dW[(size_t)m * a.ldw + k], v);
+          for (int e = 0; e < 4; ++e) {
+            const int m = m0 + wm * 32 + i * 16 + 4 * g + e;
+            if (decltype(FULL)::value || (m < Mst && k < Kp)) {
+              const float v = acc[i][j][e] * rsc[i][e];
+              float* q = dst + (size_t)m * ldd + k;
+              if (decltype(REC)::value) *q = v;
+              else atomicAdd(q, v);
+            }
+          }
         }
-      }
-    }
+    };
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+    if (full) { if (rec) emit(Yes{}, Yes{}); else emit(Yes{}, No{}); }
+    else { if (rec) emit(No{}, Yes{}); else emit(No{}, No{}); }
+  }
 
   AMT_WG_STAMP(3);
 #ifdef AMT_CHAIN_TIMING
