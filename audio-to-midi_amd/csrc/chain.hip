@@ -864,8 +864,24 @@ AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem) {
   chain_copy_in<T, TT, H, LDX>(As, reinterpret_cast<const T*>(a.AO), n0, N, tid);
   ChainCopyRegs<T, TT, H> xreg;     // x is read by the residual epilogue only: it lands while the products run
   chain_copy_load<T, TT, H>(xreg, reinterpret_cast<const T*>(a.X), H, n0, N, tid);
+  // The two FFN biases are requested here and parked in LDS.  Read from global memory where the epilogues use them (two
+  // 16-byte loads per row-block pair, waited for on the spot), each was an L2 round trip between a stage's products and
+  // its stores: ~8 per tile in the ISA.
+  __shared__ __attribute__((aligned(16))) float s_b1[FULL ? 1024 : 4], s_b2[FULL ? 256 : 4];
+  float pb1[4], pb2 = 0.f;
+  if constexpr (FULL) {
+    static_assert(I2 == 1024 && H == 256, "one bias element per thread and 256-stride");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pb1[j] = a.b1[tid + 256 * j];
+    pb2 = a.b2[tid];
+  }
   __syncthreads();
   AMT_STAMP(1);
+  if constexpr (FULL) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s_b1[tid + 256 * j] = pb1[j];
+    s_b2[tid] = pb2;
+  }
 
   // ---- h = x + ao . Wo^T
   Frag<T> w1a[KC1][S1::RB];
@@ -919,7 +935,7 @@ AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem) {
       const int m = mh + 16 * rb + 4 * g;          // permuted row of u1; u2 sits 16 rows further
       float b1a[4], b1b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { b1a[i] = a.b1[m + i]; b1b[i] = a.b1[m + 16 + i]; }
+      for (int i = 0; i < 4; ++i) { b1a[i] = s_b1[m + i]; b1b[i] = s_b1[m + 16 + i]; }
       const int j = (m >> 5) * 16 + (m & 15);      // g column
 #pragma unroll
       for (int ti = 0; ti < S1::NT; ++ti) {
@@ -957,7 +973,7 @@ AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem) {
       const int m = mO + 16 * rb + 4 * g;
       float bb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) bb[i] = a.b2[m + i];
+      for (int i = 0; i < 4; ++i) bb[i] = s_b2[m + i];
 #pragma unroll
       for (int ti = 0; ti < SO::NT; ++ti) {
         const int p = tO + 16 * ti + r;
