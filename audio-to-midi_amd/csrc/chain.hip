@@ -780,10 +780,12 @@ void block_bwd_fused(hipStream_t s, DType dt, const BlockBwdArgs& a_in, float* d
   // Rider workgroups per Block-chain launch.  Measured (ms/step at cfg2): 48: 4.70, 96: 4.35, 144: 4.21, 224: 4.18,
   // 336: 4.23, 448: 4.25, 640: 4.43; sizing them to the compute units the chain leaves free (256 - nb) gave 4.52: a
   // rider workgroup is bound by its own load -> LDS -> MFMA stage latency, so fewer, longer riders end later.
-  static const int rider_target = getenv("AMT_RIDER_TARGET") ? atoi(getenv("AMT_RIDER_TARGET")) : 224;
+  // (re-swept after the riders' loads and epilogue were fixed, round 2: 176: 3.284, 192: 3.284, 200: 3.300, 224: 3.306 -
+  // with 192 the chain and rider workgroups of a C = 128 launch fit the 512 resident slots, with 208 eight riders start late)
+  static const int rider_target = getenv("AMT_RIDER_TARGET") ? atoi(getenv("AMT_RIDER_TARGET")) : 192;
   // C = 256 (256 registers per lane: ONE workgroup per compute unit, 160 chain workgroups at cfg2): riders beyond the
   // free compute units wait for a chain workgroup to finish and the launch ends late (54 us per launch with 224)
-  static const int rider_target_256 = getenv("AMT_RIDER_TARGET_256") ? atoi(getenv("AMT_RIDER_TARGET_256")) : 224;
+  static const int rider_target_256 = getenv("AMT_RIDER_TARGET_256") ? atoi(getenv("AMT_RIDER_TARGET_256")) : 288;
   const int n_rider_wgs = wgrad_group_prepare(dt, riders, n_riders, sink, &rg, &rfl, &rby, C == 256 ? rider_target_256 : rider_target);
   if (sink->dry) return;
   a.rec = sink->ws + o;
