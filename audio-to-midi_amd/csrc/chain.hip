@@ -543,6 +543,23 @@ __global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a, Wg
   Frag<T> wa[KCA][SA::RB], wb[KCB][SB::RB];
   chain_load_w<T, SA::RB, KCA, C>(wa, WA, mA, 0, lane);
   chain_load_w<T, SB::RB, KCB, H2>(wb, WB, mB, 0, lane);   // registers are idle until the row phases
+  // The row phases' parameters (7 depthwise taps, conv bias, LN weight: 9 C floats) are requested here and parked in LDS;
+  // requested where the row phases start, their L2 round trip stood between stage B and the first row (ISA: 18 loads
+  // and a descending chain of waits in front of row phase 1).  Unconditional loads from clamped indices (cnn.hip).
+  __shared__ __attribute__((aligned(16))) float s_par[9 * C];
+  {
+    constexpr int NPAR = (9 * C + 255) / 256;
+    float pv[NPAR];
+#pragma unroll
+    for (int j = 0; j < NPAR; ++j) {
+      const int t = min(tid + 256 * j, 9 * C - 1);
+      const float* src = t < 7 * C ? a.wdw + t : (t < 8 * C ? a.bdw + (t - 7 * C) : a.lnw + (t - 8 * C));
+      pv[j] = *src;
+    }
+#pragma unroll
+    for (int j = 0; j < NPAR; ++j)
+      if (tid + 256 * j < 9 * C) s_par[tid + 256 * j] = pv[j];
+  }
 
   // ---- staging: dy and u rows l0 - 3 .. l0 + TL + 2, x rows l0 - 6 .. l0 + TL + 5; rows outside the
   // clip are loaded from a clamped row and zeroed (unconditional loads, see cnn.hip).  Every load is issued here, but
@@ -650,12 +667,22 @@ __global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a, Wg
 #pragma unroll
     for (int q = 0; q < 11; ++q) cs[q][i] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) wk[k][i] = a.wdw[k * C + sub * 8 + i];
+    for (int k = 0; k < 7; ++k) wk[k][i] = s_par[k * C + sub * 8 + i];
+  }
+  // z rows of row phase 2 (layer-scale gradient): on their way during row phase 1
+  constexpr int NP2 = (TL + RPP - 1) / RPP;
+  Chunk8<T> zc[NP2];
+  if (a.Z != nullptr) {
+#pragma unroll
+    for (int pp = 0; pp < NP2; ++pp) {
+      const int l = l0 + pp * RPP + prow;
+      zc[pp] = chunk_load(reinterpret_cast<const T*>(a.Z) + (rb + (l < L ? l : L - 1)) * C + sub * 8);
+    }
   }
   {
     float bv[8], wv[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { bv[i] = a.bdw[sub * 8 + i]; wv[i] = a.lnw[sub * 8 + i]; }
+    for (int i = 0; i < 8; ++i) { bv[i] = s_par[7 * C + sub * 8 + i]; wv[i] = s_par[8 * C + sub * 8 + i]; }
 #pragma unroll
     for (int pp = 0; pp < TT / RPP; ++pp) {
       const int p = pp * RPP + prow;
@@ -710,10 +737,8 @@ __global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a, Wg
     load8f(DYs + (i0c + 3) * LDX + sub * 8, o);
     load8f(DLs + (i0c + 3) * LDX + sub * 8, dd);
     if (a.Z != nullptr) {
-      float z[8];
-      load8f(reinterpret_cast<const T*>(a.Z) + (rb + lcl) * C + sub * 8, z);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) ag[i] += fv * o[i] * z[i];
+      for (int i = 0; i < 8; ++i) ag[i] += fv * o[i] * chunk_get(zc[pp], i);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) { dd[i] *= fv; ab[i] += dd[i]; }
