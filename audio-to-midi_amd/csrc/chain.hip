@@ -1586,7 +1586,8 @@ void qkv_bwd_fused(hipStream_t s, DType dt, const QkvBwdArgs& a_in, float* dlnw,
   a.n_chain = chain_ln_records(dt, a.N, dlnw, dlnb, sink, &a.rec);
   WgradGroup rg;
   double rfl = 0, rby = 0;
-  const int n_rider_wgs = wgrad_group_prepare(dt, riders, n_riders, sink, &rg, &rfl, &rby);
+  static const int tgt_qkv = getenv("AMT_RIDER_TARGET_QKV") ? atoi(getenv("AMT_RIDER_TARGET_QKV")) : 0;   // 0: the weight-gradient default
+  const int n_rider_wgs = wgrad_group_prepare(dt, riders, n_riders, sink, &rg, &rfl, &rby, tgt_qkv);
   if (sink->dry) return;
   a.rec_stride = 512;
   const double N = a.N, es = dt == DT_F32 ? 4 : 2;
@@ -1618,7 +1619,8 @@ void ffn_bwd_fused(hipStream_t s, DType dt, const FfnBwdArgs& a_in, float* dlnw,
   a.n_chain = chain_ln_records(dt, a.N, dlnw, dlnb, sink, &a.rec, kFfnBwdTile);
   WgradGroup rg;
   double rfl = 0, rby = 0;
-  const int n_rider_wgs = wgrad_group_prepare(dt, riders, n_riders, sink, &rg, &rfl, &rby);
+  static const int tgt_ffn = getenv("AMT_RIDER_TARGET_FFN") ? atoi(getenv("AMT_RIDER_TARGET_FFN")) : 264;   // 250 chain + ~264 rider workgroups fill the 512 resident slots (0 / 176 / 220 / 264 / 308: 3.255 / 3.252 / 3.236 / 3.235 / 3.260 ms)
+  const int n_rider_wgs = wgrad_group_prepare(dt, riders, n_riders, sink, &rg, &rfl, &rby, tgt_ffn);
   if (sink->dry) return;
   a.rec_stride = 512;
   const double N = a.N, es = dt == DT_F32 ? 4 : 2;
