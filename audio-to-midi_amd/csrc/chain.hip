@@ -1535,9 +1535,8 @@ template <typename K> static void chain_set_lds(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <typename T>
+template <typename T, int TT>
 static void qkv_bwd_fused_launch(hipStream_t s, const QkvBwdArgs& a, const WgradGroup& rg, int n_rider_wgs) {
-  constexpr int TT = FfnTile<T>::TT;
   constexpr size_t lds_chain = sizeof(T) * (size_t)TT * ((512 + 8) + (320 + 8) + (256 + 8));
   constexpr size_t lds = lds_chain > TnLds<T>::BYTES ? lds_chain : TnLds<T>::BYTES;
   static_assert(lds <= 160 * 1024 && sizeof(T) * TT * (512 + 8) >= sizeof(float) * 8 * 256, "LDS budget");
@@ -1583,7 +1582,9 @@ static int chain_ln_records(DType dt, int N, float* dlnw, float* dlnb, PartialSi
 void qkv_bwd_fused(hipStream_t s, DType dt, const QkvBwdArgs& a_in, float* dlnw, float* dlnb, PartialSink* sink,
                    const WgradArgs* riders, int n_riders) {
   QkvBwdArgs a = a_in;
-  a.n_chain = chain_ln_records(dt, a.N, dlnw, dlnb, sink, &a.rec);
+  static const int tt_env = getenv("AMT_QKV_BWD_TT") ? atoi(getenv("AMT_QKV_BWD_TT")) : 32;
+  const int tt = (dt == DT_F32 || (tt_env == 16 && a.N < 8192)) ? 16 : 32;
+  a.n_chain = chain_ln_records(dt, a.N, dlnw, dlnb, sink, &a.rec, tt);
   WgradGroup rg;
   double rfl = 0, rby = 0;
   static const int tgt_qkv = getenv("AMT_RIDER_TARGET_QKV") ? atoi(getenv("AMT_RIDER_TARGET_QKV")) : 0;   // 0: the weight-gradient default
@@ -1593,8 +1594,9 @@ void qkv_bwd_fused(hipStream_t s, DType dt, const QkvBwdArgs& a_in, float* dlnw,
   const double N = a.N, es = dt == DT_F32 ? 4 : 2;
   ProfScope ps(s, n_rider_wgs > 0 ? "qkv_bwd_fused+wgrad" : "qkv_bwd_fused", 2.0 * N * (64.0 * 512 + 256.0 * 320) + rfl,
                (N * (512 + 320 + 64 + 256 * 4.0) + 64.0 * 512 + 256.0 * 320) * es + rby);
-  if (dt == DT_F32) qkv_bwd_fused_launch<float>(s, a, rg, n_rider_wgs);
-  else qkv_bwd_fused_launch<bf16>(s, a, rg, n_rider_wgs);
+  if (dt == DT_F32) qkv_bwd_fused_launch<float, 16>(s, a, rg, n_rider_wgs);
+  else if (tt == 16) qkv_bwd_fused_launch<bf16, 16>(s, a, rg, n_rider_wgs);
+  else qkv_bwd_fused_launch<bf16, 32>(s, a, rg, n_rider_wgs);
 }
 
 void lnout_bwd_fused(hipStream_t s, DType dt, const LnOutBwdArgs& a_in, float* dlnw, float* dlnb, PartialSink* sink,
