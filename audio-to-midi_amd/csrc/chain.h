@@ -278,6 +278,37 @@ AMT_DEV void chain_l2_warm(const void* base, size_t bytes, int q, int nslices, i
   }
 }
 
+// The same warm-up, issued back to back: UNCONDITIONAL loads (addresses clamped into the range: a repeated line costs
+// nothing) into registers, consumed by `fold` behind the first barrier of the tile.  chain_l2_warm's guarded loads are folded
+// into the sink one by one and the compiler puts an `s_waitcnt vmcnt(0)` behind each: 6-12 round trips in series in front of
+// the tile's first operand.  Measured (profiles/r02_notes.md): converting EVERY chain made the step slower (the serial form
+// throttles the burst at the start of a launch); this form is used where the serial chain is longest (FFN forward: 12 rounds).
+template <int MAXLD> struct L2Warm {
+  uint4 v[MAXLD];
+  AMT_DEV void issue(const void* base, size_t bytes, int q, int nslices, int tid) {
+#pragma unroll
+    for (int i = 0; i < MAXLD; ++i) v[i] = uint4{0u, 0u, 0u, 0u};
+    if (q >= nslices || bytes < 16) return;                                          // uniform over the workgroup
+    const size_t per = ((bytes + nslices - 1) / nslices + 4095) & ~(size_t)4095;   // whole 4 KiB rounds
+    const size_t last = (bytes - 16) & ~(size_t)15;
+    const char* p = static_cast<const char*>(base);
+    const size_t beg = (size_t)q * per + (size_t)tid * 16;
+#pragma unroll
+    for (int i = 0; i < MAXLD; ++i) {
+      size_t off = beg + (size_t)i * 4096;
+      if ((size_t)i * 4096 >= per) off = beg;          // rounds past the slice repeat its first one
+      off = off < last ? off : last;
+      v[i] = *reinterpret_cast<const uint4*>(p + off);
+    }
+  }
+  // an empty volatile asm that takes the registers as inputs: the loads stay alive, nothing is computed, and the compiler
+  // cannot move this use (and with it the wait for the loads) in front of the barrier it is placed behind
+  AMT_DEV void fold() const {
+#pragma unroll
+    for (int i = 0; i < MAXLD; ++i) asm volatile("" :: "v"(v[i].x), "v"(v[i].y), "v"(v[i].z), "v"(v[i].w));
+  }
+};
+
 // LayerNorm backward over C = 256 features of TT rows (eqx LayerNorm, fp32 statistics):
 //   dX = dRes + LN'(dY),  aw += dY * xhat,  ab += dY   (column accumulators of this lane, cs[0] / cs[1])
 // dY rows come from an LDS panel (as stored, T), x / dRes rows from global memory; dX goes to an LDS

@@ -881,10 +881,12 @@ AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem) {
   AMT_STAMP_RT(6);
   AMT_STAMP(0);
   uint32_t warm = 0;
+  L2Warm<FULL ? 6 : 1> lw1;
+  L2Warm<FULL ? 3 : 1> lw2;
   if constexpr (FULL) {
     const int q = blockIdx.x >> 3, ns = max(1, (int)(gridDim.x >> 3));
-    chain_l2_warm<8>(W1, sizeof(T) * (size_t)I2 * H, q, ns, tid, warm);
-    chain_l2_warm<4>(W2, sizeof(T) * (size_t)H * I, q, ns, tid, warm);
+    lw1.issue(W1, sizeof(T) * (size_t)I2 * H, q, ns, tid);
+    lw2.issue(W2, sizeof(T) * (size_t)H * I, q, ns, tid);
   }
   Frag<T> wo[KCO][SO::RB];
   chain_load_w<T, SO::RB, KCO, H>(wo, Wo, mO, 0, lane);
@@ -904,6 +906,7 @@ AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem) {
   }
   __syncthreads();
   AMT_STAMP(1);
+  if constexpr (FULL) { lw1.fold(); lw2.fold(); }
   if constexpr (FULL) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) s_b1[tid + 256 * j] = pb1[j];
