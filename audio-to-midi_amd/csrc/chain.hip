@@ -1431,10 +1431,12 @@ __global__ __launch_bounds__(256) void ffn_bwd_fused_kernel(FfnBwdArgs a, WgradG
   // cooperative L2 warm-up of the two big weight matrices, as in ffn_fwd_fused: every workgroup of an XCD streams the
   // same 896 KiB and a cold stream advances at one compute unit's miss rate
   uint32_t warm = 0;
+  L2Warm<3> lw2;   // back-to-back form (chain.h)
+  L2Warm<6> lw1;
   {
     const int q = blockIdx.x >> 3, ns = max(1, a.n_chain >> 3);
-    chain_l2_warm<4>(W2t, sizeof(T) * (size_t)I * H, q, ns, tid, warm);
-    chain_l2_warm<8>(W1t, sizeof(T) * (size_t)H * I2, q, ns, tid, warm);
+    lw2.issue(W2t, sizeof(T) * (size_t)I * H, q, ns, tid);
+    lw1.issue(W1t, sizeof(T) * (size_t)H * I2, q, ns, tid);
   }
   Frag<T> wa[KCA][SO::RB], wb[KCB][SO::RB];
   chain_load_w<T, SO::RB, KCA, H>(wa, W2t, mO, 0, lane);
@@ -1442,6 +1444,7 @@ __global__ __launch_bounds__(256) void ffn_bwd_fused_kernel(FfnBwdArgs a, WgradG
   ChainCopyRegs<T, TT, I2> ureg;   // u is read by the GLU' epilogue only: it lands while the first products run
   chain_copy_load<T, TT, I2>(ureg, reinterpret_cast<const T*>(a.U), I2, n0, N, tid);
   __syncthreads();
+  lw2.fold(); lw1.fold();
 
   // ---- dg = dyd . W2 (two halves of 256 columns) ; du = GLU'(dg, u), in place over u
   auto glu_bwd_half = [&](int half, Frag<T> (&wpre)[KCA][SO::RB]) {
