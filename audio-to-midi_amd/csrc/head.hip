@@ -385,6 +385,7 @@ __global__ void adamw_apply_kernel(float* __restrict__ p, const float* __restric
   __shared__ float s_nrm2;
   if (threadIdx.x == 0) {
     s_nrm2 = __hip_atomic_load(norm2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the value has ARRIVED before this workgroup counts itself as a reader
     unsigned* cnt = reinterpret_cast<unsigned*>(norm2 + 1);
     if (atomicAdd(cnt, 1u) == gridDim.x - 1) {
       __hip_atomic_store(norm2, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
