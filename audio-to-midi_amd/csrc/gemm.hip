@@ -370,7 +370,7 @@ int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* si
     by += ((double)a.N * a.M + (double)a.N * a.Kp) * es + (double)a.M * a.Kp * 4;
     if (skinny[i]) {
       const int Mst = a.M_store > 0 ? a.M_store : a.M;
-      static const int skinny_rps = getenv("AMT_SKINNY_RPS") ? atoi(getenv("AMT_SKINNY_RPS")) : 256;
+      static const int skinny_rps = getenv("AMT_SKINNY_RPS") ? atoi(getenv("AMT_SKINNY_RPS")) : 512;   // 256 / 512 / 768 / 1024: 3.202 / 3.194 / 3.211 / 3.227 ms/step (round 2, after the rider fixes; 256 won before them)
       int rps = skinny_rps;
       int splits = (a.N + rps - 1) / rps;
       if (splits > 1024) { splits = 1024; rps = ((a.N + splits - 1) / splits + 127) / 128 * 128; splits = (a.N + rps - 1) / rps; }
