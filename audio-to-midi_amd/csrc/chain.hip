@@ -852,8 +852,11 @@ template <typename T> struct FfnTileFwd { static constexpr int TT = 16; };
 // the cold first touch) and measured 27 us against ~31 us for the four separate launches; with only
 // the 128 KiB output projection in the chain the kernel takes ~6 us and W1 / W2 stay tiled GEMMs,
 // whose 64 x 64 tiles move 3.5x fewer weight bytes per CU (profiles/r01_notes.md).
+// wx0 / wx1: two more weight ranges to warm with this body's own (the q/kv weights of the body that follows it in the
+// layer-boundary launch: warmed there, in the middle of the launch, they were six round trips in series)
 template <typename T, int TT, bool FULL>
-AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem) {
+AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem, const void* wx0 = nullptr, size_t bx0 = 0,
+                          const void* wx1 = nullptr, size_t bx1 = 0) {
   a.seed = eff_seed(a.seed, a.seed_dev);   // kernel argument + the context's device seed word (common.h)
   constexpr int H = 256, I = 512, I2 = 1024, LDX = H + 8, LDG = I + 8;
   using SO = ChainSplit<H, TT>;        // Wo and W2 stages: 256 output features
@@ -883,10 +886,14 @@ AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem) {
   uint32_t warm = 0;
   L2Warm<FULL ? 6 : 1> lw1;
   L2Warm<FULL ? 3 : 1> lw2;
+  L2Warm<FULL ? 2 : 1> lx0;
+  L2Warm<1> lx1;
   if constexpr (FULL) {
     const int q = blockIdx.x >> 3, ns = max(1, (int)(gridDim.x >> 3));
     lw1.issue(W1, sizeof(T) * (size_t)I2 * H, q, ns, tid);
     lw2.issue(W2, sizeof(T) * (size_t)H * I, q, ns, tid);
+    lx0.issue(wx0, bx0, q, ns, tid);
+    lx1.issue(wx1, bx1, q, ns, tid);
   }
   Frag<T> wo[KCO][SO::RB];
   chain_load_w<T, SO::RB, KCO, H>(wo, Wo, mO, 0, lane);
@@ -906,7 +913,7 @@ AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem) {
   }
   __syncthreads();
   AMT_STAMP(1);
-  if constexpr (FULL) { lw1.fold(); lw2.fold(); }
+  if constexpr (FULL) { lw1.fold(); lw2.fold(); lx0.fold(); lx1.fold(); }
   if constexpr (FULL) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) s_b1[tid + 256 * j] = pb1[j];
@@ -1094,8 +1101,8 @@ AMT_DEV void qkv_fwd_body(const QkvFwdArgs& a, unsigned char* chain_smem, const 
 
   AMT_STAMP_RT(6);
   AMT_STAMP(0);
-  uint32_t warm = 0;   // cooperative L2 warm-up (chain.h)
-  {
+  uint32_t warm = 0;   // cooperative L2 warm-up (chain.h); behind the FFN body of a boundary launch that body has done it
+  if (XLDS == nullptr) {
     const int q = blockIdx.x >> 3, ns = max(1, (int)(gridDim.x >> 3));
     chain_l2_warm<4>(Wq, sizeof(T) * (size_t)QC * H, q, ns, tid, warm);
     chain_l2_warm<2>(Wk, sizeof(T) * (size_t)KV * CK, q, ns, tid, warm);
@@ -1175,7 +1182,7 @@ template <typename T, int TT>
 __global__ __launch_bounds__(256) void ffn_qkv_fwd_fused_kernel(FfnFwdArgs fa, QkvFwdArgs qa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
   constexpr int LDX = 256 + 8;
-  ffn_fwd_body<T, TT, true>(fa, chain_smem);
+  ffn_fwd_body<T, TT, true>(fa, chain_smem, qa.Wqc, sizeof(T) * (size_t)320 * 256, qa.Wkv, sizeof(T) * (size_t)512 * 64);
   __syncthreads();                                   // the copy-out of y has read its panel; every panel is free
   // y sits in the SECOND [TT][LDX] panel of the FFN body; the q/kv body keeps x in the first: copy, then go on
   const T* ys = reinterpret_cast<const T*>(chain_smem) + TT * LDX;
