@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import argparse
 import os
+import re
 import sys
 from collections import OrderedDict
 from typing import Any, Dict
@@ -49,11 +50,43 @@ def flatten_tree(tree: Any, prefix: str = "") -> "OrderedDict[str, np.ndarray]":
     return out
 
 
+_SEQ_LEVEL = re.compile(r"^layers\.(\d+)\.layers\.(\d+)\.")
+
+
+def canonical_name(name: str) -> str:
+    """Reference pytree path -> the leaf name used by ``params.equinox_shapes``.
+
+    ``OutputSequenceGenerator.layers`` is a list of ``eqx.nn.Sequential`` (model.py:674, 704-710) and a Sequential
+    keeps its modules in an inner ``.layers`` tuple, so the real path of a CNN leaf is
+    ``layers.<s>.layers.<j>.point_conv_1.weight`` (train.py:650-653 reads ``path[1].idx`` and ``path[3].idx`` for
+    exactly that reason); this package names it ``layers.<s>.<j>.point_conv_1.weight``."""
+    return _SEQ_LEVEL.sub(r"layers.\1.\2.", name)
+
+
+def reference_name(name: str) -> str:
+    """Inverse of ``canonical_name``: put the Sequential's ``.layers`` level back."""
+    m = re.match(r"^layers\.(\d+)\.(\d+)\.", name)
+    return name if m is None else f"layers.{m.group(1)}.layers.{m.group(2)}." + name[m.end():]
+
+
 def leaves_to_flat(leaves: Dict[str, np.ndarray], conf: dict, ensemble_select=0) -> np.ndarray:
-    """Reference leaves (with or without the ensemble axis) -> flat fp32 vector in device layout, fully validated."""
+    """Reference leaves (with or without the ensemble axis, reference or canonical names) -> flat fp32 vector in
+    device layout, fully validated.  A leaf under ``layers.`` / ``transformer.`` / ``decoder.`` / ``norm.`` that the
+    parameter inventory does not know is an error (a silent drop would hide a naming mismatch); leaves outside the
+    model (e.g. the empty ``state``) are ignored."""
     shapes = _params.equinox_shapes(conf)
-    # the reference's pytree also holds leaves this path has no use for (e.g. an empty `state`); keep the known names
-    known = OrderedDict((k, v) for k, v in leaves.items() if k in shapes)
+    known: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    unknown = []
+    for k, v in leaves.items():
+        c = canonical_name(k)
+        if c in shapes:
+            if c in known:
+                raise KeyError(f"leaf {c} given twice ({k})")
+            known[c] = v
+        elif c.split(".")[0] in ("layers", "transformer", "decoder", "norm"):
+            unknown.append(k)
+    if unknown:
+        raise KeyError(f"{len(unknown)} model leaves are not in the parameter inventory, e.g. {unknown[:4]}")
     return _params.equinox_to_flat(known, conf, ensemble_select=ensemble_select)
 
 
@@ -117,8 +150,8 @@ def cmd_from_amt(a):
     params = eqx.filter(model, eqx.is_inexact_array)
     paths, treedef = jax.tree_util.tree_flatten_with_path(params)
 
-    def name(path):
-        return ".".join(str(getattr(k, "name", getattr(k, "idx", getattr(k, "key", k)))) for k in path)
+    def name(path):   # the reference's own path (with the Sequential level) -> this package's leaf name
+        return canonical_name(".".join(str(getattr(k, "name", getattr(k, "idx", getattr(k, "key", k)))) for k in path))
 
     new_leaves = []
     for path, leaf in paths:

@@ -1595,8 +1595,12 @@ static int chain_ln_records(DType dt, int N, float* dlnw, float* dlnb, PartialSi
 void qkv_bwd_fused(hipStream_t s, DType dt, const QkvBwdArgs& a_in, float* dlnw, float* dlnb, PartialSink* sink,
                    const WgradArgs* riders, int n_riders) {
   QkvBwdArgs a = a_in;
-  static const int tt_env = getenv("AMT_QKV_BWD_TT") ? atoi(getenv("AMT_QKV_BWD_TT")) : 32;
-  const int tt = (dt == DT_F32 || (tt_env == 16 && a.N < 8192)) ? 16 : 32;
+  // Tile length: 32 tokens in bf16 (production), 16 in f32; AMT_QKV_BWD_TT = 16 | 32 forces either for BOTH dtypes (read on
+  // every call, so a test can switch it between contexts): the f32 context with 32-token tiles runs the production tile
+  // shape of the bf16 path and pins its indexing at the f32 tolerance (tests/test_parity_full_gpu.py).
+  const char* tt_s = getenv("AMT_QKV_BWD_TT");
+  const int tt_env = tt_s ? atoi(tt_s) : 0;
+  const int tt = tt_env == 32 ? 32 : ((dt == DT_F32 || (tt_env == 16 && a.N < 8192)) ? 16 : 32);
   a.n_chain = chain_ln_records(dt, a.N, dlnw, dlnb, sink, &a.rec, tt);
   WgradGroup rg;
   double rfl = 0, rby = 0;
@@ -1607,7 +1611,8 @@ void qkv_bwd_fused(hipStream_t s, DType dt, const QkvBwdArgs& a_in, float* dlnw,
   const double N = a.N, es = dt == DT_F32 ? 4 : 2;
   ProfScope ps(s, n_rider_wgs > 0 ? "qkv_bwd_fused+wgrad" : "qkv_bwd_fused", 2.0 * N * (64.0 * 512 + 256.0 * 320) + rfl,
                (N * (512 + 320 + 64 + 256 * 4.0) + 64.0 * 512 + 256.0 * 320) * es + rby);
-  if (dt == DT_F32) qkv_bwd_fused_launch<float, 16>(s, a, rg, n_rider_wgs);
+  if (dt == DT_F32 && tt == 16) qkv_bwd_fused_launch<float, 16>(s, a, rg, n_rider_wgs);
+  else if (dt == DT_F32) qkv_bwd_fused_launch<float, 32>(s, a, rg, n_rider_wgs);
   else if (tt == 16) qkv_bwd_fused_launch<bf16, 16>(s, a, rg, n_rider_wgs);
   else qkv_bwd_fused_launch<bf16, 32>(s, a, rg, n_rider_wgs);
 }

@@ -134,6 +134,13 @@ void copy_pad_f32(hipStream_t s, const float* src, float* dst, size_t n, size_t 
   int grid = (int)((n_pad + 255) / 256 < 2048 ? (n_pad + 255) / 256 : 2048);
   hipLaunchKernelGGL(copy_pad_f32_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, s, src, dst, n, n_pad);
 }
+__global__ void scale_copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n, float mul) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i] * mul;
+}
+void scale_copy_f32(hipStream_t s, const float* src, float* dst, size_t n, float mul) {
+  int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(scale_copy_f32_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, s, src, dst, n, mul);
+}
 void copy_f32(hipStream_t s, const float* src, float* dst, size_t n) {
   int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   if (grid < 1) grid = 1;
@@ -158,7 +165,7 @@ bool step_begin(hipStream_t s, float* grads, size_t n, float* loss_acc, int* val
 }
 // (loss, all-finite flag) of a step into the head / tail words of a gradient bucket (train.py: GradBucket), one launch
 __global__ void pack_tail_kernel(const float* loss, const int* valid, float* head_valid, float* tail_loss, float* tail_valid) {
-  const float v = valid[0] != 0 ? 1.f : 0.f;
+  const float v = (valid[0] != 0 && isfinite(loss[0])) ? 1.f : 0.f;   // train.py:369: a non-finite loss skips the step as well
   if (tail_loss != nullptr) tail_loss[0] = loss[0];
   if (tail_valid != nullptr) tail_valid[0] = v;
   if (head_valid != nullptr) head_valid[0] = v;
@@ -353,10 +360,14 @@ __global__ __launch_bounds__(256) void adamw_compute_kernel(const float* __restr
                                                             float* __restrict__ m, float* __restrict__ v,
                                                             float* __restrict__ upd, const float* __restrict__ lr_scale,
                                                             size_t n, float lr, float b1, float b2, float eps, float wd,
-                                                            float bc1, float bc2, float* __restrict__ norm2,
+                                                            int step, const int* __restrict__ count, float* __restrict__ norm2,
                                                             const int* __restrict__ gate_i, const float* __restrict__ gate_f) {
   __shared__ float red[4];
   if (!adamw_gate_open(gate_i, gate_f)) return;   // non-finite gradients: m, v and the update stay untouched
+  // optax counts APPLIED updates: step < 0 takes the count from the device word that adamw_apply advances only when its
+  // gate is open, so a skipped step does not move the bias corrections (the reference rolls opt_state back, train.py:369-377)
+  const float t = (float)(step > 0 ? step : count[0] + 1);
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
   float acc = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float gi = g[i];
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(256) void adamw_compute_kernel(const float* __restr
 // accumulator clean without a fill launch of its own - also under hipGraph replay and whatever the caller does between steps.
 __global__ void adamw_apply_kernel(float* __restrict__ p, const float* __restrict__ upd, size_t n,
                                    float* __restrict__ norm2, float clip, const int* __restrict__ gate_i,
-                                   const float* __restrict__ gate_f) {
+                                   const float* __restrict__ gate_f, int step, int* __restrict__ count) {
   __shared__ float s_nrm2;
   if (threadIdx.x == 0) {
     s_nrm2 = __hip_atomic_load(norm2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -390,6 +401,8 @@ __global__ void adamw_apply_kernel(float* __restrict__ p, const float* __restric
     if (atomicAdd(cnt, 1u) == gridDim.x - 1) {
       __hip_atomic_store(norm2, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the count of applied updates: advanced by ONE thread of the launch, only behind an open gate (an explicit step sets it)
+      if (adamw_gate_open(gate_i, gate_f)) count[0] = step > 0 ? step : count[0] + 1;
     }
   }
   __syncthreads();
@@ -402,16 +415,15 @@ __global__ void adamw_apply_kernel(float* __restrict__ p, const float* __restric
 
 void adamw_compute(hipStream_t s, const float* params, const float* grads, float* m, float* v, float* upd,
                    const float* lr_scale, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
-                   float* norm2, const int* gate_i, const float* gate_f) {
-  float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+                   const int* count, float* norm2, const int* gate_i, const float* gate_f) {
   ProfScope ps(s, "adamw_compute", 0, 28.0 * n);
   hipLaunchKernelGGL(adamw_compute_kernel, dim3(2048), dim3(256), 0, s, params, grads, m, v, upd, lr_scale, n, lr, b1,
-                     b2, eps, wd, bc1, bc2, norm2, gate_i, gate_f);
+                     b2, eps, wd, step, count, norm2, gate_i, gate_f);
 }
 void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, float* norm2, float clip,
-                 const int* gate_i, const float* gate_f) {
+                 const int* gate_i, const float* gate_f, int step, int* count) {
   ProfScope ps(s, "adamw_apply", 0, 12.0 * n);
-  hipLaunchKernelGGL(adamw_apply_kernel, dim3(2048), dim3(256), 0, s, params, upd, n, norm2, clip, gate_i, gate_f);
+  hipLaunchKernelGGL(adamw_apply_kernel, dim3(2048), dim3(256), 0, s, params, upd, n, norm2, clip, gate_i, gate_f, step, count);
 }
 
 // ------------------------------------------------------------------ profiler (prof.h)

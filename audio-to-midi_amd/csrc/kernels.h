@@ -338,6 +338,7 @@ void convert_f32(hipStream_t s, DType dt, const float* src, void* dst, size_t n)
 void convert_transpose(hipStream_t s, DType dt, const float* src, void* dst, int R, int C);
 void fill_f32(hipStream_t s, float* p, float v, size_t n);
 void copy_f32(hipStream_t s, const float* src, float* dst, size_t n);
+void scale_copy_f32(hipStream_t s, const float* src, float* dst, size_t n, float mul);   // dst = src * mul (small vectors)
 // dst[0..n) = src, dst[n..n_pad) = 0 in one launch
 void copy_pad_f32(hipStream_t s, const float* src, float* dst, size_t n, size_t n_pad);
 
@@ -345,13 +346,14 @@ void copy_pad_f32(hipStream_t s, const float* src, float* dst, size_t n, size_t 
 // pass 1: update m, v, write the (unclipped) update into upd, accumulate sum(upd^2) into norm2[0]
 void adamw_compute(hipStream_t s, const float* params, const float* grads, float* m, float* v, float* upd,
                    const float* lr_scale, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
-                   float* norm2, const int* gate_i = nullptr, const float* gate_f = nullptr);
+                   const int* count, float* norm2, const int* gate_i, const float* gate_f);
 // pass 2: params += upd * min(1, clip / sqrt(norm2)); norm2 = float[2] (sum, reader count), left zeroed for the next step
 bool step_begin(hipStream_t s, float* grads, size_t n, float* loss_acc, int* valid);   // false: not applicable (alignment)
 void pack_tail(hipStream_t s, const float* loss, const int* valid, float* head_valid, float* tail_loss, float* tail_valid);
-// gate_i / gate_f (device, either may be null): both passes are no-ops unless *gate_i != 0 and *gate_f >= 0.999
+// gate_i / gate_f (device, either may be null): both passes are no-ops unless *gate_i != 0 and *gate_f >= 0.999;
+// step > 0: explicit optimizer step, step < 0: *count + 1 (device count of applied updates, advanced behind an open gate)
 void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, float* norm2, float clip,
-                 const int* gate_i = nullptr, const float* gate_f = nullptr);
+                 const int* gate_i, const float* gate_f, int step, int* count);
 
 // batched fp32 -> T weight conversion (plain copy or transpose), one launch for the whole model
 struct ConvDesc { uint64_t src_off; uint64_t dst_off; int rows, cols; int src_rows; int transpose;

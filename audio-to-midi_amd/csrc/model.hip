@@ -697,8 +697,16 @@ __global__ void advance_seed_kernel(uint64_t* p, uint64_t delta) { *p += delta; 
 // [L.fn_w, n_params), complete and unscaled when the call returns), 2 = the CNN stages (range [0, L.fn_w)).
 // Both halves run the same host bookkeeping (buffer rotation, scratch regions, record offsets, riders)
 // and only launch inside their own half, so 1 followed by 2 issues exactly the launches of 0.
+// Gradient accumulation over minibatches (train.py:275-310: lax.scan, fp32 accumulation, / (grad_scale * steps)): call
+// acc_index = 0 .. acc_count - 1.  Call 0 zeroes the context's accumulator, the loss accumulators and sets the flag; every
+// call ADDS its gradients there (the weight-gradient kernels add with fp32 atomics, the record sums add as well); the last
+// call's final pass writes accumulator / (scale * acc_count) to the caller's buffer and checks it.  No extra pass, no
+// second gradient buffer.
 int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labels, int B, int T, float scale,
-                 bool train, uint64_t seed, float* grads_out, int* grads_valid, int phase = 0) {
+                 bool train, uint64_t seed, float* grads_out, int* grads_valid, int phase = 0, int acc_index = 0,
+                 int acc_count = 1) {
+  const bool acc_first = acc_index == 0, acc_last = acc_index == acc_count - 1;
+  const float out_mul = 1.f / (scale * (float)acc_count);
   const amt_config& cfg = c->cfg;
   const Layout& L = c->L;
   // Gradients are accumulated (fp32 atomics, record sums) in a buffer of the context whose base is shifted so
@@ -840,8 +848,8 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   // Kernels, not hipMemsetAsync: under hipGraph replay (ROCm 7.2, MI355X) the captured memset nodes of
   // this step did not take effect from the second replay on (gradients accumulated over replays;
   // scratch/graph_dbg2.py), kernel nodes keep their stream order.  One launch for the three of them where it applies.
-  bool began = false;
-  RUN(began = step_begin(s, grads, L.n_params, c->loss_acc, grads_valid));
+  bool began = !acc_first;   // later minibatches of an accumulated step add to what is there
+  if (acc_first) RUN(began = step_begin(s, grads, L.n_params, c->loss_acc, grads_valid));
   if (!began) {
     RUN(hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, grads_valid, 1));
     RUN(fill_f32(s, grads, 0.f, L.n_params));
@@ -1020,7 +1028,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   if (phase == 1) {
     flush_deferred();   // the first transformer layer's weight gradients (in the one-call step they ride on stage 6)
     RUN(reduce_partials(s, c->part_desc_dev, c->n_part_desc_half, c->partials, grads));
-    RUN(grads_finalize(s, grads + L.fn_w, grads_out + L.fn_w, L.n_params - L.fn_w, 1.f / scale, grads_valid));
+    if (acc_last) RUN(grads_finalize(s, grads + L.fn_w, grads_out + L.fn_w, L.n_params - L.fn_w, out_mul, grads_valid));
     return 0;
   }
   if (phase == 2) { live = true; sink.dry = dry || A.overflow; deferred.clear(); }   // phase 1 ran the deferred problems itself (none of them takes sink records)
@@ -1136,10 +1144,10 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   c->part_total = sink.off;
   if (phase == 2) {
     RUN(reduce_partials(s, c->part_desc_dev + c->n_part_desc_half, c->n_part_desc - c->n_part_desc_half, c->partials, grads));
-    RUN(grads_finalize(s, grads, grads_out, L.fn_w, 1.f / scale, grads_valid));
+    if (acc_last) RUN(grads_finalize(s, grads, grads_out, L.fn_w, out_mul, grads_valid));
   } else {
     RUN(reduce_partials(s, c->part_desc_dev, c->n_part_desc, c->partials, grads));
-    RUN(grads_finalize(s, grads, grads_out, L.n_params, 1.f / scale, grads_valid));
+    if (acc_last) RUN(grads_finalize(s, grads, grads_out, L.n_params, out_mul, grads_valid));
   }
 #undef RUN
   return 0;
@@ -1151,6 +1159,7 @@ int plan(amt_ctx* c, int B, int T, int train_mode, hipStream_t s) {
   if (c->plan_B == B && c->plan_T == T && c->plan_train == train_mode && c->arena.base) return 0;
   for (const amt_ctx::PlanRec& r : c->plans) {
     if (r.B != B || r.T != T || r.train != train_mode) continue;
+    if (c->arena.cap < r.peak || c->partials_cap < r.part_total) continue;   // (cannot happen while both only grow; re-plan rather than run in a workspace that is too small)
     // planned before: the arena and the record workspace are at least as large as this plan needs (they only
     // grow), its descriptors are still on the device: nothing is allocated, no captured graph is invalidated
     c->scratch_max = r.scratch_max;
@@ -1217,7 +1226,6 @@ int plan(amt_ctx* c, int B, int T, int train_mode, hipStream_t s) {
     c->part_desc_dev = rec.desc_dev;
     c->n_part_desc = rec.n_desc;
   }
-  c->plans.push_back(rec);
   if (need > c->arena.cap) {
     HIPCHK(c, hipDeviceSynchronize());
     if (c->arena.base) (void)hipFree(c->arena.base);
@@ -1227,6 +1235,11 @@ int plan(amt_ctx* c, int B, int T, int train_mode, hipStream_t s) {
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->arena.base), need));
     c->arena.cap = need;
   }
+  // the record is kept only now that every allocation it describes exists: after a failed hipMalloc above the next
+  // call for this shape plans again and reports the out-of-memory error instead of running in a missing workspace
+  for (auto it = c->plans.begin(); it != c->plans.end();)
+    it = (it->B == B && it->T == T && it->train == train_mode) ? c->plans.erase(it) : it + 1;
+  c->plans.push_back(rec);
   c->arena.off = 0;
   c->arena.peak = 0;
   c->arena.dry = false;
@@ -1441,33 +1454,30 @@ int32_t amt_forward(amt_ctx* c, const void* audio, int32_t B, int32_t T, float* 
   return 0;
 }
 
-int32_t amt_forward_backward(amt_ctx* c, const void* audio, const float* labels, int32_t B, int32_t T, float scale,
-                             uint64_t seed, int32_t train, float* loss_out, float* grads_flat, int32_t* grads_valid,
-                             float* logits, void* stream) {
+int32_t amt_forward_train(amt_ctx* c, const void* audio, int32_t B, int32_t T, uint64_t seed, float* logits, float* probs,
+                          void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (check_shape(c, B, T)) return 1;
-  if (!(scale > 0.f)) { c->err = "scale must be positive"; return 1; }
   if (ensure_rope(c, T / 320)) return 1;
-  if (plan(c, B, T, 1, s)) return 1;
+  if (plan(c, B, T, 1, s)) return 1;           // the training plan: the forward of the training step, dropout on
   c->arena.off = 0;
-  if (run_forward(c, s, audio, B, T, true, train != 0, seed)) return 1;
-  if (logits) head_probs(s, c->logits_pad, c->L.VP, logits, nullptr, B * (T / 320), c->cfg.n_events);
-  if (run_backward(c, s, audio, labels, B, T, scale, train != 0, seed, grads_flat, grads_valid)) return 1;
+  if (run_forward(c, s, audio, B, T, true, true, seed)) return 1;
   if (c->arena.overflow) { c->err = "internal error: workspace plan too small"; return 1; }
-  copy_f32(s, c->loss_acc, loss_out, 2);
+  head_probs(s, c->logits_pad, c->L.VP, logits, probs, B * (T / 320), c->cfg.n_events);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { c->err = std::string("amt_forward_backward: ") + hipGetErrorString(e); return 1; }
+  if (e != hipSuccess) { c->err = std::string("amt_forward_train: ") + hipGetErrorString(e); return 1; }
   return 0;
 }
 
-int32_t amt_forward_backward_phase(amt_ctx* c, const void* audio, const float* labels, int32_t B, int32_t T, float scale,
+int32_t amt_forward_backward_accum(amt_ctx* c, const void* audio, const float* labels, int32_t B, int32_t T, float scale,
                                    uint64_t seed, int32_t train, float* loss_out, float* grads_flat, int32_t* grads_valid,
-                                   float* logits, int32_t phase, void* stream) {
+                                   float* logits, int32_t phase, int32_t accum_index, int32_t accum_count, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (phase != 1 && phase != 2) { c->err = "phase must be 1 or 2"; return 1; }
+  if (phase < 0 || phase > 2) { c->err = "phase must be 0 (whole step), 1 or 2"; return 1; }
+  if (accum_count < 1 || accum_index < 0 || accum_index >= accum_count) { c->err = "accum_index must be in [0, accum_count)"; return 1; }
   if (check_shape(c, B, T)) return 1;
   if (!(scale > 0.f)) { c->err = "scale must be positive"; return 1; }
-  if (phase == 1) {
+  if (phase != 2) {
     if (ensure_rope(c, T / 320)) return 1;
     if (plan(c, B, T, 1, s)) return 1;
     c->arena.off = 0;
@@ -1478,12 +1488,29 @@ int32_t amt_forward_backward_phase(amt_ctx* c, const void* audio, const float* l
     if (c->plan_B != B || c->plan_T != T || c->plan_train != 1) { c->err = "phase 2 without a matching phase 1"; return 1; }
     c->arena.off = c->fwd_end_off;
   }
-  if (run_backward(c, s, audio, labels, B, T, scale, train != 0, seed, grads_flat, grads_valid, phase)) return 1;
+  if (run_backward(c, s, audio, labels, B, T, scale, train != 0, seed, grads_flat, grads_valid, phase, accum_index, accum_count))
+    return 1;
   if (c->arena.overflow) { c->err = "internal error: workspace plan too small"; return 1; }
-  if (phase == 1) copy_f32(s, c->loss_acc, loss_out, 2);
+  // the loss accumulators hold the SUM over the minibatches so far of each minibatch's mean loss (train.py:60-62, 292)
+  if (phase != 2 && loss_out != nullptr && accum_index == accum_count - 1) scale_copy_f32(s, c->loss_acc, loss_out, 2, 1.f / (float)accum_count);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { c->err = std::string("amt_forward_backward_phase: ") + hipGetErrorString(e); return 1; }
+  if (e != hipSuccess) { c->err = std::string("amt_forward_backward: ") + hipGetErrorString(e); return 1; }
   return 0;
+}
+
+int32_t amt_forward_backward(amt_ctx* c, const void* audio, const float* labels, int32_t B, int32_t T, float scale,
+                             uint64_t seed, int32_t train, float* loss_out, float* grads_flat, int32_t* grads_valid,
+                             float* logits, void* stream) {
+  return amt_forward_backward_accum(c, audio, labels, B, T, scale, seed, train, loss_out, grads_flat, grads_valid, logits, 0, 0, 1,
+                                    stream);
+}
+
+int32_t amt_forward_backward_phase(amt_ctx* c, const void* audio, const float* labels, int32_t B, int32_t T, float scale,
+                                   uint64_t seed, int32_t train, float* loss_out, float* grads_flat, int32_t* grads_valid,
+                                   float* logits, int32_t phase, void* stream) {
+  if (phase != 1 && phase != 2) { c->err = "phase must be 1 or 2"; return 1; }
+  return amt_forward_backward_accum(c, audio, labels, B, T, scale, seed, train, loss_out, grads_flat, grads_valid, logits, phase, 0,
+                                    1, stream);
 }
 
 uint64_t amt_grad_bucket_split(const amt_ctx* c) { return c->L.fn_w; }
@@ -1552,8 +1579,8 @@ int32_t amt_optimizer_init(amt_ctx* c, float layer_lr_decay) {
     HIPCHK(c, hipMalloc(&c->adam_v, n * sizeof(float)));
     HIPCHK(c, hipMalloc(&c->adam_upd, n * sizeof(float)));
     HIPCHK(c, hipMalloc(&c->lr_scale, n * sizeof(float)));
-    HIPCHK(c, hipMalloc(&c->norm2, 2 * sizeof(float)));   // [sum of squares, reader count]: adamw_apply leaves both zero
-    HIPCHK(c, hipMemset(c->norm2, 0, 2 * sizeof(float)));
+    HIPCHK(c, hipMalloc(&c->norm2, 4 * sizeof(float)));   // [sum of squares, reader count]: adamw_apply leaves both zero; [2]: int count of applied updates
+    HIPCHK(c, hipMemset(c->norm2, 0, 4 * sizeof(float)));
     HIPCHK(c, hipMemset(c->adam_m, 0, n * sizeof(float)));
     HIPCHK(c, hipMemset(c->adam_v, 0, n * sizeof(float)));
   }
@@ -1578,14 +1605,22 @@ int32_t amt_adamw_step_gated(amt_ctx* c, const float* grads_flat, float lr_base,
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t n = c->L.n_params;
   // optax counts from 1: step <= 0 makes the bias corrections 1 - b^step zero or negative (m / 0 = inf in every parameter)
-  if (step < 1) { c->err = "amt_adamw_step: step must be >= 1 (the first optimizer step is step 1)"; return 1; }
+  if (step < 1 && step != -1) { c->err = "amt_adamw_step: step must be >= 1 (the first optimizer step is step 1), or -1 for the device count"; return 1; }
   if (!c->adam_m || c->lr_scale_decay != layer_lr_decay) {
     if (amt_optimizer_init(c, layer_lr_decay)) return 1;
   }
+  int* count = reinterpret_cast<int*>(c->norm2 + 2);
   adamw_compute(s, c->params, grads_flat, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, n, lr_base, b1, b2, eps,
-                weight_decay, step, c->norm2, valid_i32, valid_f32);
-  adamw_apply(s, c->params, c->adam_upd, n, c->norm2, clip_norm, valid_i32, valid_f32);
+                weight_decay, step, count, c->norm2, valid_i32, valid_f32);
+  adamw_apply(s, c->params, c->adam_upd, n, c->norm2, clip_norm, valid_i32, valid_f32, step, count);
   return refresh(c, s);
+}
+
+int32_t amt_optimizer_count(amt_ctx* c) {
+  if (!c->norm2) return 0;
+  int v = 0;
+  if (hipMemcpy(&v, c->norm2 + 2, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return v;
 }
 
 int32_t amt_adamw_step(amt_ctx* c, const float* grads_flat, float lr_base, float layer_lr_decay, float b1, float b2,

@@ -90,8 +90,10 @@ SIGNATURES = {
     "amt_set_attn_fp8": (_i32, [_vp, _i32]),
     "amt_num_frames": (_i32, [C.POINTER(AmtConfig), _i32]),
     "amt_forward": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "amt_forward_train": (_i32, [_vp, _vp, _i32, _i32, _u64, _vp, _vp, _vp]),
     "amt_forward_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _u64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "amt_forward_backward_phase": (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _u64, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "amt_forward_backward_accum": (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _u64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "amt_grad_bucket_split": (_u64, [_vp]),
     "amt_workspace_bytes": (_u64, [_vp]),
     "amt_plan_generation": (_u64, [_vp]),
@@ -102,6 +104,7 @@ SIGNATURES = {
     "amt_adamw_step": (_i32, [_vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "amt_adamw_step_gated": (_i32, [_vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp, _vp]),
     "amt_optimizer_init": (_i32, [_vp, _f32]),
+    "amt_optimizer_count": (_i32, [_vp]),
     "amt_profile_begin": (None, []),
     "amt_profile_end": (_i32, [_vp, _i32]),
     # ops

@@ -188,15 +188,33 @@ class OutputSequenceGenerator:
 
     def __call__(self, samples, state=None, rope_freqs: Optional[RopeFreqs] = None, key=None,
                  enable_dropout: bool = False):
-        if enable_dropout:
-            raise NotImplementedError("training-mode forward is exposed through loss_and_grads(train=True)")
-        return self.predict(state, samples, rope_freqs), state
+        """model.py:740-769 under vmap: ``((logits, probs), state)``.  ``enable_dropout=True`` is the forward pass of the
+        training step (the call compute_loss makes, train.py:56-58): attention-weight and FFN-output dropout with masks
+        drawn from ``key`` (an integer seed here; a JAX PRNG key in the reference) - the masks ``loss_and_grads(seed=key,
+        train=True)`` draws, so its logits are the ones that loss is computed from.  The CNN's stochastic depth stays
+        inactive in both modes, as in the reference (eqx.nn.Sequential forwards only ``key``, model.py:757-758, 160)."""
+        if not enable_dropout:
+            return self.predict(state, samples, rope_freqs), state
+        a = self._prep_audio(samples)
+        B, _, T = a.shape
+        S = T // 320
+        self._ensure_rope(rope_freqs, S)
+        logits = torch.empty(B, S, self.n_events, dtype=torch.float32, device=self.device)
+        probs = torch.empty_like(logits)
+        self._check(self._L.amt_forward_train(self._h, _lib.ptr(a), B, T, int(0 if key is None else key), _lib.ptr(logits),
+                                              _lib.ptr(probs), self._stream()), "amt_forward_train")
+        return (logits, probs), state
 
     # ------------------------------------------------------------------ training forward + backward
     def loss_and_grads(self, audio, labels, scale: float = 1.0, seed: int = 0, train: bool = True,
                        rope_freqs: Optional[RopeFreqs] = None, return_logits: bool = False,
-                       grads_out: Optional[torch.Tensor] = None, sync: bool = True):
-        """compute_loss + the gradient half of compute_training_step (train.py:49-62, 292-322)."""
+                       grads_out: Optional[torch.Tensor] = None, sync: bool = True, accum=(0, 1),
+                       loss_out: Optional[torch.Tensor] = None, valid_out: Optional[torch.Tensor] = None):
+        """compute_loss + the gradient half of compute_training_step (train.py:49-62, 292-322).
+
+        ``accum=(i, k)``: minibatch i of k of an accumulated step (train.py:275-310): call i = 0 .. k - 1 in order with
+        the same ``grads_out`` / ``loss_out`` / ``valid_out`` tensors; gradients are summed in the context's fp32
+        accumulator and only call k - 1 writes ``grads_out = sum / (scale * k)``, the mean loss and the flag."""
         a = self._prep_audio(audio)
         B, _, T = a.shape
         S = T // 320
@@ -206,12 +224,15 @@ class OutputSequenceGenerator:
         self._ensure_rope(rope_freqs, S)
         grads = grads_out if grads_out is not None else torch.empty(self.n_params, dtype=torch.float32,
                                                                     device=self.device)
-        loss = torch.empty(2, dtype=torch.float32, device=self.device)
-        valid = torch.empty(1, dtype=torch.int32, device=self.device)
+        loss = loss_out if loss_out is not None else torch.empty(2, dtype=torch.float32, device=self.device)
+        valid = valid_out if valid_out is not None else torch.empty(1, dtype=torch.int32, device=self.device)
         logits = torch.empty(B, S, self.n_events, dtype=torch.float32, device=self.device) if return_logits else None
-        self._check(self._L.amt_forward_backward(self._h, _lib.ptr(a), _lib.ptr(y), B, T, float(scale), int(seed),
-                                                 1 if train else 0, _lib.ptr(loss), _lib.ptr(grads), _lib.ptr(valid),
-                                                 _lib.ptr(logits), self._stream()), "amt_forward_backward")
+        ai, ak = int(accum[0]), int(accum[1])
+        self._check(self._L.amt_forward_backward_accum(self._h, _lib.ptr(a), _lib.ptr(y), B, T, float(scale), int(seed),
+                                                       1 if train else 0, _lib.ptr(loss), _lib.ptr(grads), _lib.ptr(valid),
+                                                       _lib.ptr(logits), 0, ai, ak, self._stream()), "amt_forward_backward")
+        if ai != ak - 1:
+            return loss, grads, valid, logits          # nothing has been written yet: the last minibatch finalises
         if not sync:
             return loss, grads, valid, logits
         lv = loss.cpu().numpy()
@@ -224,13 +245,16 @@ class OutputSequenceGenerator:
         return int(self._L.amt_grad_bucket_split(self._h))
 
     def loss_and_grads_phase(self, phase: int, audio, labels, grads_out: torch.Tensor, loss_out: torch.Tensor,
-                             valid_out: torch.Tensor, scale: float = 1.0, seed: int = 0, train: bool = True):
+                             valid_out: torch.Tensor, scale: float = 1.0, seed: int = 0, train: bool = True, accum=(0, 1)):
         """Asynchronous half of ``loss_and_grads`` (include/amt.h: amt_forward_backward_phase).  All tensors are
         caller-owned device tensors (audio in the activation dtype, labels fp32); nothing is synchronised."""
-        self._check(self._L.amt_forward_backward_phase(self._h, _lib.ptr(audio), _lib.ptr(labels), audio.shape[0],
+        if int(phase) not in (1, 2):
+            raise RuntimeError("amt_forward_backward_phase failed: phase must be 1 or 2")
+        self._check(self._L.amt_forward_backward_accum(self._h, _lib.ptr(audio), _lib.ptr(labels), audio.shape[0],
                                                        audio.shape[2], float(scale), int(seed), 1 if train else 0,
                                                        _lib.ptr(loss_out), _lib.ptr(grads_out), _lib.ptr(valid_out), None,
-                                                       int(phase), self._stream()), "amt_forward_backward_phase")
+                                                       int(phase), int(accum[0]), int(accum[1]), self._stream()),
+                    "amt_forward_backward_phase")
 
     def init_optimizer(self, layer_lr_decay=0.7):
         """Allocate AdamW state (train.py:845 setup_optimizers).  Call before hipGraph capture."""
@@ -239,7 +263,8 @@ class OutputSequenceGenerator:
     def adamw_step(self, grads_flat, lr_base, step, layer_lr_decay=0.7, b1=0.9, b2=0.999, eps=1e-3,
                    weight_decay=0.005, clip_norm=1.0, valid: Optional[torch.Tensor] = None,
                    valid_mean: Optional[torch.Tensor] = None):
-        """optimizer half of compute_training_step (train.py:324-325, 646-729).  ``step`` counts from 1 (optax).
+        """optimizer half of compute_training_step (train.py:324-325, 646-729).  ``step`` counts from 1 (optax);
+        ``step=-1`` takes the count of applied updates from the device (skipped steps do not advance it).
 
         ``valid`` (device int32[1], the grads_valid word of ``loss_and_grads``) and ``valid_mean`` (device
         float32[1], that flag after a mean all-reduce: 1.0 iff every rank's is 1) gate the update ON THE DEVICE:
@@ -253,6 +278,10 @@ class OutputSequenceGenerator:
                                                  float(b1), float(b2), float(eps), float(weight_decay), float(clip_norm),
                                                  int(step), _lib.ptr(valid), _lib.ptr(valid_mean), self._stream()),
                     "amt_adamw_step")
+
+    def optimizer_count(self) -> int:
+        """Number of optimizer updates applied so far (device counter; synchronises).  include/amt.h: amt_optimizer_count."""
+        return int(self._L.amt_optimizer_count(self._h))
 
     def workspace_bytes(self) -> int:
         return int(self._L.amt_workspace_bytes(self._h))

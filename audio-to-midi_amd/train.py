@@ -2,9 +2,11 @@
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Parameters are
 replicated, the batch is sharded along axis 0 (reference: `NamedSharding(mesh, P("batch"))`,
-train.py:238-244, 280), and the ONLY exchange step is one sum-all-reduce of the flat fp32 gradient
-bucket with the loss and the finite flag folded into its tail — the explicit form of the gradient
-all-reduce XLA's GSPMD inserts implicitly in the reference.
+train.py:238-244, 280), and the ONLY exchange step is the mean all-reduce of the flat fp32 gradient
+bucket with the loss and the finite flags folded into it — the explicit form of the gradient
+all-reduce XLA's GSPMD inserts implicitly in the reference.  ``DataParallelStep`` is the one
+implementation of that protocol: bench.py times it, tests/test_dp_cpu.py drives it under gloo with
+two ranks, a training loop calls it.
 """
 from __future__ import annotations
 
@@ -13,37 +15,6 @@ from dataclasses import dataclass
 from typing import Callable, Optional, Tuple
 
 import torch
-
-BUCKET_TAIL = 3  # loss, scaled_loss, grads_valid
-
-
-def new_bucket(n_params: int, device) -> torch.Tensor:
-    """[grads (n_params) | loss | scaled_loss | valid] in one contiguous fp32 buffer."""
-    return torch.zeros(n_params + BUCKET_TAIL, dtype=torch.float32, device=device)
-
-
-def pack_tail(bucket: torch.Tensor, loss, scaled_loss, valid) -> None:
-    n = bucket.numel() - BUCKET_TAIL
-    bucket[n] = loss
-    bucket[n + 1] = scaled_loss
-    bucket[n + 2] = valid
-
-
-def allreduce_bucket(bucket: torch.Tensor, dist=None) -> Tuple[torch.Tensor, float, float, bool]:
-    """Sum over ranks, divide by the world size (the reference takes the MEAN over the global
-    batch, train.py:62, and every rank holds the mean over its shard).  The finite flag becomes
-    "all ranks finite" (train.py:320-322).  Returns (grads view, loss, scaled_loss, grads_valid)."""
-    world = 1
-    if dist is not None and dist.is_initialized():
-        world = dist.get_world_size()
-        if world > 1:
-            dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
-            bucket.mul_(1.0 / world)
-    n = bucket.numel() - BUCKET_TAIL
-    tail = bucket[n:].tolist()
-    valid = abs(tail[2] - 1.0) < 0.5 / max(world, 1)   # mean of 0/1 flags is 1 only if all are 1
-    return bucket[:n], float(tail[0]), float(tail[1]), bool(valid)
-
 
 def create_learning_rate_schedule(base_learning_rate: float, warmup_steps: int, cosine_decay_steps: int) -> Callable[[int], float]:
     """train.py:455-466: linear warm-up from 0 to ``base_learning_rate`` over ``warmup_steps`` updates, then a cosine decay
@@ -85,50 +56,6 @@ class LossScaleController:
         if self.enabled and scaled_loss < self.growth_threshold:
             self.scale = self.scale * 2
         return False
-
-
-def compute_training_step(model, audio, labels, *, grad_scale: float, seed: int, bucket: torch.Tensor,
-                          lr_base: float, step: int, dist=None, accum_steps: int = 1,
-                          apply_update: bool = True, local_step: Optional[Callable] = None):
-    """One optimizer step: per-rank forward/backward on this rank's shard (optionally split into
-    `accum_steps` minibatches accumulated in fp32, train.py:275-310), ONE all-reduce, AdamW.
-
-    `local_step(audio, labels, scale, seed) -> (loss, scaled_loss, grads_flat, valid)` defaults to
-    the HIP path (`model.loss_and_grads`); tests inject the oracle there to exercise the collective
-    protocol on CPU tensors."""
-    n = bucket.numel() - BUCKET_TAIL
-    B = audio.shape[0]
-    if B % accum_steps:
-        raise ValueError("batch not divisible by accum_steps")
-    mb = B // accum_steps
-    acc = bucket[:n]
-    tot_loss = tot_scaled = 0.0
-    all_valid = True
-    for i in range(accum_steps):
-        a, y = audio[i * mb:(i + 1) * mb], labels[i * mb:(i + 1) * mb]
-        if local_step is None:
-            out = model.loss_and_grads(a, y, scale=grad_scale, seed=seed + i, train=True,
-                                       grads_out=acc if accum_steps == 1 else None)
-            loss, scaled, g, valid = out.loss, out.scaled_loss, out.grads_flat, out.grads_valid
-        else:
-            loss, scaled, g, valid = local_step(a, y, grad_scale, seed + i)
-        if accum_steps == 1:
-            if g.data_ptr() != acc.data_ptr():
-                acc.copy_(g)
-        elif i == 0:
-            acc.copy_(g)
-        else:
-            acc.add_(g)
-        tot_loss += loss
-        tot_scaled += scaled
-        all_valid = all_valid and valid
-    if accum_steps > 1:
-        acc.mul_(1.0 / accum_steps)
-    pack_tail(bucket, tot_loss / accum_steps, tot_scaled / accum_steps, 1.0 if all_valid else 0.0)
-    grads, loss, scaled_loss, valid = allreduce_bucket(bucket, dist)
-    if apply_update and valid and model is not None:
-        model.adamw_step(grads, lr_base=lr_base, step=step)
-    return loss, scaled_loss, valid
 
 
 # ======================================================================================================
@@ -178,9 +105,16 @@ class HipTrainBackend:
     """Per-rank forward/backward/optimizer on the HIP library for fixed, device-resident inputs."""
 
     def __init__(self, model, audio: torch.Tensor, labels: torch.Tensor, bucket: GradBucket, scale: float = 1.0,
-                 use_optimizer: bool = True):
+                 use_optimizer: bool = True, accum_steps: int = 1):
         self.model, self.audio, self.labels, self.bucket, self.scale = model, audio, labels, bucket, float(scale)
         self.use_optimizer = use_optimizer
+        # train.py:275-310: the rank's batch in `accum_steps` minibatches, gradients accumulated in fp32 ON THE DEVICE (the
+        # context's accumulator: amt_forward_backward_accum), grads / (grad_scale * steps) in the last minibatch's final pass
+        self.accum_steps = int(accum_steps)
+        if self.accum_steps < 1 or audio.shape[0] % self.accum_steps:
+            raise ValueError("the rank's batch must be divisible by accum_steps")
+        mb = audio.shape[0] // self.accum_steps
+        self._mb = [(audio[i * mb:(i + 1) * mb], labels[i * mb:(i + 1) * mb]) for i in range(self.accum_steps)]
         dev = audio.device
         self.loss_buf = torch.zeros(2, dtype=torch.float32, device=dev)
         self.valid_buf = torch.ones(1, dtype=torch.int32, device=dev)
@@ -189,26 +123,38 @@ class HipTrainBackend:
             model.init_optimizer()
 
     def full(self, seed: int):
-        b = self.bucket
-        loss, _, valid, _ = self.model.loss_and_grads(self.audio, self.labels, scale=self.scale, seed=seed, train=True,
-                                                      grads_out=b.grads, sync=False)
-        self.model.pack_tail(loss, valid, head_valid=b.head[0:1], tail_loss=b.tail[0:1], tail_valid=b.tail[1:2])
+        b, k = self.bucket, self.accum_steps
+        for i, (a, y) in enumerate(self._mb):      # one dropout seed per minibatch (train.py:277 splits the key)
+            self.model.loss_and_grads(a, y, scale=self.scale, seed=seed + i, train=True, grads_out=b.grads, sync=False,
+                                      accum=(i, k), loss_out=self.loss_buf, valid_out=self.valid_buf)
+        self.model.pack_tail(self.loss_buf, self.valid_buf, head_valid=b.head[0:1], tail_loss=b.tail[0:1], tail_valid=b.tail[1:2])
 
     def half(self, phase: int, seed: int):
-        b = self.bucket
-        self.model.loss_and_grads_phase(phase, self.audio, self.labels, b.grads, self.loss_buf, self.valid_buf,
-                                        scale=self.scale, seed=seed, train=True)
+        b, k = self.bucket, self.accum_steps
+        if phase == 1:      # all minibatches but the last run whole; the last one is the step that is cut in two
+            for i, (a, y) in enumerate(self._mb[:-1]):
+                self.model.loss_and_grads(a, y, scale=self.scale, seed=seed + i, train=True, grads_out=b.grads, sync=False,
+                                          accum=(i, k), loss_out=self.loss_buf, valid_out=self.valid_buf)
+        a, y = self._mb[-1]
+        self.model.loss_and_grads_phase(phase, a, y, b.grads, self.loss_buf, self.valid_buf,
+                                        scale=self.scale, seed=seed + k - 1, train=True, accum=(k - 1, k))
         if phase == 1:      # captured with the half: no eager launches between the graphs and the collectives
             self.model.pack_tail(self.loss_buf, self.valid_buf, tail_loss=b.tail[0:1], tail_valid=b.tail[1:2])
         else:
             self.model.pack_tail(self.loss_buf, self.valid_buf, head_valid=b.head[0:1])
 
     def advance_seed(self):
-        self.model.advance_seed(1)
+        self.model.advance_seed(self.accum_steps)
 
     def apply(self, step: int, lr_base: float):
-        if self.use_optimizer:   # gated on the all-reduced flag, on the device
-            self.model.adamw_step(self.bucket.grads, lr_base=lr_base, step=step, valid_mean=self.bucket.valid_all)
+        # Gated on the all-reduced flag, on the device.  step = -1: the bias corrections come from the context's DEVICE
+        # count of applied updates, which a skipped (non-finite) step does not advance - optax's count behaves the same
+        # way and the reference rolls its optimizer state back (train.py:369-377); `step` on the host would drift.
+        if self.use_optimizer:
+            self.model.adamw_step(self.bucket.grads, lr_base=lr_base, step=-1, valid_mean=self.bucket.valid_all)
+
+    def applied_steps(self) -> int:
+        return self.model.optimizer_count() if self.use_optimizer else 0
 
     def generation(self) -> int:
         return self.model.plan_generation()
@@ -230,11 +176,16 @@ class DataParallelStep:
                  lr_base: float = 1e-4):
         self.backend, self.bucket, self.split, self.dist = backend, bucket, int(split), dist
         self.world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
+        # the optimizer gate tests the MEAN of the ranks' 0/1 flags against 0.999 (csrc/head.hip: adamw_gate_open): one
+        # bad rank among N gives (N - 1) / N, which must stay below the threshold
+        if self.world >= 1000:
+            raise ValueError("the device-side optimizer gate (mean flag >= 0.999) supports fewer than 1000 ranks")
         self.overlap = bool(overlap)
         self.lr_base = lr_base
         self.cuda = bucket.buf.is_cuda
         self.graph = bool(graph) and self.cuda
         self.step_no = 0
+        self.applied = 0          # optimizer updates actually applied (device count, refreshed by result())
         self._graphs = None
         self._gen = None
         self._comm = torch.cuda.Stream(device=bucket.buf.device) if self.cuda else None
@@ -330,7 +281,12 @@ class DataParallelStep:
         be.apply(self.step_no, self.lr_base)
 
     def result(self) -> Tuple[float, bool]:
-        """(loss, grads_valid) of the last step; synchronises.  grads_valid is the AND over ranks and halves."""
+        """(loss, grads_valid) of the last step; synchronises.  grads_valid is the AND over ranks and halves (and is 0 for
+        a non-finite loss: amt_pack_tail folds isfinite(loss) into the flags, train.py:369).  At this sync point the
+        host's step count is re-aligned with the device's count of APPLIED updates, so the learning-rate schedule
+        (``schedule(applied)``) does not run ahead after skipped steps."""
         v = self.bucket.buf[[0, self.bucket.HEAD + self.bucket.n, self.bucket.HEAD + self.bucket.n + 1]].tolist()
         valid = v[0] >= 0.999 and v[2] >= 0.999
+        if hasattr(self.backend, "applied_steps"):
+            self.applied = int(self.backend.applied_steps())
         return float(v[1]), bool(valid)

@@ -83,7 +83,8 @@ def cpu_baseline(seconds_budget: float = 25.0):
     return {"value": round(Bc * CLIP_SECONDS / med, 2), "unit": "audio-sec/s", "cores": int(torch.get_num_threads()),
             "kind": "port",
             "sample": f"fwd+bwd of B={Bc} x 10 s clips, fp32, full model, median of {n} after 1 warm-up "
-                      f"({med:.2f} s/step); torch-CPU restatement of the reference (JAX unavailable offline)"}
+                      f"({med:.2f} s/step); torch-CPU restatement of the reference (JAX unavailable offline); threads capped at "
+                      f"{cores} (AMT_CPU_BASELINE_THREADS, the box's CPU share per GPU) of os.cpu_count()={os.cpu_count()}"}
 
 
 def named_rooflines(breakdown, profile_steps):
@@ -109,6 +110,123 @@ def named_rooflines(breakdown, profile_steps):
                                     "frac": round(by / t_cnn / 1e9 / PEAK_HBM_GBS, 5), "us_per_step": round(t_cnn * 1e6, 1),
                                     "algorithmic_bytes_per_step": by}
     return out
+
+
+def build_id():
+    """sha-256 (first 16 hex digits) over the kernel sources the library was built from: profile summaries under
+    profiles/ carry it, and a summary taken from another build is not quoted (the GPU box has no .git to ask)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "audio-to-midi_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def survey_8d_bytes(kernel: str, B: int, es: int = 2):
+    """SURVEY.md 8(d) "Algorithmic bytes, conv frontend", per LAUNCH of a conv-frontend class at 10-s clips: a Stem /
+    Block reads its input once and writes its output once (C * L = 128 000 elements per 10-s clip at every stage, the
+    2C hidden expansion never leaves the chip), the backward is counted 2x the forward.  None for classes 8(d) prices
+    by flops (transformer GEMMs, attention)."""
+    base = kernel.split("+")[0]
+    per_clip = 128000
+    if base in ("block_fwd_fused", "block_small_fwd", "block_run_fwd", "dwln_fwd"):
+        return 2.0 * B * per_clip * es
+    if base in ("block_bwd_fused", "block_small_bwd_full", "block_small_bwd", "dwblock_bwd"):
+        return 4.0 * B * per_clip * es
+    if base == "stem_fwd":
+        return B * (320000 + per_clip) * es
+    if base == "stem_bwd":
+        return 2.0 * B * (320000 + per_clip) * es
+    return None
+
+
+def dominant_roofline(top, profile_steps):
+    """`roofline` of the kernel class with the largest share of the step.
+
+    achieved = ALGORITHMIC bytes (conv frontend: SURVEY.md 8(d)'s numerator, NOT the bytes this design moves) or
+    algorithmic flops (2 N M K per GEMM, 4 B H S^2 64 per attention forward) per launch / the class's average launch
+    duration, measured here with HIP events on the launch stream around every EAGER launch (`timing`); the duration of
+    the same class under hipGraph replay is in the committed rocprofv3 summary named by `rocprof_stats` and is quoted
+    as `avg_launch_us_graph` when that summary was taken from this build.  `design_bytes_per_launch` is what the launch
+    sites account (chain reads + writes + the operands of the weight-gradient riders): the design's own traffic model.
+    `traffic` = HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 corrections of
+    MI355X_MICROARCH.md), read from profiles/pmc_traffic_by_class.json ONLY if that file was taken from this build."""
+    name = top["name"]
+    avg_s = 1e-3 * top["total_ms"] / top["launches"]
+    flops_l = top["flops"] / top["launches"]
+    design_l = top["bytes"] / top["launches"]
+    alg_bytes = survey_8d_bytes(name, B_PER_GPU)
+    bid = build_id()
+    traffic, graph_us, stats_file = None, None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_by_class.json")) as f:
+            pj = json.load(f)
+        if pj.get("_build_id") == bid:
+            traffic = pj.get(name, {}).get("hbm_bytes_per_launch")
+            graph_us = pj.get(name, {}).get("avg_launch_us_graph")
+            stats_file = pj.get("_rocprof_stats")
+        else:
+            log(f"roofline: profiles/pmc_traffic_by_class.json is from build {pj.get('_build_id')}, this is {bid}: traffic = null")
+    except OSError:
+        pass
+    common = {"kernel": name, "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2),
+              "timing": "HIP events around eager launches (graph replay is shorter; see avg_launch_us_graph)",
+              "avg_launch_us_graph": graph_us, "rocprof_stats": stats_file, "build_id": bid,
+              "flops_per_launch": flops_l, "design_bytes_per_launch": design_l,
+              "frac_mfma": round(flops_l / avg_s / 1e12 / PEAK_BF16_TFLOPS, 5)}
+    ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    if alg_bytes is not None:       # conv frontend: HBM roof, SURVEY 8(d) numerator
+        gbs = alg_bytes / avg_s / 1e9
+        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(gbs / PEAK_HBM_GBS, 5), "algorithmic_bytes_per_launch": alg_bytes,
+                "numerator": "SURVEY.md 8(d): 2 x (read input + write output) of a Block backward, bf16", **common}
+    tf = flops_l / avg_s / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_BF16_TFLOPS, 5), "algorithmic_bytes_per_launch": None,
+            "numerator": "SURVEY.md 8(d): 2 N M K per GEMM / 4 B H S^2 64 per attention forward", "ridge": round(ridge, 1), **common}
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as child processes through
+    torch.distributed.run (the reference gets its device mesh from one process, train.py:238-244, 834-842; here it is
+    one process per GPU over RCCL), relay their output, exit with their worst return code.  Nothing in this process has
+    initialised the GPU (no HIP call, no torch.cuda.is_available()): it only spawns and waits."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = str(so.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench: no WORLD_SIZE in the environment, starting the ranks:", " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rc = subprocess.call(cmd, env=env)
+    sys.exit(rc)
+
+
+def main_dry_run(args):
+    """World-size-N rendezvous + one all-reduce on CPU tensors (gloo): what a driver sees of the launch path, without a GPU."""
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.ones(4)
+    dist.all_reduce(t)
+    ok = bool((t == world).all())
+    if rank == 0:
+        print(json.dumps({"metric": "launcher dry run", "n_gpus": args.gpus, "ranks_seen": dist.get_world_size(),
+                          "backend": dist.get_backend(), "allreduce_ok": ok}), flush=True)
+    dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
 
 
 def main_infer(args):
@@ -203,7 +321,13 @@ def main():
                     help="10 s clips per GPU and step (default 8 = configs[1]; 32 = configs[4]'s 256 over 8 GPUs)")
     ap.add_argument("--attn-fp8", action="store_true",
                     help="configs[4]: global-attention forward on fp8 MFMA (amt_set_attn_fp8); reported, not the headline")
+    ap.add_argument("--dry-run-launcher", action="store_true",
+                    help="plumbing test of the N > 1 launch path: gloo on CPU tensors, one all-reduce, no GPU work")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)           # before anything touches the GPU: the ranks are CHILD processes
+    if args.dry_run_launcher:
+        return main_dry_run(args)
     if args.workload == "infer":
         return main_infer(args)
     global B_PER_GPU, FLOPS_PER_STEP
@@ -311,36 +435,7 @@ def main():
                 f"  {b['tflops']} TFLOP/s  {b['gbs']} GB/s")
         log(f"  sum of kernel time per step: {tot / args.profile_steps:.3f} ms (timed step {ms_per_step:.3f} ms)")
         top = ents[0]
-        # HBM bytes per launch from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate passes, gfx950 corrections applied by profiles/make_traffic.py); PMC counters cannot
-        # be collected from inside this process, so `traffic` is null when the summary has no entry.
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic_by_class.json")) as f:
-                traffic = json.load(f).get(top["name"], {}).get("hbm_bytes_per_launch")
-        except OSError:
-            pass
-        # Which roofline bounds the class: its arithmetic intensity (algorithmic flops / algorithmic bytes, both from
-        # the launch sites' ProfScope accounting) against the ridge PEAK_MFMA / PEAK_HBM =
-        # 312 flop/byte.  Below the ridge the HBM roof is the lower one, so the class is priced against HBM; the
-        # fraction of the other roof is reported beside it.
-        tf = top["flops"] / top["total_ms"] / 1e9
-        gbs = top["bytes"] / top["total_ms"] / 1e6
-        ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
-        ai = top["flops"] / top["bytes"] if top["bytes"] else float("inf")
-        common = {"kernel": top["name"], "traffic": traffic,
-                  "avg_launch_us": round(1e3 * top["total_ms"] / top["launches"], 2),
-                  "flops_per_launch": top["flops"] / top["launches"],
-                  "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
-                  "arithmetic_intensity": round(ai, 1), "ridge": round(ridge, 1),
-                  "frac_mfma": round(tf / PEAK_BF16_TFLOPS, 5), "frac_hbm": round(gbs / PEAK_HBM_GBS, 5),
-                  "achieved_tflops": round(tf, 2), "achieved_gbs": round(gbs, 1)}
-        if ai >= ridge:
-            roofline = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tf / PEAK_BF16_TFLOPS, 5), **common}
-        else:
-            roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(gbs / PEAK_HBM_GBS, 5), **common}
+        roofline = dominant_roofline(top, args.profile_steps)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -349,7 +444,9 @@ def main():
     if rank == 0:
         out = {
             "metric": "audio-sec/s (fwd+bwd, 10 s clips)", "value": round(value, 1), "unit": "audio-sec/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "n_gpus": world, "ranks_seen": dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1,
+            "comm_backend": (dist.get_backend() + " (RCCL over xGMI)") if (dist is not None and dist.is_initialized()) else None,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 (fp8 e4m3 QK^T / PV in the global-attention forward)" if args.attn_fp8 else "bf16", "data": "synthetic",
             "config": {"workload": f"train.py step: fwd + BCE + bwd of the full model, {B_PER_GPU} clips x 10 s @ 16 kHz stereo per "

@@ -102,6 +102,13 @@ int32_t amt_num_frames(const amt_config* cfg, int32_t T);
 int32_t amt_forward(amt_ctx* ctx, const void* audio, int32_t B, int32_t T, float* logits, float* probs,
                     void* stream);
 
+/* Train-mode forward only: OutputSequenceGenerator.__call__(..., enable_dropout=True) under vmap (model.py:740-769, the
+ * call compute_loss makes at train.py:56-58): the forward pass of the training step (attention-weight and FFN-output
+ * dropout drawn from `seed` + the context's seed word, the masks amt_forward_backward would draw for the same seed),
+ * logits / probs [B][S][n_events] float32 (either may be NULL).  Uses the training workspace plan. */
+int32_t amt_forward_train(amt_ctx* ctx, const void* audio, int32_t B, int32_t T, uint64_t seed, float* logits,
+                          float* probs, void* stream);
+
 /* Training forward + backward: compute_loss + the gradient half of compute_training_step.
  *   labels     [B][S][n_events] float32
  *   scale      loss scale (reference grad_scale; 1.0 for bf16)
@@ -127,6 +134,19 @@ int32_t amt_forward_backward_phase(amt_ctx* ctx, const void* audio, const float*
                                    float scale, uint64_t seed, int32_t train, float* loss_out, float* grads_flat,
                                    int32_t* grads_valid, float* logits, int32_t phase, void* stream);
 uint64_t amt_grad_bucket_split(const amt_ctx* ctx);
+
+/* Gradient accumulation over minibatches on the device (train.py:275-310: lax.scan over batch / minibatch chunks, fp32
+ * accumulation, grads / (grad_scale * steps), train.py:319): the general form of the two entry points above.
+ *   phase        0 = whole step, 1 / 2 = its halves (as amt_forward_backward_phase)
+ *   accum_index  0 .. accum_count - 1, in order, same grads_flat / grads_valid / loss_out pointers in every call
+ * Call 0 zeroes the context's fp32 accumulator; every call adds its gradients to it (no second buffer, no extra pass);
+ * only the last call writes grads_flat = accumulator / (scale * accum_count), loss_out = mean over the minibatches of
+ * their mean loss, and AND-s grads_valid.  Each call may use its own seed (the reference splits the key per
+ * minibatch, train.py:277).  accum_count == 1 is exactly amt_forward_backward / _phase. */
+int32_t amt_forward_backward_accum(amt_ctx* ctx, const void* audio, const float* labels, int32_t B, int32_t T,
+                                   float scale, uint64_t seed, int32_t train, float* loss_out, float* grads_flat,
+                                   int32_t* grads_valid, float* logits, int32_t phase, int32_t accum_index,
+                                   int32_t accum_count, void* stream);
 
 /* Bytes of activation workspace currently held (diagnostics). */
 uint64_t amt_workspace_bytes(const amt_ctx* ctx);
@@ -173,11 +193,15 @@ int32_t amt_adamw_step(amt_ctx* ctx, const float* grads_flat, float lr_base, flo
  * unless *valid_i32 != 0 (the grads_valid word of amt_forward_backward) and *valid_f32 >= 0.999 (that flag as a float
  * after a mean all-reduce over ranks: 1.0 iff every rank's gradients are finite).  Either pointer may be NULL.
  * This is the skip of train.py:369-377 (the reference rolls back to a copy instead).
- * `step` counts optimizer steps from 1 (optax); step < 1 is an error in both entry points: the bias corrections
- * 1 - b^step would be zero. */
+ * `step` counts optimizer steps from 1 (optax); 0 and values below -1 are errors in both entry points (the bias
+ * corrections 1 - b^step would be zero).  step = -1: the count lives ON THE DEVICE - the context's counter of APPLIED
+ * updates + 1; an update behind an open gate advances it (an explicit step sets it), a skipped one does not, as optax's
+ * count under the reference's roll-back (train.py:369-377).  amt_optimizer_count reads it (host-synchronous). */
 int32_t amt_adamw_step_gated(amt_ctx* ctx, const float* grads_flat, float lr_base, float layer_lr_decay, float b1,
                              float b2, float eps, float weight_decay, float clip_norm, int32_t step,
                              const int32_t* valid_i32, const float* valid_f32, void* stream);
+
+int32_t amt_optimizer_count(amt_ctx* ctx);
 
 /* ---- measurement aid (bench.py roofline leg): per-kernel-class timing with HIP events recorded
  * on the launch stream around every kernel launch.  Process-global; off by default. */

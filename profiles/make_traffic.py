@@ -4,7 +4,12 @@ prescribes) into HBM bytes per launch per bench.py kernel class.
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --profile-steps 0
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python bench.py ... (same)
-  python profiles/make_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic_by_class.json
+  python profiles/make_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic_by_class.json \
+         [kernel_stats.csv of a `rocprofv3 --kernel-trace --stats` run under hipGraph replay]
+
+The output is stamped with `_build_id` (bench.build_id(): sha-256 over csrc/) so that bench.py quotes it only for the
+build it was taken from, and - when the stats CSV is given - carries each class's average launch duration under graph
+replay (`avg_launch_us_graph`) and the CSV's name (`_rocprof_stats`).
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE is in KB and reports exactly half of the
 bytes of wide coalesced reads -> x2; WRITE_SIZE (KB) is exact.  bytes = (2*FETCH + WRITE) * 1024.
@@ -52,14 +57,37 @@ def load(d, counter):
     return acc
 
 
+def graph_durations(stats_csv):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(stats_csv)):
+        c = classify(r["Name"])
+        if c:
+            acc[c][0] += float(r["TotalDurationNs"]); acc[c][1] += int(r["Calls"])
+    return {c: v[0] / v[1] / 1e3 for c, v in acc.items() if v[1]}
+
+
 if __name__ == "__main__":
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     fe, wr = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     out = {}
+    try:
+        import bench
+        out["_build_id"] = bench.build_id()
+    except Exception as e:   # noqa: BLE001
+        out["_build_id"] = None
+        print("warning: no build id:", e, file=sys.stderr)
+    gd = {}
+    if len(sys.argv) > 4:
+        gd = graph_durations(sys.argv[4])
+        out["_rocprof_stats"] = "profiles/" + os.path.basename(sys.argv[4])
     for c in fe:
         if c in wr and fe[c][1] == wr[c][1]:
             n = fe[c][1]
             out[c] = {"launches_sampled": n, "fetch_size_kb_raw_per_launch": fe[c][0] / n,
                       "write_size_kb_per_launch": wr[c][0] / n,
                       "hbm_bytes_per_launch": (2 * fe[c][0] + wr[c][0]) * 1024 / n}
+            if c in gd:
+                out[c]["avg_launch_us_graph"] = round(gd[c], 2)
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))

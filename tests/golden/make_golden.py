@@ -27,6 +27,9 @@ CASES = {
     "reduced_s50": ([1, 1, 1, 1, 1, 2, 1], 2, 50, 2, 7, 3),      # padded local windows (6 pad rows)
     "reduced_s32": ([1, 1, 1, 1, 1, 2, 1], 2, 32, 2, 7, 3),      # pad-free local windows
     "reduced_s250": ([1, 1, 1, 1, 1, 1, 1], 1, 250, 1, 11, 5),   # the reference's 5 s window geometry (31 windows)
+    # round 3: the benchmark shape per clip - full depth (39 Blocks, 16 layers), 10 s = 500 frames (62 local windows,
+    # RoPE rows beyond the reference's 300-row table), one clip; of the stacked attention leaf only layer pair 0 is stored
+    "full_s500": ([3, 3, 3, 3, 3, 21, 3], 8, 500, 1, 1234, 42),
 }
 
 
@@ -59,7 +62,7 @@ def build(name):
     }
     k_attn = [k for k in keys if k.endswith("kv_down_proj.weight")][0]
     out["grad_attn_name"] = np.array(k_attn)
-    out["grad_attn"] = grads[k_attn].astype(np.float32)
+    out["grad_attn"] = (grads[k_attn][:1] if name.startswith("full") else grads[k_attn]).astype(np.float32)
     return out
 
 
@@ -78,8 +81,9 @@ def build_post():
 
 
 if __name__ == "__main__":
-    for name in CASES:
+    for name in (sys.argv[1:] or CASES):
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **build(name))
         print("wrote", name)
-    np.savez_compressed(os.path.join(HERE, "post.npz"), **build_post())
-    print("wrote post")
+    if len(sys.argv) == 1:
+        np.savez_compressed(os.path.join(HERE, "post.npz"), **build_post())
+        print("wrote post")

@@ -22,70 +22,12 @@ def _conf():
     return conf
 
 
-def _oracle_step(conf, params):
-    def step(a, y, scale, seed):
-        loss, _, g = torch_model.loss_and_grads(params, a.numpy(), y.numpy(), conf, scale=scale, dtype=torch.float64)
-        flat = torch.from_numpy(P.equinox_to_flat({k: v / scale for k, v in g.items()}, conf))
-        return loss / scale, loss, flat, True
-    return step
-
-
-def _worker(rank, world, port, q, poison):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.set_num_threads(2)
-    conf = _conf()
-    params = np_model.init_params(conf, seed=3, gamma=1.0)
-    audio, labels = synth.make_batch(4, 320 * 20, seed=9)
-    shard = slice(rank * 2, rank * 2 + 2)
-    bucket = train.new_bucket(P.param_count(conf), "cpu")
-    step = _oracle_step(conf, params)
-    if poison and rank == 1:
-        inner = step
-        step = lambda a, y, s, sd: (lambda o: (o[0], o[1], o[2], False))(inner(a, y, s, sd))
-    loss, scaled, valid = train.compute_training_step(
-        None, torch.from_numpy(audio[shard]), torch.from_numpy(labels[shard]), grad_scale=4.0, seed=1,
-        bucket=bucket, lr_base=0.0, step=1, dist=dist, accum_steps=2, apply_update=False, local_step=step)
-    if rank == 0:
-        q.put((loss, scaled, valid, bucket[:-train.BUCKET_TAIL].numpy().copy()))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
 
 
-@pytest.mark.parametrize("poison", [False, True])
-def test_two_ranks_equal_one_rank(poison):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, poison)) for r in range(2)]
-    for p in procs:
-        p.start()
-    loss, scaled, valid, grads = q.get(timeout=300)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    conf = _conf()
-    params = np_model.init_params(conf, seed=3, gamma=1.0)
-    audio, labels = synth.make_batch(4, 320 * 20, seed=9)
-    ref_loss, _, g = torch_model.loss_and_grads(params, audio, labels, conf)
-    ref = P.equinox_to_flat(g, conf)
-    assert valid == (not poison)
-    assert abs(loss - ref_loss) < 1e-6 * abs(ref_loss) and abs(scaled - 4 * ref_loss) < 1e-5 * abs(ref_loss)
-    assert np.linalg.norm(grads - ref) < 1e-5 * np.linalg.norm(ref)
-
-
-def test_single_process_bucket_and_loss_scale_controller():
-    b = train.new_bucket(5, "cpu")
-    b[:5] = torch.arange(5.0)
-    train.pack_tail(b, 2.5, 10.0, 1.0)
-    g, loss, scaled, valid = train.allreduce_bucket(b, None)
-    assert g.tolist() == [0, 1, 2, 3, 4] and (loss, scaled, valid) == (2.5, 10.0, True)
+def test_loss_scale_controller():
     c = train.LossScaleController(scale=8.0)
     assert c.update(True, 100.0, 800.0) is False and c.scale == 16.0         # scaled_loss < 1e4: double
     assert c.update(True, 100.0, 20000.0) is False and c.scale == 16.0
@@ -95,20 +37,47 @@ def test_single_process_bucket_and_loss_scale_controller():
     assert off.update(True, 1.0, 1.0) is False and off.scale == 1.0
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` typed without a launcher: the process starts the ranks as children
+    through torch.distributed.run BEFORE anything touches a GPU, relays rank 0's JSON line and exits with their code.
+    --dry-run-launcher stops after the rendezvous and one all-reduce on CPU tensors (gloo), so this runs without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-launcher"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["ranks_seen"] == 2 and out["n_gpus"] == 2 and out["allreduce_ok"] is True and out["backend"] == "gloo"
+
+
 # ------------------------------------------------------------------ DataParallelStep (the protocol bench.py runs)
 class _OracleBackend:
     """CPU stand-in for HipTrainBackend: the oracle computes the rank's gradients, the bucket / flag / collective /
     gate logic around it is the production code (audio_to_midi_amd.train.DataParallelStep)."""
 
-    def __init__(self, conf, params, audio, labels, bucket, split, poison=False):
+    def __init__(self, conf, params, audio, labels, bucket, split, poison=False, accum_steps=1):
         self.conf, self.params, self.audio, self.labels = conf, params, audio, labels
         self.bucket, self.split, self.poison = bucket, split, poison
+        self.accum_steps = accum_steps
         self.gates = []
         self._cache = None
 
     def _compute(self):
-        loss, _, g = torch_model.loss_and_grads(self.params, self.audio, self.labels, self.conf, dtype=torch.float64)
-        flat = torch.from_numpy(P.equinox_to_flat(g, self.conf)).to(torch.float32)
+        # train.py:275-310: the rank's batch in `accum_steps` minibatches; gradients summed in fp32, / steps at the end
+        k = self.accum_steps
+        mb = self.audio.shape[0] // k
+        loss, flat = 0.0, None
+        for i in range(k):
+            li, _, g = torch_model.loss_and_grads(self.params, self.audio[i * mb:(i + 1) * mb], self.labels[i * mb:(i + 1) * mb],
+                                                  self.conf, dtype=torch.float64)
+            fi = torch.from_numpy(P.equinox_to_flat(g, self.conf)).to(torch.float32)
+            flat = fi if flat is None else flat + fi
+            loss += li
+        flat, loss = flat / k, loss / k
         if self.poison:
             flat[self.split + 5] = float("nan")      # a non-finite gradient in the first half's range
         return float(loss), flat
@@ -145,7 +114,7 @@ def _split_of(conf):
     return next(s.offset for s in P.device_layout(conf) if s.name == "norm.weight")
 
 
-def _dp_worker(rank, world, port, q, poison, overlap):
+def _dp_worker(rank, world, port, q, poison, overlap, accum=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -156,7 +125,7 @@ def _dp_worker(rank, world, port, q, poison, overlap):
     shard = slice(rank * 2, rank * 2 + 2)
     bucket = train.GradBucket(P.param_count(conf), "cpu")
     split = _split_of(conf)
-    be = _OracleBackend(conf, params, audio[shard], labels[shard], bucket, split, poison=poison and rank == 1)
+    be = _OracleBackend(conf, params, audio[shard], labels[shard], bucket, split, poison=poison and rank == 1, accum_steps=accum)
     dp = train.DataParallelStep(be, bucket, split, dist=dist, overlap=overlap, graph=True)   # graph is ignored on CPU
     dp.prepare(seed=0)
     dp.step()
@@ -166,15 +135,16 @@ def _dp_worker(rank, world, port, q, poison, overlap):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("overlap,accum", [(False, 1), (True, 1), (False, 2)])
 @pytest.mark.parametrize("poison", [False, True])
-def test_data_parallel_step_two_ranks_equal_one_rank(poison, overlap):
+def test_data_parallel_step_two_ranks_equal_one_rank(poison, overlap, accum):
     """N-rank gradients == 1-rank gradients on the global batch, for the one-collective and the two-collective
-    (overlap) form; the finite flags AND across ranks and close the optimizer gate on EVERY rank."""
+    (overlap) form and with the rank's shard accumulated over two minibatches (train.py:275-310); the finite flags AND
+    across ranks and close the optimizer gate on EVERY rank."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, poison, overlap)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, poison, overlap, accum)) for r in range(2)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=300) for _ in range(2)], key=lambda o: o[0])

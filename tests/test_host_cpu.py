@@ -146,6 +146,42 @@ def test_checkpoint_leaves_are_validated_and_the_ensemble_axis_is_handled(tmp_pa
     assert np.array_equal(convert_orbax.leaves_to_flat(leaves, conf, ensemble_select=1), 3 * flat)
     back = convert_orbax.flat_to_leaves(flat, conf)
     assert all(back[k].shape == (1,) + p[k].shape and np.array_equal(back[k][0], p[k]) for k in p)
+    # the reference's REAL path structure.  OutputSequenceGenerator.layers is a list of eqx.nn.Sequential
+    # (model.py:674, 704-710) whose modules sit in an inner `.layers` tuple: layers[s].layers[j].point_conv_1.weight
+    # (train.py:650-653 reads path[1].idx and path[3].idx).  A tree built with that level must convert to the same
+    # flat vector, the name mapping must be a bijection, and an unknown model leaf must raise instead of being dropped.
+    ref_tree = {"layers": []}
+    for s in range(len(conf["dims"])):
+        mods = []
+        for j in range(conf["depths"][s] + 1):
+            node = {}
+            for name, v in ens.items():
+                pre = f"layers.{s}.{j}."
+                if name.startswith(pre):
+                    cur = node
+                    parts = name[len(pre):].split(".")
+                    for q in parts[:-1]:
+                        cur = cur.setdefault(q, {})
+                    cur[parts[-1]] = v
+            mods.append(node)
+        ref_tree["layers"].append({"layers": tuple(mods)})
+    for name, v in ens.items():
+        if not name.startswith("layers."):
+            cur = ref_tree
+            parts = name.split(".")
+            for q in parts[:-1]:
+                cur = cur.setdefault(q, {})
+            cur[parts[-1]] = v
+    ref_leaves = convert_orbax.flatten_tree(ref_tree)
+    assert "layers.5.layers.1.point_conv_1.weight" in ref_leaves and "layers.5.1.point_conv_1.weight" not in ref_leaves
+    assert {convert_orbax.canonical_name(k) for k in ref_leaves} == set(p)
+    assert all(convert_orbax.reference_name(convert_orbax.canonical_name(k)) == k for k in ref_leaves)
+    assert np.array_equal(convert_orbax.leaves_to_flat(ref_leaves, conf, ensemble_select=1), 3 * flat)
+    stray = dict(ref_leaves); stray["layers.5.layers.1.point_conv_3.weight"] = np.zeros((2, 1))
+    with pytest.raises(KeyError, match="parameter inventory"):
+        convert_orbax.leaves_to_flat(stray, conf, ensemble_select=0)
+    ok_extra = dict(ref_leaves); ok_extra["state.unused"] = np.zeros(1)          # outside the model: ignored
+    assert np.array_equal(convert_orbax.leaves_to_flat(ok_extra, conf, ensemble_select=0), flat)
     # flat file round trip
     infer.save_checkpoint(str(tmp_path), flat, conf, step=7)
     f2, c2, s2 = infer.load_checkpoint(str(tmp_path))

@@ -1,0 +1,129 @@
+"""Round 3: the rest of the training-step surface through the C ABI.
+
+  * gradient accumulation over minibatches on the device   (train.py:275-310)  amt_forward_backward_accum
+  * train-mode forward through the reference's call        (model.py:740-769)  amt_forward_train
+  * optimizer count that skipped steps do not advance      (train.py:369-377)  amt_adamw_step_gated(step = -1)
+  * a non-finite loss closes the bucket flags              (train.py:369)      amt_pack_tail
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import audio_to_midi_amd as amt  # noqa: E402
+from audio_to_midi_amd import synth, train  # noqa: E402
+from oracle import np_model, torch_model  # noqa: E402
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_accumulated_minibatches_equal_one_batch(small_conf, dtype):
+    """k minibatches accumulated on the device == one batch of all their clips (mean of means of equal-sized groups), and
+    == the float64 oracle on the whole batch; nothing reaches the caller's buffer before the last minibatch."""
+    params = np_model.init_params(small_conf, seed=5, gamma=1.0)
+    audio, labels = synth.make_batch(6, 320 * 40, seed=8)
+    a, y = torch.from_numpy(audio), torch.from_numpy(labels)
+    model = amt.OutputSequenceGenerator(small_conf, dtype=dtype)
+    model.load_equinox_params(params)
+    whole = model.loss_and_grads(a, y, scale=4.0, train=False)
+    g = torch.full((model.n_params,), 9.0, dtype=torch.float32, device="cuda")
+    loss = torch.full((2,), -1.0, device="cuda")
+    valid = torch.zeros(1, dtype=torch.int32, device="cuda")
+    k = 3
+    for i in range(k):
+        out = model.loss_and_grads(a[2 * i:2 * i + 2], y[2 * i:2 * i + 2], scale=4.0, train=False, grads_out=g, accum=(i, k),
+                                   loss_out=loss, valid_out=valid)
+        if i < k - 1:
+            torch.cuda.synchronize()
+            assert float((g - 9.0).abs().max()) == 0.0 and float(loss[0]) == -1.0      # untouched until the last one
+    assert out.grads_valid
+    tol = 1e-5 if dtype == "float32" else 2e-2      # bf16: d logits are scaled by 1 / minibatch size before they are rounded
+    assert abs(out.loss - whole.loss) <= 1e-5 * abs(whole.loss) and abs(out.scaled_loss - 4 * whole.loss) <= 1e-4 * abs(whole.loss)
+    assert float((out.grads_flat - whole.grads_flat).norm() / whole.grads_flat.norm()) < tol
+    if dtype == "float32":
+        loss_ref, _, grads_ref = torch_model.loss_and_grads(params, audio, labels, small_conf)
+        got = model.grads_to_equinox(out.grads_flat.cpu().numpy())
+        worst = max(np.linalg.norm(got[n] - r) / (np.linalg.norm(r) + 1e-30) for n, r in grads_ref.items()
+                    if np.linalg.norm(r) > 1e-3 * max(np.linalg.norm(v) for v in grads_ref.values()))
+        assert abs(out.loss - loss_ref) <= 1e-5 * abs(loss_ref) and worst < 2e-3, worst
+    with pytest.raises(RuntimeError):
+        model.loss_and_grads(a[:2], y[:2], accum=(3, 3))
+
+
+def test_data_parallel_step_accumulates_on_the_device(small_conf):
+    """DataParallelStep over a HipTrainBackend with accum_steps = 2 (eager and as a replayed hipGraph, one- and two-phase
+    form): the bucket holds the gradients of the whole rank batch; dropout seeds differ per minibatch."""
+    model = amt.OutputSequenceGenerator(small_conf, key=9, dtype="bfloat16", gamma=1.0)
+    audio, labels = synth.make_batch(4, 320 * 48, seed=3)
+    a, y = torch.from_numpy(audio).to("cuda", torch.bfloat16), torch.from_numpy(labels).cuda()
+    ref = []
+    for i in range(2):      # what the step must produce with seed s: minibatch i with seed s + i, summed / 2
+        ref.append(model.loss_and_grads(a[2 * i:2 * i + 2], y[2 * i:2 * i + 2], seed=50 + i, train=True))
+    g_ref = (ref[0].grads_flat + ref[1].grads_flat) / 2
+    l_ref = (ref[0].loss + ref[1].loss) / 2
+    for overlap in (False, True):
+        bucket = train.GradBucket(model.n_params, "cuda")
+        be = train.HipTrainBackend(model, a, y, bucket, use_optimizer=False, accum_steps=2)
+        dp = train.DataParallelStep(be, bucket, be.split, dist=None, overlap=overlap, graph=False)
+        dp.prepare(seed=50)
+        model.seed_word().zero_()
+        dp.step(seed=50)
+        loss, valid = dp.result()
+        assert valid and abs(loss - l_ref) <= 1e-5 * abs(l_ref)
+        assert float((bucket.grads - g_ref).norm() / g_ref.norm()) < 2e-2, overlap
+
+
+def test_train_mode_forward_is_the_forward_of_the_training_step(small_conf):
+    """OutputSequenceGenerator.__call__(..., enable_dropout=True) (model.py:740-769; compute_loss calls it at
+    train.py:56-58): the logits are bit for bit the ones the training step computes its loss from for the same key,
+    they differ from the inference logits, another key gives other masks, and inference ignores the key."""
+    model = amt.OutputSequenceGenerator(small_conf, key=2, dtype="bfloat16", gamma=1.0)
+    audio, labels = synth.make_batch(2, 320 * 64, seed=1)
+    a, y = torch.from_numpy(audio), torch.from_numpy(labels)
+    (lt, pt), state = model(a, None, None, key=77, enable_dropout=True)
+    step = model.loss_and_grads(a, y, seed=77, train=True, return_logits=True)
+    assert torch.equal(lt, step.logits) and state is None
+    assert torch.allclose(pt, torch.sigmoid(lt), atol=1e-6)
+    (li, _), _ = model(a, None, None, key=77, enable_dropout=False)
+    assert not torch.equal(li, lt) and torch.equal(li, model.predict(None, a)[0])
+    (lt2, _), _ = model(a, None, None, key=78, enable_dropout=True)
+    assert not torch.equal(lt2, lt)
+    z = lt.double()
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(z, y.cuda().double(), reduction="sum") / 2
+    assert abs(float(bce) - step.loss) <= 1e-4 * abs(step.loss)
+
+
+def test_optimizer_count_lives_on_the_device_and_skipped_steps_do_not_advance_it(small_conf):
+    """with step = -1 the bias corrections use the device count of APPLIED updates.  open, skipped, open must
+    equal two explicit steps 1, 2 on a twin model (a host count would have used 1, 3)."""
+    model = amt.OutputSequenceGenerator(small_conf, key=5, dtype="float32", gamma=1.0)
+    twin = amt.OutputSequenceGenerator(small_conf, key=5, dtype="float32", gamma=1.0)
+    model.init_optimizer(); twin.init_optimizer()
+    rng = np.random.default_rng(0)
+    g1 = torch.from_numpy((rng.standard_normal(model.n_params) * 1e-2).astype(np.float32)).cuda()
+    g2 = torch.from_numpy((rng.standard_normal(model.n_params) * 1e-2).astype(np.float32)).cuda()
+    opened, closed = torch.tensor([1.0], device="cuda"), torch.tensor([0.5], device="cuda")
+    assert model.optimizer_count() == 0
+    model.adamw_step(g1, lr_base=1e-3, step=-1, valid_mean=opened)
+    assert model.optimizer_count() == 1
+    p1 = model.weights_tensor().clone()
+    model.adamw_step(g2, lr_base=1e-3, step=-1, valid_mean=closed)          # non-finite somewhere: skipped
+    assert model.optimizer_count() == 1 and torch.equal(model.weights_tensor(), p1)
+    model.adamw_step(g2, lr_base=1e-3, step=-1, valid_mean=opened)
+    assert model.optimizer_count() == 2
+    twin.adamw_step(g1, lr_base=1e-3, step=1)
+    twin.adamw_step(g2, lr_base=1e-3, step=2)
+    assert twin.optimizer_count() == 2
+    assert float((model.weights_tensor() - twin.weights_tensor()).abs().max()) < 5e-7      # norm^2 is an atomic sum: last bits
+    with pytest.raises(RuntimeError):
+        model.adamw_step(g1, lr_base=1e-3, step=-2)
+
+
+def test_non_finite_loss_closes_the_bucket_flags(small_conf):
+    model = amt.OutputSequenceGenerator(small_conf, key=5, dtype="float32", gamma=1.0)
+    one = torch.ones(1, dtype=torch.int32, device="cuda")
+    buf = torch.full((4,), -1.0, device="cuda")
+    for lv, want in ((2.5, 1.0), (float("nan"), 0.0), (float("inf"), 0.0)):
+        model.pack_tail(torch.tensor([lv, 0.0], device="cuda"), one, head_valid=buf[0:1], tail_loss=buf[1:2], tail_valid=buf[2:3])
+        torch.cuda.synchronize()
+        assert float(buf[0]) == want and float(buf[2]) == want

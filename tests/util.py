@@ -92,3 +92,36 @@ def rng_u32(seed, stream_id, idx):
 def keep_mask(seed, stream_id, idx, p):
     thr = int(np.rint(np.float32(p) * np.float32(16777216.0)))
     return ((rng_u32(seed, stream_id, idx) >> np.uint32(8)) >= np.uint32(thr)).astype(np.float64), 1.0 - thr / 16777216.0
+
+
+def dropout_masks_for(seed, conf, B, S, n_heads=4):
+    """The device's dropout masks of one training step rebuilt on the host, in the form oracle/torch_model.py takes:
+    per layer dict(attn = keep mask of the attention weights, ffn = keep mask of the FFN output, keep = keep
+    probability).  Streams: 2 * layer for the attention weights, 2 * layer + 1 for the FFN output; element index =
+    flat index of [B][H][nwin][16][16] (local layers), [B][H][S][S] (global layers), [B][S][256] (FFN); csrc/common.h."""
+    import torch
+    from oracle import np_model
+    p = conf["transformer_dropout_rate"]
+    _, _, nwin, _ = np_model.local_window_geometry(S)
+    H = n_heads
+    masks = []
+    for li in range(2 * conf["num_transformer_layers"]):
+        if li % 2 == 0:
+            k_, kp = keep_mask(seed, 2 * li, np.arange(B * H * nwin * 256).reshape(B, H, nwin, 16, 16), p)
+            attn = torch.tensor(k_).permute(0, 2, 1, 3, 4)
+        else:
+            k_, kp = keep_mask(seed, 2 * li, np.arange(B * H * S * S).reshape(B, H, S, S), p)
+            attn = torch.tensor(k_)
+        f_, _ = keep_mask(seed, 2 * li + 1, np.arange(B * S * 256).reshape(B, S, 256), p)
+        masks.append(dict(attn=attn, ffn=torch.tensor(f_), keep=kp))
+    return masks
+
+
+def bf16_round_gemm_weights(params):
+    """The parameters a bf16 context computes with: GEMM weights (2-D and higher, except norms, biases, gamma, the
+    depthwise taps and the stem conv, which the kernels read in fp32) rounded to bf16; for the oracle side of a bf16
+    comparison, so that the comparison measures the arithmetic and not the weight rounding."""
+    import torch
+    return {k: torch.tensor(v).to(torch.bfloat16).to(torch.float64).numpy() if v.ndim >= 2 and "norm" not in k
+            and "bias" not in k and "gamma" not in k and "depth_conv" not in k and k != "layers.0.0.conv.weight"
+            else v for k, v in params.items()}
