@@ -355,9 +355,16 @@ __global__ __launch_bounds__(256 * NG) void block_run_fwd_kernel(BlockRunFwdArgs
   team_leave(r.st, t);
 }
 
-template <typename T, int C, bool SAVE>
-static void block_fwd_fused_launch(hipStream_t s, const BlockFwdArgs& a) {
-  constexpr int TT = BlockTile<C>::TT * (SAVE ? 1 : (sizeof(T) == 4 || C == 256 ? 2 : 4));
+// Inference tile length.  A chain workgroup streams the Block's 4 C^2 weight elements once per TILE, so the flops per
+// weight byte it pulls from L2 equal the tile length: at ~28 B/clk per compute unit (profiles/r01_notes.md) the MFMA
+// pipes are fed only from ~128 tokens per tile on (4096 / TT B/clk at the full MFMA rate).  The longest tile whose
+// panels fit LDS: 128 tokens at C = 128 (137 KiB), 256 at C = 64; AMT_BLOCK_INF_LONG=0 restores round 2's 64 / 128.
+template <int C, typename T> struct BlockInferTile {
+  static constexpr int SHORT = BlockTile<C>::TT * (sizeof(T) == 4 || C == 256 ? 2 : 4);
+  static constexpr int LONG = (C == 128 || C == 64) ? 2 * SHORT : SHORT;
+};
+template <typename T, int C, bool SAVE, int TT>
+static void block_fwd_fused_launch_tt(hipStream_t s, const BlockFwdArgs& a) {
   constexpr size_t lds = sizeof(T) * (size_t)TT * (2 * (C + 8) + (SAVE ? 2 : 1) * (2 * C + 8));
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool once = (lds > 64 * 1024
@@ -369,6 +376,18 @@ static void block_fwd_fused_launch(hipStream_t s, const BlockFwdArgs& a) {
   const long N = (long)a.B * a.L;
   const int grid = (int)((N + TT - 1) / TT);
   hipLaunchKernelGGL((block_fwd_fused_kernel<T, C, TT, SAVE>), dim3(grid), dim3(256), lds, s, a);
+}
+template <typename T, int C, bool SAVE>
+static void block_fwd_fused_launch(hipStream_t s, const BlockFwdArgs& a) {
+  if constexpr (SAVE) {
+    block_fwd_fused_launch_tt<T, C, true, BlockTile<C>::TT>(s, a);
+  } else {
+    using IT = BlockInferTile<C, T>;
+    static const bool long_tiles = !(getenv("AMT_BLOCK_INF_LONG") && atoi(getenv("AMT_BLOCK_INF_LONG")) == 0);
+    // short clips (few tiles per compute unit) keep the short tile: the long one would leave compute units idle
+    if (IT::LONG != IT::SHORT && long_tiles && (long)a.B * a.L >= 256L * IT::LONG) block_fwd_fused_launch_tt<T, C, false, IT::LONG>(s, a);
+    else block_fwd_fused_launch_tt<T, C, false, IT::SHORT>(s, a);
+  }
 }
 
 static int team_grid() {   // one workgroup per compute unit, on the full 8-XCD chip only
@@ -1124,7 +1143,7 @@ AMT_DEV void qkv_fwd_body(const QkvFwdArgs& a, unsigned char* chain_smem, const 
   chain_load_w<T, SK::RB, KCK, CK>(wk, Wk, mK, 0, lane);
   __syncthreads();
   AMT_STAMP(2);
-  chain_copy_out<T, TT, H, LDX>(Xs, reinterpret_cast<T*>(a.XN), n0, N, tid);
+  if (a.XN != nullptr) chain_copy_out<T, TT, H, LDX>(Xs, reinterpret_cast<T*>(a.XN), n0, N, tid);   // (inference passes none)
 
   // ---- qc = xn . Wqc^T
   {

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const T* __restrict__ aud
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { c[i] -= mu; q += c[i] * c[i]; }
-  float rs = 1.f / sqrtf(0.25f * q + kLnEps);
+  float rs = __builtin_amdgcn_rsqf(0.25f * q + kLnEps);
   float y[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) y[i] = c[i] * rs * lnw[i] + lnb[i];
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const T* __restrict__ aud
       float q = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) { c[i] -= mu; q += c[i] * c[i]; }
-      float rs = 1.f / sqrtf(0.25f * q + kLnEps);
+      float rs = __builtin_amdgcn_rsqf(0.25f * q + kLnEps);
       float s1 = 0.f, s2 = 0.f, gy[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void block_small_fwd_kernel(
     float q = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) { d[c] -= mu; q += d[c] * d[c]; }
-    const float rs = 1.f / sqrtf(q * (1.f / C) + kLnEps);
+    const float rs = __builtin_amdgcn_rsqf(q * (1.f / C) + kLnEps);
     float ln[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) ln[c] = to_f(from_f<T>(d[c] * rs * slw[wz + c] + slb[wz + c]));

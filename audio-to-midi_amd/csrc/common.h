@@ -174,20 +174,25 @@ AMT_DEV void mma(f32x4& acc, const Frag<float>& a, const Frag<float>& b) {
 }
 
 // ------------------------------------------------------------------ math
-// 0.5 x (1 + tanh(u)) == x * sigmoid(2u): one v_exp_f32 and one reciprocal instead of libm's tanhf
-// (~16 of them per lane cost 1.5-2 us in every GELU epilogue).  |error| ~1e-6 relative in fp32.
+// jax.nn.gelu default (approximate=True): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3), written as
+// x * sigmoid(2u) = x / (1 + exp(-2u)) with exp(-2u) = exp2(x (c0 + c1 x^2)): SEVEN instructions (mul, fma, mul, v_exp_f32,
+// add, v_rcp_f32, mul).  Round 2's form (separate constant multiplies, __expf, and __frcp_rn = a correctly rounded
+// division: v_div_scale x 2, v_rcp, four fma, v_div_fmas, v_div_fixup) compiled to 22 and made every GELU / GLU epilogue
+// VALU-bound: 57 million evaluations per launch at streaming-inference sizes, 891 of the ~1100 vector instructions
+// between two MFMA stages of the FFN chain (in-kernel stamps, profiles/r03_notes.md).  v_exp_f32 and v_rcp_f32 are
+// accurate to 1 ulp, the whole expression to ~4e-7 relative: inside the fp32 tolerance against the float64 oracle (2e-5).
+constexpr float GELU_C0 = -2.f * 0.7978845608028654f * 1.4426950408889634f;   // -2 sqrt(2/pi) log2(e)
+constexpr float GELU_C1 = GELU_C0 * 0.044715f;
 AMT_DEV float gelu_tanh(float x) {
-  // jax.nn.gelu default (approximate=True): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  return x * __frcp_rn(1.f + __expf(-2.f * u));
+  const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, GELU_C1, GELU_C0));   // exp(-2u); inf for x << 0
+  return x * __builtin_amdgcn_rcpf(1.f + e);
 }
 AMT_DEV float gelu_tanh_grad(float x) {
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  float s = __frcp_rn(1.f + __expf(-2.f * u));           // (1 + tanh u) / 2
-  float du = k0 * (1.f + 3.f * k1 * x * x);
-  return s + 2.f * x * s * (1.f - s) * du;                // 1 - tanh^2 u = 4 s (1 - s)
+  const float t = x * x;
+  const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(t, GELU_C1, GELU_C0));
+  const float s = __builtin_amdgcn_rcpf(1.f + e);                       // (1 + tanh u) / 2
+  const float du2 = __builtin_fmaf(t, 6.f * 0.7978845608028654f * 0.044715f, 2.f * 0.7978845608028654f);   // 2 du/dx
+  return __builtin_fmaf(x * s * (1.f - s), du2, s);                     // s + 2 x s (1 - s) du/dx
 }
 AMT_DEV float sigmoidf(float z) { return 1.f / (1.f + __expf(-z)); }
 

@@ -220,6 +220,9 @@ struct FfnFwdArgs {
   int dbg_slot;
 };
 void ffn_fwd_fused(hipStream_t s, DType dt, const FfnFwdArgs& a);
+// Large-N form (chain_big.hip): 128-token tiles, FFN hidden dimension in slices, same results bit for bit.  save = false
+// (inference) writes nothing but Y.  false: not served (N < 8192 tokens, attention-output-only form, AMT_BIG=0).
+bool ffn_fwd_big(hipStream_t s, DType dt, const FfnFwdArgs& a, bool save);
 
 // First half of a transformer layer forward up to the attention core, in one launch (model.py:539,
 // 300-334, 353-357; H = 256, 4 heads x 64, kv_compress 64):

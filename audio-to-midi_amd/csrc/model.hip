@@ -601,7 +601,8 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
       QkvFwdArgs qa;
       memset(&qa, 0, sizeof(qa));
       qa.X = x; qa.ln_w = c->P(q.ln1_w); qa.ln_b = c->P(q.ln1_b); qa.Wqc = c->WC(q.c_wqcp); qa.Wkv = c->WC(q.c_wkvp);
-      qa.XN = t.xn; qa.mean = t.m1; qa.rstd = t.r1; qa.QC = t.qc; qa.KV = t.kv; qa.N = N; qa.dbg_slot = 96 + (int)l;
+      qa.XN = save ? t.xn : nullptr;        // LN1(x) is an operand of the backward pass only
+      qa.mean = t.m1; qa.rstd = t.r1; qa.QC = t.qc; qa.KV = t.kv; qa.N = N; qa.dbg_slot = 96 + (int)l;
       return qa;
     };
     if (qkv_done) {
@@ -653,7 +654,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
           }
           qkv_done = true;
         } else {
-          RUN(ffn_fwd_fused(s, dt, fa));
+          RUN(if (!ffn_fwd_big(s, dt, fa, save)) ffn_fwd_fused(s, dt, fa));
         }
         cur = y;
         continue;

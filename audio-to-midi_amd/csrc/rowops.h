@@ -103,7 +103,9 @@ AMT_DEV void ln_stats(float (&x)[VEC], float& mu, float& rs) {
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { x[i] = __fsub_rn(x[i], mu); q = __fmaf_rn(x[i], x[i], q); }
-  rs = 1.f / sqrtf(__fadd_rn(__fmul_rn(group_sum<LPR>(q), 1.f / C), kLnEps));
+  // v_rsq_f32 (1 ulp) instead of 1.f / sqrtf(): a correctly rounded square root followed by a correctly rounded division
+  // is ~25 instructions per row pass, in every lane; every kernel takes its rstd from here, so the bits stay consistent
+  rs = __builtin_amdgcn_rsqf(__fadd_rn(__fmul_rn(group_sum<LPR>(q), 1.f / C), kLnEps));
 }
 // (x - mean) * rstd * w + b
 AMT_DEV float ln_apply(float d, float rs, float w, float b) { return __fmaf_rn(__fmul_rn(d, rs), w, b); }

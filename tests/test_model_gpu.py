@@ -554,3 +554,27 @@ def test_adamw_steps_match_the_optimizer_oracle(small_conf):
                         tail_loss=buf[5:6], tail_valid=buf[6:7])
         torch.cuda.synchronize()
         assert buf.tolist() == [want, -1.0, -1.0, -1.0, -1.0, 3.25, want, -1.0]
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_large_n_chains_equal_the_short_tile_chains(small_conf, dtype, monkeypatch):
+    """csrc/chain_big.hip (round 3): from 8192 tokens on the forward chains run 128-token tiles (64 in f32) with the hidden
+    dimension in slices.  Every product keeps the unfused K order and every rounding its place, so inference logits,
+    training logits, loss and - up to the atomic summation order of the weight gradients - gradients equal the short-tile
+    chains' (AMT_BIG=0) bit for bit, ragged last tile included (41 clips x 250 frames = 10 250 tokens = 80 tiles + 10)."""
+    conf = dict(small_conf)
+    audio, labels = synth.make_batch(41, 80000, seed=12)
+    a, y = torch.from_numpy(audio), torch.from_numpy(labels)
+    outs = {}
+    for big in ("1", "0"):
+        monkeypatch.setenv("AMT_BIG", big)
+        model = amt.OutputSequenceGenerator(conf, key=31, dtype=dtype, gamma=1.0)
+        logits, _ = model.predict(None, a)
+        step = model.loss_and_grads(a, y, seed=7, train=True, return_logits=True)
+        outs[big] = (logits.clone(), step.logits.clone(), step.loss, step.grads_flat.clone())
+        model.close()
+    assert torch.equal(outs["1"][0], outs["0"][0])
+    assert torch.equal(outs["1"][1], outs["0"][1])
+    assert abs(outs["1"][2] - outs["0"][2]) <= 1e-6 * abs(outs["0"][2])
+    rel = float((outs["1"][3] - outs["0"][3]).norm() / outs["0"][3].norm())
+    assert rel < (1e-5 if dtype == "float32" else 1e-3), rel

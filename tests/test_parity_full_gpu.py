@@ -120,25 +120,33 @@ def _margin_mixed_track(st_ref, st_dev, m):
     """The track extract_events is run on for the reference side of a margin-filtered comparison (events are
     bit-exact "on tracks whose probabilities keep a margin from the thresholds").  A cell takes the DEVICE's value where
     a decision of common.rs:47-144 that reads it is not robust against a perturbation of m per cell, the oracle's value
-    everywhere else:
-      * thresholds 0.1 / 0.4 / 0.5 (common.rs:51-54):                  |p - t| <= m
-      * "still rising" p[f] < p[f + 1] (common.rs:111):                |p[f] - p[f + 1]| <= 2 m      -> both cells
-      * re-attack mean(p[f .. f+6)) - mean(p[f-6 .. f)) > 0.1 (:96-108): |difference - 0.1| <= 2 m   -> all 12 cells
-    Decisions that read only unflagged cells come out the same on both tracks whenever |device - oracle| <= m."""
+    everywhere else.  With p = oracle probability, d[f] = mean(p[f .. f+6)) - mean(p[f-6 .. f)):
+      * thresholds 0.1 / 0.4 / 0.5 (common.rs:51-54):           |p - t| <= m
+      * re-attack test d > 0.1 (common.rs:96-108), which can only fire where p[f] > 0.4:
+                                                                 |d - 0.1| <= 2 m and p[f] > 0.4 - m   -> the 12 cells of the two windows
+      * "still rising" p[f] < p[f+1] (common.rs:111), which only gates a re-attack:
+                                 |p[f] - p[f+1]| <= 2 m and d > 0.1 - 2 m and p[f] > 0.4 - m          -> both cells
+    Every decision that reads only unflagged cells comes out the same on both tracks whenever |device - oracle| <= m in
+    every cell; a flagged decision reads device values only.  (The activation probability, common.rs:68-84, never
+    reaches an event: the velocity is the constant 7.)"""
     F, K = st_ref.shape
+    p = st_ref.astype(np.float64)
     near = np.zeros((F, K), dtype=bool)
     for t in (0.5, 0.4, 0.1):
-        near |= np.abs(st_ref - t) <= m
-    tie = np.abs(st_ref[:-1] - st_ref[1:]) <= 2 * m
-    near[:-1] |= tie
-    near[1:] |= tie
-    c = np.concatenate([np.zeros((1, K)), np.cumsum(st_ref.astype(np.float64), axis=0)])
+        near |= np.abs(p - t) <= m
+    c = np.concatenate([np.zeros((1, K)), np.cumsum(p, axis=0)])
+    d = np.full((F, K), -np.inf)
     for f in range(6, F):
         hi = min(f + 6, F)
-        d = (c[hi] - c[f]) / 6.0 - (c[f] - c[f - 6]) / 6.0          # /6 also at the end of the track, as common.rs does
-        flag = np.abs(d - 0.1) <= 2 * m
-        if flag.any():
-            near[f - 6:hi, flag] = True
+        d[f] = (c[hi] - c[f]) / 6.0 - (c[f] - c[f - 6]) / 6.0       # / 6 also at the end of the track, as common.rs does
+    can_fire = p > 0.4 - m
+    win = (np.abs(d - 0.1) <= 2 * m) & can_fire
+    for f in np.nonzero(win.any(axis=1))[0]:
+        near[f - 6:min(f + 6, F), win[f]] = True
+    tie = np.zeros((F, K), dtype=bool)
+    tie[:-1] = (np.abs(p[:-1] - p[1:]) <= 2 * m) & (d[:-1] > 0.1 - 2 * m) & can_fire[:-1]
+    near |= tie
+    near[1:] |= tie[:-1]
     return np.where(near, st_dev, st_ref), near
 
 
@@ -179,5 +187,9 @@ def test_bf16_events_are_bit_exact_outside_the_bf16_margin(tmp_path, head_bias):
     ev_ref = opost.extract_events(st_ref)
     common = len(set(events) & set(ev_ref))
     assert common >= 0.9 * max(len(ev_ref), len(events)), (common, len(ev_ref), len(events))
-    # how much of the track is decided by the oracle alone (reported in DESIGN.md; a weak bound here)
-    assert near.mean() < (0.9 if head_bias == 0.0 else 0.6), near.mean()
+    # how much of the track is decided by the oracle alone (the numbers are in DESIGN.md; a weak bound here)
+    print(f"bf16 events, head bias {head_bias}: margin {m:.3e}, cells within the margin {near.mean():.3f}, events {len(events)} "
+          f"(oracle {len(ev_ref)}, identical without any filter {common})")
+    # measured: 75 % of the cells of the dense track (every key flickers around the thresholds) and 18 % of the sparse one
+    # sit inside the margin of some decision
+    assert near.mean() < (0.85 if head_bias == 0.0 else 0.3), near.mean()
