@@ -122,7 +122,9 @@ AMT_DEV void block_fwd_tile(const BlockFwdArgs& a_in, const long n0, const long 
   // kernel past 256 registers = one wave per SIMD, and such launches paid ~6 us more between
   // dependent kernels in the training step (profiles/r01_notes.md).
   uint32_t warm = 0;   // cooperative L2 warm-up (chain.h); the team form requests the weights one Block ahead instead
-  if constexpr (C >= 128 && !TEAM) {
+  // (SAVE only: the long inference grids find the weights in L2 from their second round of tiles on, and the six
+  // serial round trips of the warm-up stood in front of EVERY tile: ~9 of 32 thousand cycles per tile at 224 000 positions)
+  if constexpr (C >= 128 && !TEAM && SAVE) {
     const int q = blockIdx.x >> 3, ns = max(1, (int)(gridDim.x >> 3));
     constexpr size_t WBYTES = chain_packed_elems(H2, C) * sizeof(T);
     constexpr int MAXLD = (int)((WBYTES + 8 * 4096 - 1) / (8 * 4096)) + 1;
@@ -151,31 +153,46 @@ AMT_DEV void block_fwd_tile(const BlockFwdArgs& a_in, const long n0, const long 
 #pragma unroll
       for (int k = 0; k < 7; ++k) wk[k][i] = a.wdw[k * C + sub * 8 + i];
     }
+    constexpr int NPASS = TT / RPP;
+    // The seven tap rows of pass pp + 1 are requested before pass pp is evaluated (raw chunks, converted at their use):
+    // one pass after the other, each pass waited for its own seven loads - eight L2 round trips in series per 128-row
+    // inference tile (found in the ISA: `s_waitcnt vmcnt(0)` in front of every pass).
+    Chunk8<T> xa[7], xb[7];
+    auto issue = [&](int pp, Chunk8<T> (&xc)[7]) {
+      const long row = n0 + pp * RPP + prow;
+      const long rc = row < N ? row : N - 1;
+      const int b = (int)(rc / a.L), l = (int)(rc % a.L);
+      const long rowbase = (long)b * a.L;
 #pragma unroll
-    for (int pp = 0; pp < TT / RPP; ++pp) {
+      for (int k = 0; k < 7; ++k) {
+        const int ll = l + k - 3;
+        const int lc = ll < 0 ? 0 : (ll >= a.L ? a.L - 1 : ll);
+        if constexpr (TEAM) {
+          float t[8];
+          team_load8f<TEAM>(xrs, X, (rowbase + lc) * C + sub * 8, t);
+          store8f(reinterpret_cast<T*>(&xc[k]), t);
+        } else {
+          xc[k] = chunk_load(X + (rowbase + lc) * C + sub * 8);
+        }
+      }
+    };
+    auto evaluate = [&](int pp, const Chunk8<T> (&xc)[7]) {
       const int p = pp * RPP + prow;
       const long row = n0 + p;
       const bool valid = row < N;
       const long rc = valid ? row : N - 1;
-      const int b = (int)(rc / a.L), l = (int)(rc % a.L);
-      const long rowbase = (long)b * a.L;
-      float x[7][8], d[8];
-#pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        int ll = l + k - 3;
-        int lc = ll < 0 ? 0 : (ll >= a.L ? a.L - 1 : ll);
-        team_load8f<TEAM>(xrs, X, (rowbase + lc) * C + sub * 8, x[k]);
-      }
+      const int l = (int)(rc % a.L);
+      float d[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) d[i] = bv[i];
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
-        int ll = l + k - 3;
-        float m = (ll >= 0 && ll < a.L) ? 1.f : 0.f;
+        const int ll = l + k - 3;
+        const float m = (ll >= 0 && ll < a.L) ? 1.f : 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) d[i] += wk[k][i] * (x[k][i] * m);
+        for (int i = 0; i < 8; ++i) d[i] += wk[k][i] * (chunk_get(xc[k], i) * m);
       }
-      store8f(Rs + p * LDX + sub * 8, x[3]);
+      chunk_store(Rs + p * LDX + sub * 8, xc[3]);
       float mu, rs;
       ln_stats<8, LPR>(d, mu, rs);
       float y[8];
@@ -189,6 +206,12 @@ AMT_DEV void block_fwd_tile(const BlockFwdArgs& a_in, const long n0, const long 
         store8f(reinterpret_cast<T*>(a.LN) + row * C + sub * 8, y);
         if (sub == 0) { a.mean[row] = mu; a.rstd[row] = rs; }
       }
+    };
+    issue(0, xa);
+#pragma unroll
+    for (int pp = 0; pp < NPASS; ++pp) {
+      if (pp + 1 < NPASS) issue(pp + 1, (pp & 1) ? xa : xb);
+      evaluate(pp, (pp & 1) ? xb : xa);
     }
   }
   AMT_DBG_IF(4096) chain_load_w<T, S2::RB, KC2, H2>(wb, W2, m2, 0, lane);

@@ -549,13 +549,17 @@ void dwblock_bwd(hipStream_t s, DType dt, const void* dLN, const void* X, const 
 // depthwise conv + LayerNorm + pw1 + GELU + pw2 + layer scale + residual in registers, weights
 // broadcast from LDS.  Every tensor the backward pass needs is written exactly as the unfused
 // path writes it (LN output, u, h = gelu(u), z, y, mean, rstd), with the same roundings.
+// SAVE = false (inference): only y (and the tail LayerNorm's rows) leave the kernel; the six saved tensors were 400 of the
+// 517 MB a C = 4 launch moved at streaming-inference sizes (143 us per launch, 3.6 TB/s: HBM-bound by stores nobody reads).
+// (`save` is a run-time flag, not a template parameter: two instantiations contracted their fp32 arithmetic differently
+// and predict() stopped matching the training forward bit for bit.)
 template <typename T, int C>
 __global__ __launch_bounds__(256, 2) void block_small_fwd_kernel(
     const T* __restrict__ X, const float* __restrict__ wdw, const float* __restrict__ bdw,
     const float* __restrict__ lnw, const float* __restrict__ lnb, const T* __restrict__ w1, const float* __restrict__ b1,
     const T* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ gamma, T* __restrict__ LN,
     float* __restrict__ mean, float* __restrict__ rstd, T* __restrict__ U, T* __restrict__ Hh, T* __restrict__ Z,
-    T* __restrict__ Y, int B, int L, TailLn tail) {
+    T* __restrict__ Y, int B, int L, TailLn tail, int save) {
   constexpr int H2 = 2 * C;
   __shared__ __attribute__((aligned(16))) float sw1[H2 * C], sw2[C * H2], sb1[H2], sb2[C], sg[C], sdw[7 * C], sbd[C], slw[C], slb[C];
   __shared__ __attribute__((aligned(16))) float stw[C], stb[C];
@@ -630,11 +634,13 @@ __global__ __launch_bounds__(256, 2) void block_small_fwd_kernel(
       z[c] = to_f(from_f<T>(a));
       y[c] = x[3][c] + sg[wz + c] * z[c];
     }
-    storevf<C>(LN + row * C, ln);
-    storevf<C>(Z + row * C, z);
     storevf<C>(Y + row * C, y);
-    mean[row] = mu;
-    rstd[row] = rs;
+    if (save) {
+      storevf<C>(LN + row * C, ln);
+      storevf<C>(Z + row * C, z);
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
     if (tail.w != nullptr) {   // LayerNorm of the stored y row (kernels.h: TailLn), the roundings of ln_fwd_kernel
       float t[C], tm, tr;
 #pragma unroll
@@ -646,7 +652,8 @@ __global__ __launch_bounds__(256, 2) void block_small_fwd_kernel(
       tail.mean[row] = tm;
       tail.rstd[row] = tr;
     }
-    if constexpr (H2 == 8) {
+    if (!save) {
+    } else if constexpr (H2 == 8) {
       storevf<8>(U + row * H2, u);
       storevf<8>(Hh + row * H2, h);
     } else {
@@ -991,11 +998,12 @@ void block_small_fwd(hipStream_t s, DType dt, const void* X, const float* wdw, c
   const int grid = (int)std::min<long>((N + 255) / 256, 2048);
   TailLn tl{};
   if (tail != nullptr) tl = *tail;
-  ProfScope ps(s, "block_small_fwd", 2.0 * N * (7 * C + 4 * C * C), 8.0 * N * C * (dt == DT_F32 ? 4 : 2));
+  const bool save = U != nullptr;      // inference passes no save tensors
+  ProfScope ps(s, "block_small_fwd", 2.0 * N * (7 * C + 4 * C * C), (save ? 8.0 : 2.0) * N * C * (dt == DT_F32 ? 4 : 2));
 #define AMT_LAUNCH_SF(TT, CC_)                                                                                         \
   hipLaunchKernelGGL((block_small_fwd_kernel<TT, CC_>), dim3(grid), dim3(256), 0, s, (const TT*)X, wdw, bdw, lnw, lnb,  \
                      (const TT*)w1, b1, (const TT*)w2, b2, gamma, (TT*)LN, mean, rstd, (TT*)U, (TT*)Hh, (TT*)Z, (TT*)Y, \
-                     B, L, tl)
+                     B, L, tl, save ? 1 : 0)
   if (dt == DT_F32) { if (C == 4) AMT_LAUNCH_SF(float, 4); else AMT_LAUNCH_SF(float, 8); }
   else { if (C == 4) AMT_LAUNCH_SF(bf16, 4); else AMT_LAUNCH_SF(bf16, 8); }
 #undef AMT_LAUNCH_SF

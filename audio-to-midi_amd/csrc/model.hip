@@ -529,8 +529,9 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
       if (C <= 8) {   // per-position kernel: the 1x1 convs are too narrow for an MFMA tile
         void* y = out_buf((size_t)N * C);
         RUN(block_small_fwd(s, dt, cur, c->P(bp.dw_w), c->P(bp.dw_b), c->P(bp.ln_w), c->P(bp.ln_b), c->WC(bp.c_pw1),
-                            c->P(bp.pw1_b), c->WC(bp.c_pw2), c->P(bp.pw2_b), c->P(bp.gamma), bs.ln, bs.mean, bs.rstd,
-                            bs.u, bs.h, bs.z, y, B, Lcur, C, &tl));
+                            c->P(bp.pw1_b), c->WC(bp.c_pw2), c->P(bp.pw2_b), c->P(bp.gamma), save ? bs.ln : nullptr,
+                            save ? bs.mean : nullptr, save ? bs.rstd : nullptr, save ? bs.u : nullptr, save ? bs.h : nullptr,
+                            save ? bs.z : nullptr, y, B, Lcur, C, &tl));
         cur = y;
         continue;
       }
