@@ -124,6 +124,18 @@ AMT_DEV void kv_store(T* Ks, T* Vs, const Chunk8<T> (&kc)[2], const Chunk8<T> (&
 AMT_DEV uint32_t gdrop_idx(int b, int H, int h, int S, int q, int key) {
   return (uint32_t)(((b * H + h) * S + q)) * (uint32_t)S + (uint32_t)key;
 }
+// OR over the four lanes that share (lane & 15): the bits move through the float swap helpers untouched
+AMT_DEV uint32_t or_over_g(uint32_t v) {
+  float a, b;
+  xrow16(__builtin_bit_cast(float, v), a, b);
+  v = __builtin_bit_cast(uint32_t, a) | __builtin_bit_cast(uint32_t, b);
+  xrow32(__builtin_bit_cast(float, v), a, b);
+  return __builtin_bit_cast(uint32_t, a) | __builtin_bit_cast(uint32_t, b);
+}
+// keep-bit word of (clip b, head h, key tile kt, query q): see AttnArgs::keepbits
+AMT_DEV size_t keepbits_index(int b, int H, int h, int ntile, int kt, int q) {
+  return ((size_t)(b * H + h) * ntile + kt) * (size_t)(64 * ntile) + q;
+}
 
 // ------------------------------------------------------------------ global forward
 // NG = 2 groups of four waves share the 64 queries of the workgroup and split the key tiles
@@ -208,6 +220,7 @@ __global__ __launch_bounds__(256 * NG) void attn_global_fwd_kernel(AttnArgs a) {
       float m_new = fmaxf(m_run, mx);
       float alpha = __expf(m_run - m_new);
       float psum = 0.f;
+      uint32_t kb[2] = {0u, 0u};       // keep bits of this lane's 16 scores: word st >> 1, bit 16 (st & 1) + e (+ 4 g below)
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
         float pv[4];
@@ -219,10 +232,17 @@ __global__ __launch_bounds__(256 * NG) void attn_global_fwd_kernel(AttnArgs a) {
             int key = kt * 64 + 16 * st + 4 * g + e;
             bool keep = rng_keep(a.seed, a.stream, gdrop_idx(b, a.H, h, S, qrow, key), a.drop_thresh24);
             p = keep ? p * a.inv_keep : 0.f;
+            kb[st >> 1] |= (keep ? 1u : 0u) << (16 * (st & 1) + e);
           }
           pv[e] = p;
         }
         store4f(Pw + r * ALD + 16 * st + 4 * g, pv);
+      }
+      if (DROP) {
+        if (a.keepbits != nullptr) {   // uniform
+          const uint32_t lo = or_over_g(kb[0] << (4 * g)), hi = or_over_g(kb[1] << (4 * g));
+          if (g == 0) a.keepbits[keepbits_index(b, a.H, h, ntile, kt, qrow)] = ((unsigned long long)hi << 32) | lo;
+        }
       }
       psum = sum_xor32(sum_xor16(psum));
       l_run = l_run * alpha + psum;
@@ -523,10 +543,12 @@ void attn_global_fwd_fp8(hipStream_t s, const AttnArgs& a, const float* amax_pre
 // tiles in the dK/dV role) round-robin, each group with its own LDS tiles; their accumulators are summed through
 // LDS at the end (no rescaling: both roles use the forward's log-sum-exp).  Launched with NG = 1 (see attn_global_bwd).
 template <typename T> struct GBwdLds {
-  static constexpr size_t GROUP_BYTES = (size_t)(64 * 2 + 128) * ALD * sizeof(T) + 128 * sizeof(float);
+  static constexpr size_t GROUP_BYTES = (size_t)(64 * 2 + 128) * ALD * sizeof(T) + 256 * sizeof(float);   // + lse, delta, keep words
 };
 
-template <typename T, int NG, bool DROP>
+// BITS: the dropout keep decisions come from the forward's bit mask (AttnArgs::keepbits) instead of the hash: ~3 instead of
+// ~14 vector instructions per score in a loop that is bound by vector issue (~720 per 64 x 64 tile, profiles/r01_notes.md).
+template <typename T, int NG, bool DROP, bool BITS>
 AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, int b, int h, unsigned char* smem_all) {
   const AttnArgs& a = ba.f;
   const int tid_all = threadIdx.x, half = NG > 1 ? (tid_all >> 8) : 0, tid = tid_all & 255;
@@ -586,6 +608,12 @@ AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, int b, int
     if (active) kv_store<T>(Ks, Vs, kc, vc, rr, S, kt, tid);
     __syncthreads();
     if (kt + NG < nkt) kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, kt + NG, tid, a.cos, a.sin);
+    uint32_t kw[2] = {0u, 0u};             // this query's keep bits for the tile, shifted so that bit 16 (st & 1) + e is key (st, e)
+    if (DROP && BITS && active) {
+      const unsigned long long w = a.keepbits[keepbits_index(b, a.H, h, nkt, kt, qrow)];
+      kw[0] = (uint32_t)w >> (4 * g);
+      kw[1] = (uint32_t)(w >> 32) >> (4 * g);
+    }
     if (active) {
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
@@ -602,7 +630,8 @@ AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, int b, int
           float p = (key < S) ? __expf(sacc[e] - lse) : 0.f;
           float dp = dpacc[e];
           if (DROP) {
-            bool keep = rng_keep(a.seed, a.stream, gdrop_idx(b, a.H, h, S, qrow, key), a.drop_thresh24);
+            const bool keep = BITS ? ((kw[st >> 1] >> (16 * (st & 1) + e)) & 1u) != 0u
+                                   : rng_keep(a.seed, a.stream, gdrop_idx(b, a.H, h, S, qrow, key), a.drop_thresh24);
             dp = keep ? dp * a.inv_keep : 0.f;
           }
           ds[e] = p * (dp - dl);
@@ -651,7 +680,7 @@ AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, int b, int
   }
 }
 
-template <typename T, int NG, bool DROP>
+template <typename T, int NG, bool DROP, bool BITS>
 AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, int h, unsigned char* smem_all) {
   const AttnArgs& a = ba.f;
   const int tid_all = threadIdx.x, half = NG > 1 ? (tid_all >> 8) : 0, tid = tid_all & 255;
@@ -662,6 +691,7 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
   T* dST = PT + 4 * 16 * ALD;      // [4 waves][16][ALD]
   float* lse_s = reinterpret_cast<float*>(dST + 4 * 16 * ALD);
   float* delta_s = lse_s + 64;
+  uint32_t* kb_s = reinterpret_cast<uint32_t*>(delta_s + 64);   // [2][64]: low / high halves of the 64 queries' keep words
   const int lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
   const int S = a.S;
   const int key = tile * 64 + wave * 16 + r;
@@ -732,6 +762,11 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
       if (tid < 64) {
         int q = qt * 64 + tid;
         lse_s[tid] = (q < S) ? a.LSE[(size_t)(b * a.H + h) * S + q] : 0.f;
+        if (DROP && BITS) {       // this key tile's keep words of the 64 queries: 512 contiguous bytes
+          const unsigned long long w = a.keepbits[keepbits_index(b, a.H, h, nqt, tile, q)];
+          kb_s[tid] = (uint32_t)w;
+          kb_s[64 + tid] = (uint32_t)(w >> 32);
+        }
       }
     }
     __syncthreads();
@@ -747,6 +782,11 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
         float pd[4], ds[4];
         const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * st + 4 * g);
         const f32x4 del4 = *reinterpret_cast<const f32x4*>(delta_s + 16 * st + 4 * g);
+        // this lane's key is bit (16 wave + r) of a query's word: the half is uniform over the wave
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+        u32x4 kq = u32x4{0u, 0u, 0u, 0u};
+        if (DROP && BITS) kq = *reinterpret_cast<const u32x4*>(kb_s + 64 * (wave >> 1) + 16 * st + 4 * g);
+        const int kbit = 16 * (wave & 1) + r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           int ql = 16 * st + 4 * g + e, q = qt * 64 + ql;
@@ -754,7 +794,8 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
           float p = valid ? __expf(sacc[e] - lse4[e]) : 0.f;
           float dp = dpacc[e], pdrop = p;
           if (DROP) {
-            bool keep = rng_keep(a.seed, a.stream, gdrop_idx(b, a.H, h, S, q, key), a.drop_thresh24);
+            const bool keep = BITS ? ((kq[e] >> kbit) & 1u) != 0u
+                                   : rng_keep(a.seed, a.stream, gdrop_idx(b, a.H, h, S, q, key), a.drop_thresh24);
             dp = keep ? dp * a.inv_keep : 0.f;
             pdrop = keep ? p * a.inv_keep : 0.f;
           }
@@ -811,7 +852,7 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
 }
 
 // blocks [0, ntile) of a (clip, head) compute dQ, blocks [ntile, 2 ntile) dK/dV
-template <typename T, int NG, bool DROP>
+template <typename T, int NG, bool DROP, bool BITS>
 __global__ __launch_bounds__(256 * NG, 2 * NG) void attn_global_bwd_kernel(AttnBwdArgs ba, int ntile) {
   ba.f.seed = eff_seed(ba.f.seed, ba.f.seed_dev);   // kernel argument + the context's device seed word (common.h)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -821,8 +862,8 @@ __global__ __launch_bounds__(256 * NG, 2 * NG) void attn_global_bwd_kernel(AttnB
   const int bh = (jj / per) * 8 + xcd, role = jj % per;
   if (bh >= ba.f.B * ba.f.H) return;
   const int h = bh % ba.f.H, b = bh / ba.f.H;
-  if (role < ntile) attn_global_bwd_dq_body<T, NG, DROP>(ba, role, b, h, smem_raw);
-  else attn_global_bwd_dkv_body<T, NG, DROP>(ba, role - ntile, b, h, smem_raw);
+  if (role < ntile) attn_global_bwd_dq_body<T, NG, DROP, BITS>(ba, role, b, h, smem_raw);
+  else attn_global_bwd_dkv_body<T, NG, DROP, BITS>(ba, role - ntile, b, h, smem_raw);
 }
 
 template <typename K> static void set_max_lds(K kernel, size_t bytes) {
@@ -855,17 +896,23 @@ void attn_global_bwd(hipStream_t s, DType dt, const AttnBwdArgs& a) {
   dim3 grid(((a.f.B * a.f.H + 7) / 8 * 8) * 2 * ntile);
   ProfScope ps(s, "attn_global_bwd", 8.0 * a.f.B * a.f.H * (double)a.f.S * a.f.S * 64,
                8.0 * a.f.B * a.f.S * a.f.H * 64 * (dt == DT_F32 ? 4 : 2));
+  const bool drop = a.f.drop_thresh24 != 0, bits = drop && a.f.keepbits != nullptr;
   if (dt == DT_F32) {
-    static bool once = (set_max_lds(attn_global_bwd_kernel<float, 1, true>, 96 * 1024),
-                        set_max_lds(attn_global_bwd_kernel<float, 1, false>, 96 * 1024), true);
+    static bool once = (set_max_lds(attn_global_bwd_kernel<float, 1, true, true>, 96 * 1024),
+                        set_max_lds(attn_global_bwd_kernel<float, 1, true, false>, 96 * 1024),
+                        set_max_lds(attn_global_bwd_kernel<float, 1, false, false>, 96 * 1024), true);
     (void)once;
-    if (a.f.drop_thresh24) hipLaunchKernelGGL((attn_global_bwd_kernel<float, 1, true>), grid, dim3(256), GBwdLds<float>::GROUP_BYTES, s, a, ntile);
-    else hipLaunchKernelGGL((attn_global_bwd_kernel<float, 1, false>), grid, dim3(256), GBwdLds<float>::GROUP_BYTES, s, a, ntile);
+    const size_t lds = GBwdLds<float>::GROUP_BYTES;
+    if (bits) hipLaunchKernelGGL((attn_global_bwd_kernel<float, 1, true, true>), grid, dim3(256), lds, s, a, ntile);
+    else if (drop) hipLaunchKernelGGL((attn_global_bwd_kernel<float, 1, true, false>), grid, dim3(256), lds, s, a, ntile);
+    else hipLaunchKernelGGL((attn_global_bwd_kernel<float, 1, false, false>), grid, dim3(256), lds, s, a, ntile);
   } else {
     // NG = 2 (the forward's split) measured 47.5 us against 38.2 us for NG = 1 stand-alone: 128 VGPRs with 37
     // spilled, and this kernel is bound by VALU / LDS issue (~720 VALU + 95 LDS instructions per tile), not latency
-    if (a.f.drop_thresh24) hipLaunchKernelGGL((attn_global_bwd_kernel<bf16, 1, true>), grid, dim3(256), GBwdLds<bf16>::GROUP_BYTES, s, a, ntile);
-    else hipLaunchKernelGGL((attn_global_bwd_kernel<bf16, 1, false>), grid, dim3(256), GBwdLds<bf16>::GROUP_BYTES, s, a, ntile);
+    const size_t lds = GBwdLds<bf16>::GROUP_BYTES;
+    if (bits) hipLaunchKernelGGL((attn_global_bwd_kernel<bf16, 1, true, true>), grid, dim3(256), lds, s, a, ntile);
+    else if (drop) hipLaunchKernelGGL((attn_global_bwd_kernel<bf16, 1, true, false>), grid, dim3(256), lds, s, a, ntile);
+    else hipLaunchKernelGGL((attn_global_bwd_kernel<bf16, 1, false, false>), grid, dim3(256), lds, s, a, ntile);
   }
 }
 

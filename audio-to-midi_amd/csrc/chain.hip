@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256 * NG) void block_run_fwd_kernel(BlockRunFwdArgs
 // panels fit LDS: 128 tokens at C = 128 (137 KiB), 256 at C = 64; AMT_BLOCK_INF_LONG=0 restores round 2's 64 / 128.
 template <int C, typename T> struct BlockInferTile {
   static constexpr int SHORT = BlockTile<C>::TT * (sizeof(T) == 4 || C == 256 ? 2 : 4);
-  static constexpr int LONG = (C == 128 || C == 64) ? 2 * SHORT : SHORT;
+  static constexpr int LONG = (C == 128 || C == 64 || (C == 256 && sizeof(T) == 2)) ? 2 * SHORT : SHORT;
 };
 template <typename T, int C, bool SAVE, int TT>
 static void block_fwd_fused_launch_tt(hipStream_t s, const BlockFwdArgs& a) {
@@ -1245,7 +1245,11 @@ static void qkv_fwd_fused_launch_tt(hipStream_t s, const QkvFwdArgs& a) {
 }
 template <typename T>
 static void qkv_fwd_fused_launch(hipStream_t s, const QkvFwdArgs& a) {
+  // tile length: 16 tokens while that is what fills the chip, 32 from 8192 tokens on (AMT_QKV_FWD_TT=64: 64-token tiles
+  // from 49152 tokens on - three 128-KiB panels per workgroup, one workgroup per compute unit: slower)
+  static const int tt_env = getenv("AMT_QKV_FWD_TT") ? atoi(getenv("AMT_QKV_FWD_TT")) : 0;
   if (a.N < 8192) qkv_fwd_fused_launch_tt<T, FfnTileFwd<T>::TT>(s, a);
+  else if (sizeof(T) == 2 && a.N >= 49152 && tt_env == 64) qkv_fwd_fused_launch_tt<T, 2 * FfnTile<T>::TT>(s, a);   // opt-in: measured 79 against 63 us at 112 000 tokens
   else qkv_fwd_fused_launch_tt<T, FfnTile<T>::TT>(s, a);
 }
 
@@ -1613,9 +1617,8 @@ static void lnout_bwd_fused_launch(hipStream_t s, const LnOutBwdArgs& a, const W
 // 16-token tiles (250 workgroups at cfg2, 50 KiB of LDS: riders share the compute units); 32-token tiles for bf16 ran
 // 51 us per launch against 43 us for the three launches it replaces
 constexpr int kFfnBwdTile = 16;
-template <typename T>
+template <typename T, int TT>
 static void ffn_bwd_fused_launch(hipStream_t s, const FfnBwdArgs& a, const WgradGroup& rg, int n_rider_wgs) {
-  constexpr int TT = kFfnBwdTile;
   constexpr size_t lds_chain = sizeof(T) * (size_t)TT * (2 * (256 + 8) + (1024 + 8));
   constexpr size_t lds = lds_chain > TnLds<T>::BYTES ? lds_chain : TnLds<T>::BYTES;
   static_assert(lds <= 160 * 1024, "LDS budget");
@@ -1678,7 +1681,11 @@ void lnout_bwd_fused(hipStream_t s, DType dt, const LnOutBwdArgs& a_in, float* d
 void ffn_bwd_fused(hipStream_t s, DType dt, const FfnBwdArgs& a_in, float* dlnw, float* dlnb, PartialSink* sink,
                    const WgradArgs* riders, int n_riders) {
   FfnBwdArgs a = a_in;
-  a.n_chain = chain_ln_records(dt, a.N, dlnw, dlnb, sink, &a.rec, kFfnBwdTile);
+  // 16-token tiles at every size; AMT_FFN_BWD_TT=32: 32-token tiles from 8192 tokens on (bf16) - half the weight
+  // streams, but 100 KiB of LDS per workgroup leave one workgroup per compute unit
+  static const int tt_env = getenv("AMT_FFN_BWD_TT") ? atoi(getenv("AMT_FFN_BWD_TT")) : 0;
+  const int tt = (dt == DT_BF16 && a.N >= 8192 && tt_env == 32) ? 32 : kFfnBwdTile;   // opt-in: measured 110 against 82 us at 16 000 tokens
+  a.n_chain = chain_ln_records(dt, a.N, dlnw, dlnb, sink, &a.rec, tt);
   WgradGroup rg;
   double rfl = 0, rby = 0;
   static const int tgt_ffn = getenv("AMT_RIDER_TARGET_FFN") ? atoi(getenv("AMT_RIDER_TARGET_FFN")) : 264;   // 250 chain + ~264 rider workgroups fill the 512 resident slots (0 / 176 / 220 / 264 / 308: 3.255 / 3.252 / 3.236 / 3.235 / 3.260 ms)
@@ -1689,8 +1696,9 @@ void ffn_bwd_fused(hipStream_t s, DType dt, const FfnBwdArgs& a_in, float* dlnw,
   ProfScope ps(s, n_rider_wgs > 0 ? "ffn_bwd_fused+wgrad" : "ffn_bwd_fused",
                2.0 * N * (512.0 * 256 + 256.0 * 1024 + 256.0 * 256) + rfl,
                (N * (256 * 5.0 + 2.0 * 1024) + 512.0 * 256 + 256.0 * 1024 + 256.0 * 256) * es + rby);
-  if (dt == DT_F32) ffn_bwd_fused_launch<float>(s, a, rg, n_rider_wgs);
-  else ffn_bwd_fused_launch<bf16>(s, a, rg, n_rider_wgs);
+  if (dt == DT_F32) ffn_bwd_fused_launch<float, kFfnBwdTile>(s, a, rg, n_rider_wgs);
+  else if (tt == 32) ffn_bwd_fused_launch<bf16, 32>(s, a, rg, n_rider_wgs);
+  else ffn_bwd_fused_launch<bf16, kFfnBwdTile>(s, a, rg, n_rider_wgs);
 }
 
 }  // namespace amt

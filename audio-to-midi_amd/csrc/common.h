@@ -180,7 +180,7 @@ AMT_DEV void mma(f32x4& acc, const Frag<float>& a, const Frag<float>& b) {
 // division: v_div_scale x 2, v_rcp, four fma, v_div_fmas, v_div_fixup) compiled to 22 and made every GELU / GLU epilogue
 // VALU-bound: 57 million evaluations per launch at streaming-inference sizes, 891 of the ~1100 vector instructions
 // between two MFMA stages of the FFN chain (in-kernel stamps, profiles/r03_notes.md).  v_exp_f32 and v_rcp_f32 are
-// accurate to 1 ulp, the whole expression to ~4e-7 relative: inside the fp32 tolerance against the float64 oracle (2e-5).
+// accurate to 1 ulp, the whole expression to ~4e-7 relative: inside the fp32 tolerance of the parity tests (2e-5 against float64).
 constexpr float GELU_C0 = -2.f * 0.7978845608028654f * 1.4426950408889634f;   // -2 sqrt(2/pi) log2(e)
 constexpr float GELU_C1 = GELU_C0 * 0.044715f;
 AMT_DEV float gelu_tanh(float x) {

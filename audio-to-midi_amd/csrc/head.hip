@@ -160,7 +160,7 @@ __global__ void step_begin_kernel(f32x4* g, size_t n, float* loss_acc, int* vali
 }
 bool step_begin(hipStream_t s, float* grads, size_t n, float* loss_acc, int* valid) {
   if ((reinterpret_cast<uintptr_t>(grads) & 15) != 0) return false;
-  hipLaunchKernelGGL(step_begin_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<f32x4*>(grads), n, loss_acc, valid);
+  hipLaunchKernelGGL(step_begin_kernel, dim3(n == 0 ? 1 : 2048), dim3(256), 0, s, reinterpret_cast<f32x4*>(grads), n, loss_acc, valid);
   return true;
 }
 // (loss, all-finite flag) of a step into the head / tail words of a gradient bucket (train.py: GradBucket), one launch
@@ -424,6 +424,139 @@ void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, float
                  const int* gate_i, const float* gate_f, int step, int* count) {
   ProfScope ps(s, "adamw_apply", 0, 12.0 * n);
   hipLaunchKernelGGL(adamw_apply_kernel, dim3(2048), dim3(256), 0, s, params, upd, n, norm2, clip, gate_i, gate_f, step, count);
+}
+
+// ------------------------------------------------------------------ AdamW straight from the gradient accumulator
+// The fused protocol of a single-rank step (include/amt.h: amt_adamw_step_gated with grads_flat == NULL): the backward
+// pass leaves its raw fp32 sums in the context's accumulator and NO pass writes unscaled gradients anywhere.
+//   pass 1 (norm):   reads g, p, m, v; forms the Adam update u exactly as pass 2 will and adds |u|^2 to norm2.  Writes
+//                    nothing else - a non-finite gradient makes norm2 non-finite, and that IS the all-finite flag
+//                    (g = NaN or +-Inf gives m' = NaN / Inf and u = NaN; train.py:320-322 tests the gradients themselves).
+//   pass 2 (commit): gate = caller's flags && isfinite(norm2) && isfinite(loss); behind an open gate it recomputes m', v',
+//                    u (same expressions, same bits), applies the global-norm clip (optax.clip_by_global_norm on the
+//                    UPDATES) and writes p, m, v; in every case it zeroes g, so the next step's backward adds into a
+//                    clean accumulator without a fill launch.  One thread publishes the flag and advances the count.
+// Against grads_finalize + adamw_compute + adamw_apply: 52 instead of 60 bytes per parameter, two launches instead of
+// three, no 46-MB zero fill at the start of the next step.
+AMT_DEV float adamw_update(float gi, float pi, float mo, float vo, float lrs, float lr, float b1, float b2, float eps, float wd,
+                           float bc1, float bc2, float& mi, float& vi) {
+  mi = b1 * mo + (1.f - b1) * gi;
+  vi = b2 * vo + (1.f - b2) * gi * gi;
+  float u = (mi / bc1) / (sqrtf(vi / bc2) + eps);
+  u += wd * pi;
+  u *= -lr * lrs;
+  return u;
+}
+// Both passes move 16 bytes per lane and array (f32x4) over the 16-byte-aligned body [0, n4 * 4) and finish the last
+// n % 4 elements (and everything, when a pointer is not 16-byte aligned: VEC = false) with scalar accesses.
+template <bool VEC>
+__global__ __launch_bounds__(256) void adamw_norm_kernel(const float* __restrict__ p, const float* __restrict__ g,
+                                                         const float* __restrict__ m, const float* __restrict__ v,
+                                                         const float* __restrict__ lr_scale, size_t n, float gmul, float lr,
+                                                         float b1, float b2, float eps, float wd, int step,
+                                                         const int* __restrict__ count, float* __restrict__ norm2) {
+  __shared__ float red[4];
+  const float t = (float)(step > 0 ? step : count[0] + 1);
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  float acc = 0.f;
+  const size_t n4 = VEC ? (n >> 2) : 0;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+  if (VEC) {
+    for (size_t i = tid; i < n4; i += nthr) {
+      const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i], p4 = reinterpret_cast<const f32x4*>(p)[i];
+      const f32x4 m4 = reinterpret_cast<const f32x4*>(m)[i], v4 = reinterpret_cast<const f32x4*>(v)[i];
+      const f32x4 s4 = reinterpret_cast<const f32x4*>(lr_scale)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float mi, vi;
+        const float u = adamw_update(g4[e] * gmul, p4[e], m4[e], v4[e], s4[e], lr, b1, b2, eps, wd, bc1, bc2, mi, vi);
+        acc += u * u;
+      }
+    }
+  }
+  for (size_t i = (n4 << 2) + tid; i < n; i += nthr) {
+    float mi, vi;
+    const float u = adamw_update(g[i] * gmul, p[i], m[i], v[i], lr_scale[i], lr, b1, b2, eps, wd, bc1, bc2, mi, vi);
+    acc += u * u;
+  }
+  acc = group_sum<64>(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(norm2, red[0] + red[1] + red[2] + red[3]);
+}
+template <bool VEC>
+__global__ __launch_bounds__(256) void adamw_commit_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, const float* __restrict__ lr_scale, size_t n,
+                                                           float gmul, float lr, float b1, float b2, float eps, float wd, int step,
+                                                           int* __restrict__ count, float* __restrict__ norm2, float clip,
+                                                           const int* __restrict__ gate_i, const float* __restrict__ gate_f,
+                                                           const float* __restrict__ loss, int* __restrict__ valid_out) {
+  __shared__ float s_nrm2;
+  __shared__ int s_cnt;
+  if (threadIdx.x == 0) {
+    s_nrm2 = __hip_atomic_load(norm2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_cnt = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // both values have ARRIVED before this workgroup counts itself as a reader
+    unsigned* rd = reinterpret_cast<unsigned*>(norm2 + 1);
+    if (atomicAdd(rd, 1u) == gridDim.x - 1) {          // last reader: everybody has the old norm2 / count
+      const bool open = adamw_gate_open(gate_i, gate_f) && isfinite(s_nrm2) && (loss == nullptr || isfinite(loss[0]));
+      __hip_atomic_store(norm2, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rd, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (open) count[0] = step > 0 ? step : s_cnt + 1;
+      if (valid_out != nullptr) valid_out[0] = open ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  const bool open = adamw_gate_open(gate_i, gate_f) && isfinite(s_nrm2) && (loss == nullptr || isfinite(loss[0]));
+  const float t = (float)(step > 0 ? step : s_cnt + 1);
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float nrm = sqrtf(s_nrm2);
+  const float f = (clip > 0.f && nrm > clip) ? clip / nrm : 1.f;
+  const size_t n4 = VEC ? (n >> 2) : 0;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (VEC) {
+    for (size_t i = tid; i < n4; i += nthr) {
+      if (open) {
+        const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 p4 = reinterpret_cast<f32x4*>(p)[i], m4 = reinterpret_cast<f32x4*>(m)[i], v4 = reinterpret_cast<f32x4*>(v)[i];
+        const f32x4 s4 = reinterpret_cast<const f32x4*>(lr_scale)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float mi, vi;
+          const float u = adamw_update(g4[e] * gmul, p4[e], m4[e], v4[e], s4[e], lr, b1, b2, eps, wd, bc1, bc2, mi, vi);
+          m4[e] = mi; v4[e] = vi; p4[e] = p4[e] + u * f;
+        }
+        reinterpret_cast<f32x4*>(p)[i] = p4; reinterpret_cast<f32x4*>(m)[i] = m4; reinterpret_cast<f32x4*>(v)[i] = v4;
+      }
+      reinterpret_cast<f32x4*>(g)[i] = z4;
+    }
+  }
+  for (size_t i = (n4 << 2) + tid; i < n; i += nthr) {
+    if (open) {
+      float mi, vi;
+      const float pi = p[i];
+      const float u = adamw_update(g[i] * gmul, pi, m[i], v[i], lr_scale[i], lr, b1, b2, eps, wd, bc1, bc2, mi, vi);
+      m[i] = mi;
+      v[i] = vi;
+      p[i] = pi + u * f;
+    }
+    g[i] = 0.f;
+  }
+}
+void adamw_fused(hipStream_t s, float* params, float* gacc, float* m, float* v, const float* lr_scale, size_t n, float gmul,
+                 float lr, float b1, float b2, float eps, float wd, int step, int* count, float* norm2, float clip,
+                 const int* gate_i, const float* gate_f, const float* loss, int* valid_out) {
+  const bool vec = ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(gacc) | reinterpret_cast<uintptr_t>(m) |
+                     reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(lr_scale)) & 15) == 0;
+  {
+    ProfScope ps(s, "adamw_norm", 0, 20.0 * n);
+    if (vec) hipLaunchKernelGGL(adamw_norm_kernel<true>, dim3(2048), dim3(256), 0, s, params, gacc, m, v, lr_scale, n, gmul, lr, b1, b2, eps, wd, step, count, norm2);
+    else hipLaunchKernelGGL(adamw_norm_kernel<false>, dim3(2048), dim3(256), 0, s, params, gacc, m, v, lr_scale, n, gmul, lr, b1, b2, eps, wd, step, count, norm2);
+  }
+  ProfScope ps(s, "adamw_commit", 0, 36.0 * n);
+  if (vec) hipLaunchKernelGGL(adamw_commit_kernel<true>, dim3(2048), dim3(256), 0, s, params, gacc, m, v, lr_scale, n, gmul, lr, b1, b2, eps, wd, step, count, norm2, clip, gate_i, gate_f, loss, valid_out);
+  else hipLaunchKernelGGL(adamw_commit_kernel<false>, dim3(2048), dim3(256), 0, s, params, gacc, m, v, lr_scale, n, gmul, lr, b1, b2, eps, wd, step, count, norm2, clip, gate_i, gate_f, loss, valid_out);
 }
 
 // ------------------------------------------------------------------ profiler (prof.h)

@@ -305,6 +305,10 @@ struct AttnArgs {
   int B, S, H;                // H heads of dim 64
   uint64_t seed; uint32_t stream; uint32_t drop_thresh24; float inv_keep;
   const uint64_t* seed_dev;   // optional device word ADDED to `seed` by the kernel (fresh masks under hipGraph replay)
+  // Global attention, dropout on (optional): the forward leaves the keep decisions of its weight dropout here, one bit per
+  // score - word [(b H + h) * ntile + kt][q] (q < 64 ntile), bit 16 st + 4 g + e = key 64 kt + 16 st + 4 g + e - and both
+  // roles of the backward read them back instead of hashing 16 indices per lane and 64 x 64 tile again (attn.hip).
+  unsigned long long* keepbits;
 };
 struct AttnBwdArgs {
   AttnArgs f;                 // forward tensors (O = forward output, LSE)
@@ -353,6 +357,11 @@ void adamw_compute(hipStream_t s, const float* params, const float* grads, float
 // pass 2: params += upd * min(1, clip / sqrt(norm2)); norm2 = float[2] (sum, reader count), left zeroed for the next step
 bool step_begin(hipStream_t s, float* grads, size_t n, float* loss_acc, int* valid);   // false: not applicable (alignment)
 void pack_tail(hipStream_t s, const float* loss, const int* valid, float* head_valid, float* tail_loss, float* tail_valid);
+// AdamW straight from the context's gradient accumulator (head.hip): norm pass + commit pass, g is read as g * gmul and left
+// ZEROED; the all-finite flag is isfinite(|update|^2) && isfinite(loss) and goes to valid_out (device int, optional)
+void adamw_fused(hipStream_t s, float* params, float* gacc, float* m, float* v, const float* lr_scale, size_t n, float gmul,
+                 float lr, float b1, float b2, float eps, float wd, int step, int* count, float* norm2, float clip,
+                 const int* gate_i, const float* gate_f, const float* loss, int* valid_out);
 // gate_i / gate_f (device, either may be null): both passes are no-ops unless *gate_i != 0 and *gate_f >= 0.999;
 // step > 0: explicit optimizer step, step < 0: *count + 1 (device count of applied updates, advanced behind an open gate)
 void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, float* norm2, float clip,

@@ -258,7 +258,7 @@ struct Arena {
 
 struct BlockSave { void *x, *ln, *u, *h, *z; float *mean, *rstd; };
 struct StageSave { void *x, *ln; float *mean, *rstd; std::vector<BlockSave> blocks; };
-struct LayerSave { void *x, *xn, *qc, *kv, *ao, *h, *hn, *u, *g; float *m1, *r1, *m2, *r2, *lse; };
+struct LayerSave { void *x, *xn, *qc, *kv, *ao, *h, *hn, *u, *g; float *m1, *r1, *m2, *r2, *lse; unsigned long long* keepbits; };
 
 }  // namespace
 
@@ -303,6 +303,13 @@ struct amt_ctx {
   float* loss_acc = nullptr;    // device float[2]
   float* gacc = nullptr;        // internal gradient accumulation buffer [n_params + 64], see run_backward
   int gacc_pad = 0;
+  // fused-optimizer protocol (amt_forward_backward* with grads_flat == NULL, then amt_adamw_step_gated with grads_flat ==
+  // NULL): the accumulator is handed from the backward pass to the optimizer, which leaves it zeroed
+  // Invariant once the protocol has been used (fused_used): BETWEEN steps the accumulator holds zeros - it is zeroed at
+  // creation, by the optimizer's commit pass, by amt_grad_accumulator_reset, and at the END of every backward pass that
+  // writes the caller's buffer - so a fused backward pass (also a replayed one) never has to zero it first.
+  bool fused_used = false;
+  float gacc_mul = 1.f;         // 1 / (scale * accum_count) of the sums the last fused backward pass left there
   // per-block partial-sum records of the backward row kernels (kernels.h: PartialSink)
   float* partials = nullptr;
   size_t partials_cap = 0, part_total = 0;
@@ -321,6 +328,7 @@ struct amt_ctx {
   bool fuse = true;             // chain kernels (chain.hip); AMT_FUSE=0 selects the unfused launch sequence
   int nochain = 0;              // debugging: AMT_NOCHAIN bit mask disables individual chain kernels / riders
   bool attn_fp8 = false;        // amt_set_attn_fp8: global-attention forward on fp8 MFMA (bf16 contexts only)
+  bool attn_nobits = false;     // AMT_ATTN_BITS=0: the attention backward re-hashes its dropout masks (round-2 form, for A/B and the equality test)
   float* amax = nullptr;        // [layers][prev q,k,v,- | cur q,k,v,-]: delayed per-tensor scaling state
   uint64_t* seed_word = nullptr;   // device word added to every dropout seed (amt_seed_word / amt_advance_seed)
   TeamState* team = nullptr;    // XCD-team protocol words (team.h); null: team launches disabled (AMT_TEAM=0)
@@ -589,6 +597,15 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
     }
     ls.ao = A.alloc((size_t)N * H * es);
     ls.lse = local ? nullptr : (float*)A.alloc((size_t)B * cfg.n_heads * S * sizeof(float));
+    // keep bits of the global layer's attention-weight dropout, written by the forward, read by both backward roles
+    // (kernels.h: AttnArgs::keepbits); the fp8 forward does not write them (its backward falls back to the hash)
+    {
+      const size_t nt = (size_t)(S + 63) / 64;
+      // (allocated whether or not the fp8 forward is switched on: the switch may change between calls of one cached plan)
+      ls.keepbits = (!local && save && dp.thr && !c->attn_nobits)
+                        ? (unsigned long long*)A.alloc((size_t)B * cfg.n_heads * nt * nt * 64 * sizeof(unsigned long long)) : nullptr;
+      if (fp8) ls.keepbits = nullptr;
+    }
     ls.hn = A.alloc((size_t)N * H * es);
     ls.m2 = (float*)A.alloc((size_t)N * sizeof(float));
     ls.r2 = (float*)A.alloc((size_t)N * sizeof(float));
@@ -624,6 +641,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
     aa.QC = ls.qc; aa.ldqc = L.QC; aa.KV = ls.kv; aa.ldkv = L.KVW; aa.O = ls.ao; aa.ldo = H; aa.LSE = ls.lse;
     aa.cos = c->rope_cos; aa.sin = c->rope_sin; aa.B = B; aa.S = S; aa.H = cfg.n_heads;
     aa.seed = seed; aa.seed_dev = c->seed_word; aa.stream = stream_attn((int)li); aa.drop_thresh24 = dp.thr; aa.inv_keep = dp.inv_keep;
+    aa.keepbits = ls.keepbits;
     if (local) RUN(attn_local_fwd(s, dt, aa));
     else if (fp8) RUN(attn_global_fwd_fp8(s, aa, c->amax + 8 * li, c->amax + 8 * li + 4));
     else RUN(attn_global_fwd(s, dt, aa));
@@ -851,12 +869,19 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   // this step did not take effect from the second replay on (gradients accumulated over replays;
   // scratch/graph_dbg2.py), kernel nodes keep their stream order.  One launch for the three of them where it applies.
   bool began = !acc_first;   // later minibatches of an accumulated step add to what is there
-  if (acc_first) RUN(began = step_begin(s, grads, L.n_params, c->loss_acc, grads_valid));
+  const bool fused_opt = grads_out == nullptr && !dry;     // the optimizer consumes (and zeroes) the accumulator itself
+  if (acc_first && fused_opt) {                             // clean by the invariant: only the two loss words and the flag
+    RUN(step_begin(s, grads, 0, c->loss_acc, grads_valid));
+    began = true;
+  } else if (acc_first) {
+    RUN(began = step_begin(s, grads, L.n_params, c->loss_acc, grads_valid));
+  }
   if (!began) {
     RUN(hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, grads_valid, 1));
     RUN(fill_f32(s, grads, 0.f, L.n_params));
     RUN(fill_f32(s, c->loss_acc, 0.f, 2));
   }
+  if (fused_opt) { c->fused_used = true; c->gacc_mul = out_mul; }
 
   // two ping-pong gradient buffers for the residual stream / CNN activations
   const size_t act_elems = (size_t)B * (T / 5) * 4;
@@ -975,6 +1000,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     ab.f.QC = ls.qc; ab.f.ldqc = L.QC; ab.f.KV = ls.kv; ab.f.ldkv = L.KVW; ab.f.O = ls.ao; ab.f.ldo = H;
     ab.f.LSE = ls.lse; ab.f.cos = c->rope_cos; ab.f.sin = c->rope_sin; ab.f.B = B; ab.f.S = S; ab.f.H = cfg.n_heads;
     ab.f.seed = seed; ab.f.seed_dev = c->seed_word; ab.f.stream = stream_attn(li); ab.f.drop_thresh24 = dp.thr; ab.f.inv_keep = dp.inv_keep;
+    ab.f.keepbits = local ? nullptr : ls.keepbits;
     ab.dO = dao; ab.lddo = H; ab.dQC = dqc; ab.lddqc = L.QC; ab.dKV = dkv; ab.lddkv = L.KVW; ab.delta = delta;
     if (local) RUN(attn_local_bwd(s, dt, ab)); else RUN(attn_global_bwd(s, dt, ab));
     const int ckv = cfg.kv_compress;
@@ -1030,7 +1056,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   if (phase == 1) {
     flush_deferred();   // the first transformer layer's weight gradients (in the one-call step they ride on stage 6)
     RUN(reduce_partials(s, c->part_desc_dev, c->n_part_desc_half, c->partials, grads));
-    if (acc_last) RUN(grads_finalize(s, grads + L.fn_w, grads_out + L.fn_w, L.n_params - L.fn_w, out_mul, grads_valid));
+    if (acc_last && grads_out != nullptr) RUN(grads_finalize(s, grads + L.fn_w, grads_out + L.fn_w, L.n_params - L.fn_w, out_mul, grads_valid));
     return 0;
   }
   if (phase == 2) { live = true; sink.dry = dry || A.overflow; deferred.clear(); }   // phase 1 ran the deferred problems itself (none of them takes sink records)
@@ -1146,11 +1172,13 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   c->part_total = sink.off;
   if (phase == 2) {
     RUN(reduce_partials(s, c->part_desc_dev + c->n_part_desc_half, c->n_part_desc - c->n_part_desc_half, c->partials, grads));
-    if (acc_last) RUN(grads_finalize(s, grads, grads_out, L.fn_w, out_mul, grads_valid));
+    if (acc_last && grads_out != nullptr) RUN(grads_finalize(s, grads, grads_out, L.fn_w, out_mul, grads_valid));
   } else {
     RUN(reduce_partials(s, c->part_desc_dev, c->n_part_desc, c->partials, grads));
-    if (acc_last) RUN(grads_finalize(s, grads, grads_out, L.n_params, out_mul, grads_valid));
+    if (acc_last && grads_out != nullptr) RUN(grads_finalize(s, grads, grads_out, L.n_params, out_mul, grads_valid));
   }
+  // keep the fused protocol's invariant (accumulator clean between steps) when the two protocols are mixed on one context
+  if (acc_last && grads_out != nullptr && c->fused_used) RUN(fill_f32(s, grads, 0.f, L.n_params));
 #undef RUN
   return 0;
 }
@@ -1339,6 +1367,7 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   // every CU and slow down when sharing them.  Kept as an opt-in for larger per-GPU batches.
   c->use_side = getenv("AMT_SIDE_STREAM") != nullptr;
   c->fuse = !(getenv("AMT_FUSE") && atoi(getenv("AMT_FUSE")) == 0);
+  c->attn_nobits = getenv("AMT_ATTN_BITS") && atoi(getenv("AMT_ATTN_BITS")) == 0;
   c->nochain = getenv("AMT_NOCHAIN") ? atoi(getenv("AMT_NOCHAIN")) : 0;
   // whole second half of a layer (output projection, LN2, W1 / GLU, W2, dropout, residual) in one launch.  Round 1
   // measured it slower and left it off; with 16-token forward tiles and the boundary cost understood (it is the write-back
@@ -1380,6 +1409,7 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   if ((he = hipMemset(c->seed_word, 0, sizeof(uint64_t))) != hipSuccess) return fail("hipMemset", he);
   if ((he = hipMalloc(reinterpret_cast<void**>(&c->gacc), (L.n_params + 64) * sizeof(float))) != hipSuccess)
     return fail("hipMalloc(gradient accumulator)", he);
+  if ((he = hipMemset(c->gacc, 0, (L.n_params + 64) * sizeof(float))) != hipSuccess) return fail("hipMemset", he);
   if (!L.layers.empty()) {
     const LayerP& l0 = L.layers[0];
     size_t a0 = l0.ln1_w;
@@ -1612,10 +1642,25 @@ int32_t amt_adamw_step_gated(amt_ctx* c, const float* grads_flat, float lr_base,
     if (amt_optimizer_init(c, layer_lr_decay)) return 1;
   }
   int* count = reinterpret_cast<int*>(c->norm2 + 2);
+  if (grads_flat == nullptr) {
+    // fused protocol: the gradients are the sums the last amt_forward_backward*(grads_flat = NULL) left in the context's
+    // accumulator; valid_i32 is an OUTPUT here (the all-finite flag of this step, 1 = update applied)
+    if (!c->fused_used) { c->err = "amt_adamw_step(grads_flat = NULL): no backward pass has left gradients in the context (call amt_forward_backward* with grads_flat = NULL first)"; return 1; }
+    adamw_fused(s, c->params, c->gacc + c->gacc_pad, c->adam_m, c->adam_v, c->lr_scale, n, c->gacc_mul, lr_base, b1, b2, eps,
+                weight_decay, step, count, c->norm2, clip_norm, nullptr, valid_f32, c->loss_acc, const_cast<int32_t*>(valid_i32));
+    return refresh(c, s);
+  }
   adamw_compute(s, c->params, grads_flat, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, n, lr_base, b1, b2, eps,
                 weight_decay, step, count, c->norm2, valid_i32, valid_f32);
   adamw_apply(s, c->params, c->adam_upd, n, c->norm2, clip_norm, valid_i32, valid_f32, step, count);
   return refresh(c, s);
+}
+
+int32_t amt_grad_accumulator_reset(amt_ctx* c, void* stream) {
+  fill_f32(static_cast<hipStream_t>(stream), c->gacc + c->gacc_pad, 0.f, c->L.n_params);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { c->err = std::string("amt_grad_accumulator_reset: ") + hipGetErrorString(e); return 1; }
+  return 0;
 }
 
 int32_t amt_optimizer_count(amt_ctx* c) {

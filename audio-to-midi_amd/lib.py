@@ -105,6 +105,7 @@ SIGNATURES = {
     "amt_adamw_step_gated": (_i32, [_vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp, _vp]),
     "amt_optimizer_init": (_i32, [_vp, _f32]),
     "amt_optimizer_count": (_i32, [_vp]),
+    "amt_grad_accumulator_reset": (_i32, [_vp, _vp]),
     "amt_profile_begin": (None, []),
     "amt_profile_end": (_i32, [_vp, _i32]),
     # ops

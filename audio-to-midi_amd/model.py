@@ -209,7 +209,8 @@ class OutputSequenceGenerator:
     def loss_and_grads(self, audio, labels, scale: float = 1.0, seed: int = 0, train: bool = True,
                        rope_freqs: Optional[RopeFreqs] = None, return_logits: bool = False,
                        grads_out: Optional[torch.Tensor] = None, sync: bool = True, accum=(0, 1),
-                       loss_out: Optional[torch.Tensor] = None, valid_out: Optional[torch.Tensor] = None):
+                       loss_out: Optional[torch.Tensor] = None, valid_out: Optional[torch.Tensor] = None,
+                       fused_optimizer: bool = False):
         """compute_loss + the gradient half of compute_training_step (train.py:49-62, 292-322).
 
         ``accum=(i, k)``: minibatch i of k of an accumulated step (train.py:275-310): call i = 0 .. k - 1 in order with
@@ -222,8 +223,13 @@ class OutputSequenceGenerator:
         if tuple(y.shape) != (B, S, self.n_events):
             raise ValueError(f"labels must be [{B}, {S}, {self.n_events}], got {tuple(y.shape)}")
         self._ensure_rope(rope_freqs, S)
-        grads = grads_out if grads_out is not None else torch.empty(self.n_params, dtype=torch.float32,
-                                                                    device=self.device)
+        if fused_optimizer:      # the gradients stay in the context's accumulator for adamw_step(None, ...) (include/amt.h)
+            if grads_out is not None:
+                raise ValueError("fused_optimizer=True leaves the gradients in the context: pass no grads_out")
+            grads = None
+        else:
+            grads = grads_out if grads_out is not None else torch.empty(self.n_params, dtype=torch.float32,
+                                                                        device=self.device)
         loss = loss_out if loss_out is not None else torch.empty(2, dtype=torch.float32, device=self.device)
         valid = valid_out if valid_out is not None else torch.empty(1, dtype=torch.int32, device=self.device)
         logits = torch.empty(B, S, self.n_events, dtype=torch.float32, device=self.device) if return_logits else None
@@ -231,7 +237,7 @@ class OutputSequenceGenerator:
         self._check(self._L.amt_forward_backward_accum(self._h, _lib.ptr(a), _lib.ptr(y), B, T, float(scale), int(seed),
                                                        1 if train else 0, _lib.ptr(loss), _lib.ptr(grads), _lib.ptr(valid),
                                                        _lib.ptr(logits), 0, ai, ak, self._stream()), "amt_forward_backward")
-        if ai != ak - 1:
+        if ai != ak - 1 or fused_optimizer:
             return loss, grads, valid, logits          # nothing has been written yet: the last minibatch finalises
         if not sync:
             return loss, grads, valid, logits
@@ -272,12 +278,18 @@ class OutputSequenceGenerator:
         needed, so the step stays hipGraph-capturable."""
         if valid is not None and (valid.dtype != torch.int32 or not valid.is_cuda):
             raise ValueError("valid must be a device int32 tensor")
+        # grads_flat=None: the fused protocol - the gradients are what loss_and_grads(fused_optimizer=True) left in the
+        # context; `valid` is then an OUTPUT (1 iff the update was applied)
         if valid_mean is not None and (valid_mean.dtype != torch.float32 or not valid_mean.is_cuda):
             raise ValueError("valid_mean must be a device float32 tensor")
         self._check(self._L.amt_adamw_step_gated(self._h, _lib.ptr(grads_flat), float(lr_base), float(layer_lr_decay),
                                                  float(b1), float(b2), float(eps), float(weight_decay), float(clip_norm),
                                                  int(step), _lib.ptr(valid), _lib.ptr(valid_mean), self._stream()),
                     "amt_adamw_step")
+
+    def reset_grad_accumulator(self):
+        """Zero the context's gradient accumulator (after a fused backward pass whose gradients are not to be applied)."""
+        self._check(self._L.amt_grad_accumulator_reset(self._h, self._stream()), "amt_grad_accumulator_reset")
 
     def optimizer_count(self) -> int:
         """Number of optimizer updates applied so far (device counter; synchronises).  include/amt.h: amt_optimizer_count."""

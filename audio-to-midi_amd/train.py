@@ -105,9 +105,12 @@ class HipTrainBackend:
     """Per-rank forward/backward/optimizer on the HIP library for fixed, device-resident inputs."""
 
     def __init__(self, model, audio: torch.Tensor, labels: torch.Tensor, bucket: GradBucket, scale: float = 1.0,
-                 use_optimizer: bool = True, accum_steps: int = 1):
+                 use_optimizer: bool = True, accum_steps: int = 1, fused: bool = False):
         self.model, self.audio, self.labels, self.bucket, self.scale = model, audio, labels, bucket, float(scale)
         self.use_optimizer = use_optimizer
+        # fused = the single-rank protocol (include/amt.h): the gradients never leave the context, AdamW reads the raw
+        # sums (norm pass + commit pass) and leaves the accumulator zeroed; no collective can see them, so world size 1 only
+        self.fused = bool(fused) and use_optimizer
         # train.py:275-310: the rank's batch in `accum_steps` minibatches, gradients accumulated in fp32 ON THE DEVICE (the
         # context's accumulator: amt_forward_backward_accum), grads / (grad_scale * steps) in the last minibatch's final pass
         self.accum_steps = int(accum_steps)
@@ -125,9 +128,16 @@ class HipTrainBackend:
     def full(self, seed: int):
         b, k = self.bucket, self.accum_steps
         for i, (a, y) in enumerate(self._mb):      # one dropout seed per minibatch (train.py:277 splits the key)
-            self.model.loss_and_grads(a, y, scale=self.scale, seed=seed + i, train=True, grads_out=b.grads, sync=False,
-                                      accum=(i, k), loss_out=self.loss_buf, valid_out=self.valid_buf)
-        self.model.pack_tail(self.loss_buf, self.valid_buf, head_valid=b.head[0:1], tail_loss=b.tail[0:1], tail_valid=b.tail[1:2])
+            self.model.loss_and_grads(a, y, scale=self.scale, seed=seed + i, train=True, grads_out=None if self.fused else b.grads,
+                                      sync=False, accum=(i, k), loss_out=self.loss_buf, valid_out=self.valid_buf,
+                                      fused_optimizer=self.fused)
+        if not self.fused:      # (fused: the flag is an output of the optimizer's commit pass, packed by apply())
+            self.model.pack_tail(self.loss_buf, self.valid_buf, head_valid=b.head[0:1], tail_loss=b.tail[0:1], tail_valid=b.tail[1:2])
+
+    def discard(self):
+        """Drop the gradients of a step that will not be applied (warm-up / capture rehearsal runs in prepare())."""
+        if self.fused:
+            self.model.reset_grad_accumulator()
 
     def half(self, phase: int, seed: int):
         b, k = self.bucket, self.accum_steps
@@ -150,7 +160,11 @@ class HipTrainBackend:
         # Gated on the all-reduced flag, on the device.  step = -1: the bias corrections come from the context's DEVICE
         # count of applied updates, which a skipped (non-finite) step does not advance - optax's count behaves the same
         # way and the reference rolls its optimizer state back (train.py:369-377); `step` on the host would drift.
-        if self.use_optimizer:
+        if self.fused:
+            b = self.bucket
+            self.model.adamw_step(None, lr_base=lr_base, step=-1, valid=self.valid_buf)
+            self.model.pack_tail(self.loss_buf, self.valid_buf, head_valid=b.head[0:1], tail_loss=b.tail[0:1], tail_valid=b.tail[1:2])
+        elif self.use_optimizer:
             self.model.adamw_step(self.bucket.grads, lr_base=lr_base, step=-1, valid_mean=self.bucket.valid_all)
 
     def applied_steps(self) -> int:
@@ -209,7 +223,9 @@ class DataParallelStep:
     def prepare(self, seed: int = 0):
         """Run once eagerly (plans the workspace: every allocation happens here), then capture the graphs."""
         be = self.backend
+        discard = getattr(be, "discard", lambda: None)      # fused protocol: rehearsal gradients must not reach the optimizer
         be.full(seed)
+        discard()
         if self.overlap:
             be.half(1, seed); be.half(2, seed)
         if self.cuda:
@@ -220,6 +236,7 @@ class DataParallelStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up on a side stream, as torch's capture rules want
             be.full(seed)
+            discard()
             if self.overlap:
                 be.half(1, seed); be.half(2, seed)
         torch.cuda.current_stream().wait_stream(side)

@@ -310,6 +310,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
     ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--no-fused-optimizer", action="store_true",
+                    help="N = 1: write the unscaled gradients to the bucket and run the three-pass optimizer (the N > 1 form)")
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: one all-reduce after the whole backward pass instead of the two-bucket overlap")
@@ -377,7 +379,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    backend = amt_train.HipTrainBackend(model, audio, labels, bucket, scale=1.0, use_optimizer=not args.no_optimizer)
+    # one rank, one collective-free step: the fused protocol (include/amt.h) - AdamW reads the gradient sums where the
+    # backward pass left them (grads / scale, the finite check and the clip are all still computed, train.py:319-325)
+    fused = world == 1 and not overlap and not args.no_optimizer and not args.no_fused_optimizer
+    backend = amt_train.HipTrainBackend(model, audio, labels, bucket, scale=1.0, use_optimizer=not args.no_optimizer, fused=fused)
     dp = amt_train.DataParallelStep(backend, bucket, backend.split, dist=dist, overlap=overlap, graph=not args.no_graph,
                                     lr_base=1e-4)
     dp.prepare(seed=12345)       # every allocation (optimizer state, workspace plan) happens before graph capture
@@ -455,6 +460,7 @@ def main():
                        "global_batch": world * B_PER_GPU, "clip_seconds": CLIP_SECONDS, "frames": T_SAMPLES // 320,
                        "parallelism": f"dp{world}", "hipgraph": graph is not None,
                        "grad_allreduce": ("two collectives (ReduceOp.AVG), the first overlapped with the CNN backward" if overlap else "one bucket (ReduceOp.AVG)") if world > 1 or overlap else None,
+                       "optimizer": None if args.no_optimizer else ("fused: norm pass + commit pass over the context's gradient accumulator" if fused else "grads_finalize + adamw_compute + adamw_apply over the bucket"),
                        "weights": "random init (Equinox distributions), 11606230 params"},
             "model_tflops": round(world * FLOPS_PER_STEP / (elapsed / args.steps) / 1e12, 2),
             "loss": round(loss_val, 3), "grads_valid": bool(grads_valid), "loss_finite": True,

@@ -203,6 +203,21 @@ int32_t amt_adamw_step_gated(amt_ctx* ctx, const float* grads_flat, float lr_bas
 
 int32_t amt_optimizer_count(amt_ctx* ctx);
 
+/* ---- the fused single-rank protocol: no gradient vector leaves the context ----------------------------------------
+ * amt_forward_backward / _phase / _accum with grads_flat == NULL leave their raw fp32 gradient sums in the context's
+ * accumulator and skip the pass that would write grads / (scale * steps) to the caller (train.py:319); grads_valid is
+ * then only reset to 1.  amt_adamw_step_gated with grads_flat == NULL consumes them: a norm pass (the global norm of the
+ * Adam updates, nothing written) and a commit pass that applies the clipped update behind the gate
+ *     (valid_f32 == NULL || *valid_f32 >= 0.999)  &&  every gradient finite  &&  loss finite
+ * and ZEROES the accumulator in every case.  valid_i32 is an OUTPUT in this form: 1 iff the update was applied (the
+ * grads_valid of train.py:320-322 together with the loss test of train.py:369).  52 instead of 60 bytes of HBM traffic
+ * per parameter, two launches instead of three, and no zero fill at the start of the next step: the accumulator is
+ * clean between steps by construction (zeroed at creation, by the commit pass, by amt_grad_accumulator_reset, and at the
+ * end of every backward pass that does write grads_flat).  A backward pass whose gradients are NOT to be applied (a
+ * warm-up run, an aborted step) must be followed by amt_grad_accumulator_reset, otherwise the next one adds to it -
+ * which is also how train.py:275-310's accumulation over minibatches looks in this protocol. */
+int32_t amt_grad_accumulator_reset(amt_ctx* ctx, void* stream);
+
 /* ---- measurement aid (bench.py roofline leg): per-kernel-class timing with HIP events recorded
  * on the launch stream around every kernel launch.  Process-global; off by default. */
 typedef struct amt_prof_entry {

@@ -578,3 +578,24 @@ def test_large_n_chains_equal_the_short_tile_chains(small_conf, dtype, monkeypat
     assert abs(outs["1"][2] - outs["0"][2]) <= 1e-6 * abs(outs["0"][2])
     rel = float((outs["1"][3] - outs["0"][3]).norm() / outs["0"][3].norm())
     assert rel < (1e-5 if dtype == "float32" else 1e-3), rel
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_attention_backward_keep_bits_equal_the_rehashed_masks(small_conf, dtype, monkeypatch):
+    """Round 3: the global-attention forward leaves the keep decisions of its weight dropout as one bit per score and
+    both backward roles read them back (csrc/attn.hip, AttnArgs::keepbits) instead of hashing the 64 x 64 indices of every
+    tile twice more.  Same decisions, so the step equals the re-hashing form (AMT_ATTN_BITS=0) up to the atomic summation
+    order of the weight gradients; S = 150: three key tiles, the last one ragged."""
+    audio, labels = synth.make_batch(3, 320 * 150, seed=17)
+    a, y = torch.from_numpy(audio), torch.from_numpy(labels)
+    outs = {}
+    for bits in ("1", "0"):
+        monkeypatch.setenv("AMT_ATTN_BITS", bits)
+        model = amt.OutputSequenceGenerator(small_conf, key=13, dtype=dtype, gamma=1.0)
+        o = model.loss_and_grads(a, y, seed=99, train=True, return_logits=True)
+        outs[bits] = (o.logits.clone(), o.loss, o.grads_flat.clone())
+        model.close()
+    assert torch.equal(outs["1"][0], outs["0"][0])
+    assert abs(outs["1"][1] - outs["0"][1]) <= 1e-6 * abs(outs["0"][1])          # the loss is an atomic sum: last bits
+    rel = float((outs["1"][2] - outs["0"][2]).norm() / outs["0"][2].norm())
+    assert rel < (1e-5 if dtype == "float32" else 1e-3), rel

@@ -127,3 +127,74 @@ def test_non_finite_loss_closes_the_bucket_flags(small_conf):
         model.pack_tail(torch.tensor([lv, 0.0], device="cuda"), one, head_valid=buf[0:1], tail_loss=buf[1:2], tail_valid=buf[2:3])
         torch.cuda.synchronize()
         assert float(buf[0]) == want and float(buf[2]) == want
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_fused_optimizer_protocol_equals_the_three_pass_form(small_conf, dtype):
+    """include/amt.h, "the fused single-rank protocol": loss_and_grads(fused_optimizer=True) leaves the raw gradient sums in
+    the context and adamw_step(None) consumes them (norm pass + commit pass, accumulator left zeroed).  Three steps with the
+    clip active equal grads_finalize + adamw_compute + adamw_apply on a twin model; a non-finite step (NaN audio) is
+    skipped with flag 0, leaves parameters, m, v and the update count alone and does not leak into the next step; a
+    discarded backward pass (reset_grad_accumulator) does not either; mixing in a plain loss_and_grads keeps the invariant."""
+    audio, labels = synth.make_batch(2, 320 * 48, seed=21)
+    a, y = torch.from_numpy(audio), torch.from_numpy(labels)
+    fused = amt.OutputSequenceGenerator(small_conf, key=3, dtype=dtype, gamma=1.0)
+    plain = amt.OutputSequenceGenerator(small_conf, key=3, dtype=dtype, gamma=1.0)
+    fused.init_optimizer(); plain.init_optimizer()
+    flag = torch.full((1,), -7, dtype=torch.int32, device="cuda")
+    lr = 2e-2          # large enough for the global-norm clip (1.0) to bind in the first steps
+    for k in range(3):
+        if k == 1:      # a discarded pass and a plain call in between must not change what the next fused step applies
+            fused.loss_and_grads(a, y, seed=500, train=True, fused_optimizer=True)
+            fused.reset_grad_accumulator()
+            fused.loss_and_grads(a, y, seed=501, train=True)
+        fused.loss_and_grads(a, y, scale=2.0, seed=10 + k, train=True, fused_optimizer=True)
+        fused.adamw_step(None, lr_base=lr, step=-1, valid=flag)
+        out = plain.loss_and_grads(a, y, scale=2.0, seed=10 + k, train=True)
+        plain.adamw_step(out.grads_flat, lr_base=lr, step=k + 1)
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 1 and fused.optimizer_count() == k + 1
+        d = float((fused.weights_tensor() - plain.weights_tensor()).abs().max())
+        # float32 pins the arithmetic (the only difference is the summation order of the weight-gradient atomics).  bfloat16:
+        # a last-bit difference of an fp32 master weight can flip the bf16 rounding of its compute copy (2^-9 relative), the
+        # next step's gradients then differ visibly and Adam's early steps (|update| ~ lr whatever |g|) turn that into a few
+        # percent of one step: measured 4.7e-4 at lr = 2e-2
+        assert d < (2e-6 if dtype == "float32" else 2e-3), (k, d)
+    p_before = fused.weights_tensor().clone()
+    bad = a.clone(); bad[0, 0, 100] = float("nan")
+    fused.loss_and_grads(bad, y, seed=77, train=True, fused_optimizer=True)
+    fused.adamw_step(None, lr_base=lr, step=-1, valid=flag)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0 and fused.optimizer_count() == 3 and torch.equal(fused.weights_tensor(), p_before)
+    fused.loss_and_grads(a, y, scale=2.0, seed=13, train=True, fused_optimizer=True)       # the poisoned sums are gone
+    fused.adamw_step(None, lr_base=lr, step=-1, valid=flag)
+    out = plain.loss_and_grads(a, y, scale=2.0, seed=13, train=True)
+    plain.adamw_step(out.grads_flat, lr_base=lr, step=4)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1 and bool(torch.isfinite(fused.weights_tensor()).all())
+    assert float((fused.weights_tensor() - plain.weights_tensor()).abs().max()) < (2e-6 if dtype == "float32" else 4e-3)
+    fresh = amt.OutputSequenceGenerator(small_conf, key=3, dtype=dtype, gamma=1.0)
+    with pytest.raises(RuntimeError):
+        fresh.adamw_step(None, lr_base=lr, step=-1)            # nothing has been left in the context
+
+
+def test_data_parallel_step_uses_the_fused_protocol_under_graph_replay(small_conf):
+    """DataParallelStep over HipTrainBackend(fused=True), captured and replayed: the rehearsal runs of prepare() are
+    discarded, every replay + apply is one optimizer update, and the result equals the unfused backend's."""
+    audio, labels = synth.make_batch(2, 320 * 48, seed=4)
+    outs = {}
+    for fused in (True, False):
+        model = amt.OutputSequenceGenerator(small_conf, key=8, dtype="bfloat16", gamma=1.0)
+        a, y = torch.from_numpy(audio).to("cuda", torch.bfloat16), torch.from_numpy(labels).cuda()
+        bucket = train.GradBucket(model.n_params, "cuda")
+        be = train.HipTrainBackend(model, a, y, bucket, fused=fused)
+        dp = train.DataParallelStep(be, bucket, be.split, dist=None, overlap=False, graph=True, lr_base=1e-3)
+        dp.prepare(seed=5)
+        model.seed_word().zero_()
+        for _ in range(3):
+            dp.step()
+        loss, valid = dp.result()
+        assert valid and dp.applied == 3 and model.optimizer_count() == 3
+        outs[fused] = (loss, model.weights_tensor().clone())
+    assert abs(outs[True][0] - outs[False][0]) <= 1e-3 * abs(outs[False][0])
+    assert float((outs[True][1] - outs[False][1]).abs().max()) < 2e-4      # bf16 copies amplify last-bit differences (see above); lr = 1e-3
