@@ -328,6 +328,7 @@ struct amt_ctx {
   bool fuse = true;             // chain kernels (chain.hip); AMT_FUSE=0 selects the unfused launch sequence
   int nochain = 0;              // debugging: AMT_NOCHAIN bit mask disables individual chain kernels / riders
   bool attn_fp8 = false;        // amt_set_attn_fp8: global-attention forward on fp8 MFMA (bf16 contexts only)
+  mutable bool team_dead = false;   // a team hand-off has timed out (seen by amt_team_status): no further team launches from this context
   bool attn_nobits = false;     // AMT_ATTN_BITS=0: the attention backward re-hashes its dropout masks (round-2 form, for A/B and the equality test)
   float* amax = nullptr;        // [layers][prev q,k,v,- | cur q,k,v,-]: delayed per-tensor scaling state
   uint64_t* seed_word = nullptr;   // device word added to every dropout seed (amt_seed_word / amt_advance_seed)
@@ -473,7 +474,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
     const int N = B * Lcur;
     sv.blocks.assign(st.blocks.size(), BlockSave());
     // XCD-team form: the whole stage in one launch (team.h; chain.hip: block_run_fwd)
-    if (save && c->fuse && c->team != nullptr && C >= 16 && st.blocks.size() >= 2 && st.blocks.size() <= (size_t)BLOCK_RUN_MAX &&
+    if (save && c->fuse && c->team != nullptr && !c->team_dead && C >= 16 && st.blocks.size() >= 2 && st.blocks.size() <= (size_t)BLOCK_RUN_MAX &&
         !(c->nochain & 1) && !(c->nochain & 1024)) {
       BlockRunFwdArgs ra;
       memset(&ra, 0, sizeof(ra));
@@ -1569,7 +1570,11 @@ int32_t amt_advance_seed(amt_ctx* c, uint64_t delta, void* stream) {
   return 0;
 }
 
-int32_t amt_team_status(const amt_ctx* c) { return c->team ? team_state_timeout(c->team) : 0; }
+int32_t amt_team_status(const amt_ctx* c) {
+  const int st = c->team ? team_state_timeout(c->team) : 0;
+  if (st != 0) c->team_dead = true;     // sticky on the host as well: the CNN stages go back to one launch per Block
+  return st;
+}
 
 void amt_profile_begin(void) {
   Profiler& p = profiler();

@@ -121,9 +121,12 @@ AMT_DEV Team team_assemble(TeamState* st, const TeamTicket& k) {
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     unsigned spins = 0;
-    bool ok = true;
+    // the timeout word is STICKY: once any hand-off of this context has given up, team sizes / flag lines may be in a
+    // partial state, so every later team launch falls through at once (the host then stops launching team
+    // forms as well: chain.hip: block_run_fwd)
+    bool ok = team_ld_u32(&st->timeout[0]) == 0u;
     unsigned cnt = 0;
-    for (;;) {
+    for (; ok;) {
       cnt = lane < TEAM_MAX ? team_ld_u32(&st->members[lane][0]) : 0u;
       unsigned total = cnt;
 #pragma unroll

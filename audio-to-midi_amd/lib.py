@@ -192,7 +192,8 @@ def load_post():
     global _post
     if _post is not None:
         return _post
-    if not os.path.exists(POST_LIB_PATH):
-        raise ImportError(f"{POST_LIB_PATH} not found: run `python __graft_entry__.py`")
-    _post = C.CDLL(POST_LIB_PATH)
+    path = os.environ.get("AMT_POST_LIB", POST_LIB_PATH)      # (an instrumented build of the same sources, e.g. AddressSanitizer: tests/test_post_cpu.py)
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: run `python __graft_entry__.py`")
+    _post = C.CDLL(path)
     return _post

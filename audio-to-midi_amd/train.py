@@ -306,4 +306,8 @@ class DataParallelStep:
         valid = v[0] >= 0.999 and v[2] >= 0.999
         if hasattr(self.backend, "applied_steps"):
             self.applied = int(self.backend.applied_steps())
+        m = getattr(self.backend, "model", None)
+        if m is not None and hasattr(m, "team_status") and m.team_status() != 0:     # polled where the loop synchronises anyway
+            raise RuntimeError("an in-launch XCD-team hand-off timed out (amt_team_status != 0): the outputs of that step are "
+                               "undefined; the context has switched its CNN stages back to one launch per Block")
         return float(v[1]), bool(valid)

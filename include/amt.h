@@ -176,8 +176,10 @@ int32_t amt_pack_tail(amt_ctx* ctx, const float* loss, const int32_t* grads_vali
                       float* tail_valid, void* stream);
 
 /* In-launch XCD-team hand-offs (csrc/team.h) spin with a bound.  0 = none has ever given up in this context; non-zero =
- * a launch timed out (its outputs are undefined and every later team launch falls through): treat as fatal.
- * Host-synchronous read. */
+ * a launch timed out (its outputs are undefined): treat that step as lost.  The timeout word is sticky on the device
+ * (every later team launch gives up at its first poll and its kernels fall through) and, once this call has seen it, on
+ * the host: the context launches one kernel per Block from then on.  Host-synchronous read; poll it where the training
+ * loop synchronises anyway (audio_to_midi_amd.train.DataParallelStep.result does). */
 int32_t amt_team_status(const amt_ctx* ctx);
 
 /* ---- next-row: optimizer step of compute_training_step (train.py:324-325, 646-729) ----------

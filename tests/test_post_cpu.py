@@ -68,3 +68,49 @@ def test_frame_events_round_trip():
     got = post.extract_events(np.clip(a, 0.005, 0.995))
     assert got == opost.extract_events(np.clip(a, 0.005, 0.995))
     assert {(10, 40), (5, 3), (200, 88), (31, 40)} <= {(e[0], e[1]) for e in got}
+
+
+def test_post_library_under_address_sanitizer(tmp_path):
+    """SURVEY.md section 5 ("race detection / sanitizers"): an AddressSanitizer host build of the C++ post-processing code
+    (csrc/post.cpp) replays the golden vectors and the edge cases of this file in a child process (libasan preloaded, the
+    instrumented library loaded through AMT_POST_LIB).  Any heap overflow / use-after-free in stitch_probs,
+    extract_events, extract_midi_events / free_midi_events or convert_to_frame_events aborts the child."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gxx = shutil.which("g++")
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if gxx is None or not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no g++ / libasan in this environment")
+    so = tmp_path / "libamt_post_asan.so"
+    src = os.path.join(root, "audio-to-midi_amd", "csrc", "post.cpp")
+    r = subprocess.run([gxx, "-O1", "-g", "-std=c++17", "-fsanitize=address", "-fno-omit-frame-pointer", "-shared", "-fPIC",
+                        "-o", str(so), src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from audio_to_midi_amd import post
+g = np.load(os.path.join(%r, "tests", "golden", "post.npz"))
+assert np.array_equal(post.stitch_probs(g["windows"], 0.5, 0.02), g["stitched"])
+ev = post.extract_events(g["track"])
+assert np.array_equal(np.array(ev, dtype=np.int64).reshape(-1, 4), g["events"])
+ev16 = post.extract_midi_events_f16(g["windows"].astype(np.float16), 0.5, 0.02)    # the cbinds.rs entry point (f16, stitch + extract)
+assert len(ev16) > 0
+assert post.extract_events(np.zeros((0, 90), np.float32)) == []                      # empty track
+assert post.extract_events(np.full((3, 90), 0.9, np.float32))[0][2] == 3             # note held to the end of a short track
+fr = post.to_frame_events(ev[:50], 400, 0, 380)
+assert fr.shape == (400, 90)
+try:
+    post.stitch_probs(np.zeros((2, 10, 90), np.float32), 5.0, 0.02)                   # overlap longer than a window
+except IndexError:
+    pass
+print("ASAN_CHILD_OK")
+""" % (root, root)
+    env = dict(os.environ, LD_PRELOAD=asan, AMT_POST_LIB=str(so), ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "ASAN_CHILD_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "AddressSanitizer" not in r.stderr

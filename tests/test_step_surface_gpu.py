@@ -184,8 +184,10 @@ def test_data_parallel_step_uses_the_fused_protocol_under_graph_replay(small_con
     audio, labels = synth.make_batch(2, 320 * 48, seed=4)
     outs = {}
     for fused in (True, False):
-        model = amt.OutputSequenceGenerator(small_conf, key=8, dtype="bfloat16", gamma=1.0)
-        a, y = torch.from_numpy(audio).to("cuda", torch.bfloat16), torch.from_numpy(labels).cuda()
+        # float32: the two forms then differ only by the summation order of the weight-gradient atomics (a bf16 context
+        # amplifies such last-bit differences through the rounding of its compute copies: 3e-4 after three steps)
+        model = amt.OutputSequenceGenerator(small_conf, key=8, dtype="float32", gamma=1.0)
+        a, y = torch.from_numpy(audio).cuda(), torch.from_numpy(labels).cuda()
         bucket = train.GradBucket(model.n_params, "cuda")
         be = train.HipTrainBackend(model, a, y, bucket, fused=fused)
         dp = train.DataParallelStep(be, bucket, be.split, dist=None, overlap=False, graph=True, lr_base=1e-3)
@@ -196,5 +198,5 @@ def test_data_parallel_step_uses_the_fused_protocol_under_graph_replay(small_con
         loss, valid = dp.result()
         assert valid and dp.applied == 3 and model.optimizer_count() == 3
         outs[fused] = (loss, model.weights_tensor().clone())
-    assert abs(outs[True][0] - outs[False][0]) <= 1e-3 * abs(outs[False][0])
-    assert float((outs[True][1] - outs[False][1]).abs().max()) < 2e-4      # bf16 copies amplify last-bit differences (see above); lr = 1e-3
+    assert abs(outs[True][0] - outs[False][0]) <= 1e-5 * abs(outs[False][0])
+    assert float((outs[True][1] - outs[False][1]).abs().max()) < 5e-6
