@@ -356,6 +356,19 @@ AMT_DEV bool adamw_gate_open(const int* gate_i, const float* gate_f) {
   if (gate_f != nullptr && !(gate_f[0] >= 0.999f)) return false;
   return true;
 }
+// optax.scale_by_adam + add_decayed_weights + scale_by_learning_rate for one element.  bc1 / bc2 are passed as their
+// RECIPROCALS and the square root / the quotient are v_sqrt_f32 / v_rcp_f32 (1 ulp each): written with two IEEE divisions
+// and a correctly rounded sqrtf the update is ~170 vector instructions per element and both optimizer passes were bound
+// by vector issue, not by HBM (4 TB/s; found by counting v_div_fmas / v_sqrt in the ISA).
+AMT_DEV float adamw_update(float gi, float pi, float mo, float vo, float lrs, float lr, float b1, float b2, float eps, float wd,
+                           float ibc1, float ibc2, float& mi, float& vi) {
+  mi = b1 * mo + (1.f - b1) * gi;
+  vi = b2 * vo + (1.f - b2) * gi * gi;
+  float u = (mi * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vi * ibc2) + eps);
+  u += wd * pi;
+  u *= -lr * lrs;
+  return u;
+}
 __global__ __launch_bounds__(256) void adamw_compute_kernel(const float* __restrict__ p, const float* __restrict__ g,
                                                             float* __restrict__ m, float* __restrict__ v,
                                                             float* __restrict__ upd, const float* __restrict__ lr_scale,
@@ -367,17 +380,13 @@ __global__ __launch_bounds__(256) void adamw_compute_kernel(const float* __restr
   // optax counts APPLIED updates: step < 0 takes the count from the device word that adamw_apply advances only when its
   // gate is open, so a skipped step does not move the bias corrections (the reference rolls opt_state back, train.py:369-377)
   const float t = (float)(step > 0 ? step : count[0] + 1);
-  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float ibc1 = 1.f / (1.f - powf(b1, t)), ibc2 = 1.f / (1.f - powf(b2, t));
   float acc = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    float gi = g[i];
-    float mi = b1 * m[i] + (1.f - b1) * gi;
-    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    float mi, vi;
+    const float u = adamw_update(g[i], p[i], m[i], v[i], lr_scale ? lr_scale[i] : 1.f, lr, b1, b2, eps, wd, ibc1, ibc2, mi, vi);
     m[i] = mi;
     v[i] = vi;
-    float u = (mi / bc1) / (sqrtf(vi / bc2) + eps);      // optax.scale_by_adam
-    u += wd * p[i];                                      // add_decayed_weights
-    u *= -lr * (lr_scale ? lr_scale[i] : 1.f);           // scale_by_learning_rate
     upd[i] = u;
     acc += u * u;
   }
@@ -438,15 +447,6 @@ void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, float
 //                    clean accumulator without a fill launch.  One thread publishes the flag and advances the count.
 // Against grads_finalize + adamw_compute + adamw_apply: 52 instead of 60 bytes per parameter, two launches instead of
 // three, no 46-MB zero fill at the start of the next step.
-AMT_DEV float adamw_update(float gi, float pi, float mo, float vo, float lrs, float lr, float b1, float b2, float eps, float wd,
-                           float bc1, float bc2, float& mi, float& vi) {
-  mi = b1 * mo + (1.f - b1) * gi;
-  vi = b2 * vo + (1.f - b2) * gi * gi;
-  float u = (mi / bc1) / (sqrtf(vi / bc2) + eps);
-  u += wd * pi;
-  u *= -lr * lrs;
-  return u;
-}
 // Both passes move 16 bytes per lane and array (f32x4) over the 16-byte-aligned body [0, n4 * 4) and finish the last
 // n % 4 elements (and everything, when a pointer is not 16-byte aligned: VEC = false) with scalar accesses.
 template <bool VEC>
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void adamw_norm_kernel(const float* __restrict
                                                          const int* __restrict__ count, float* __restrict__ norm2) {
   __shared__ float red[4];
   const float t = (float)(step > 0 ? step : count[0] + 1);
-  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float bc1 = 1.f / (1.f - powf(b1, t)), bc2 = 1.f / (1.f - powf(b2, t));     // reciprocals (adamw_update)
   float acc = 0.f;
   const size_t n4 = VEC ? (n >> 2) : 0;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void adamw_commit_kernel(float* __restrict__ p
   __syncthreads();
   const bool open = adamw_gate_open(gate_i, gate_f) && isfinite(s_nrm2) && (loss == nullptr || isfinite(loss[0]));
   const float t = (float)(step > 0 ? step : s_cnt + 1);
-  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float bc1 = 1.f / (1.f - powf(b1, t)), bc2 = 1.f / (1.f - powf(b2, t));     // reciprocals (adamw_update)
   const float nrm = sqrtf(s_nrm2);
   const float f = (clip > 0.f && nrm > clip) ? clip / nrm : 1.f;
   const size_t n4 = VEC ? (n >> 2) : 0;
