@@ -886,6 +886,15 @@ void attn_global_fwd(hipStream_t s, DType dt, const AttnArgs& a) {
     // (four groups of two tiles each measured the same 13.9 us as two groups of four: what is left is the
     // first-tile latency, the merge and the launch itself)
     size_t lds = (size_t)2 * (64 * 2 + 64) * ALD * sizeof(bf16);
+    // short sequences (the reference's 5-s windows: 250 frames = 4 key tiles): one wave group per workgroup - two groups
+    // would take two key tiles each and then merge.  Chosen by S alone, so that a window's logits do not depend on how
+    // many windows share the call (AMT_ATTN_FWD_NG=2 keeps two groups).
+    static const int ng_env = getenv("AMT_ATTN_FWD_NG") ? atoi(getenv("AMT_ATTN_FWD_NG")) : 0;
+    if (ng_env != 2 && a.S <= 256) {
+      if (a.drop_thresh24) hipLaunchKernelGGL((attn_global_fwd_kernel<bf16, 1, true>), grid, dim3(256), lds / 2, s, a);
+      else hipLaunchKernelGGL((attn_global_fwd_kernel<bf16, 1, false>), grid, dim3(256), lds / 2, s, a);
+      return;
+    }
     if (a.drop_thresh24) hipLaunchKernelGGL((attn_global_fwd_kernel<bf16, 2, true>), grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL((attn_global_fwd_kernel<bf16, 2, false>), grid, dim3(512), lds, s, a);
   }

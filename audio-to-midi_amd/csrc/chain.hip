@@ -406,7 +406,9 @@ static void block_fwd_fused_launch(hipStream_t s, const BlockFwdArgs& a) {
     block_fwd_fused_launch_tt<T, C, true, BlockTile<C>::TT>(s, a);
   } else {
     using IT = BlockInferTile<C, T>;
-    static const bool long_tiles = !(getenv("AMT_BLOCK_INF_LONG") && atoi(getenv("AMT_BLOCK_INF_LONG")) == 0);
+    // AMT_BLOCK_INF_LONG: bit mask of the widths that take the long tile (1: C = 64, 2: C = 128, 4: C = 256; default all)
+    static const int long_mask = getenv("AMT_BLOCK_INF_LONG") ? atoi(getenv("AMT_BLOCK_INF_LONG")) : 7;
+    const bool long_tiles = (long_mask & (C == 64 ? 1 : (C == 128 ? 2 : 4))) != 0;
     // short clips (few tiles per compute unit) keep the short tile: the long one would leave compute units idle
     if (IT::LONG != IT::SHORT && long_tiles && (long)a.B * a.L >= 256L * IT::LONG) block_fwd_fused_launch_tt<T, C, false, IT::LONG>(s, a);
     else block_fwd_fused_launch_tt<T, C, false, IT::SHORT>(s, a);
