@@ -203,28 +203,51 @@ AMT_DEV void chain_copy_store(T* Ps, const ChainCopyRegs<T, TT, W>& regs, int ti
 
 // Row LayerNorm over C = 8 * LPR features of the rows of an LDS panel (fp32 statistics, eqx LayerNorm):
 // Ys = LN(Xs) (may alias Xs row-for-row), mean / rstd to global for rows < N.
-template <typename T, int TT, int C, int LD>
-AMT_DEV void chain_ln_rows(const T* Xs, T* Ys, const float* __restrict__ w, const float* __restrict__ b,
-                           float* __restrict__ mean, float* __restrict__ rstd, long n0, long N, int tid) {
-  constexpr int LPR = C / 8, RPP = 256 / LPR;
+// The passes of a tile are independent, but Ys may alias Xs, so written one pass after the other the compiler keeps every
+// pass's LDS load behind the previous pass's store: one LDS round trip plus a ~120-instruction dependent chain (two
+// lane-group reductions) per pass, in series, with one wave per SIMD and nothing to fill the gaps (in-kernel stamps:
+// 850 cycles per 8-row pass, profiles/r03_notes.md section 7).  Here up to LN_GROUP passes are loaded first, evaluated
+// side by side (independent chains the scheduler interleaves) and stored together; every row's arithmetic is unchanged.
+constexpr int LN_GROUP = 4;
+template <typename T, int TT, int C, int LD, bool TO_GLOBAL>
+AMT_DEV void chain_ln_rows_impl(const T* Xs, T* Ys, T* __restrict__ G, const float* __restrict__ w, const float* __restrict__ b,
+                                float* __restrict__ mean, float* __restrict__ rstd, long n0, long N, int tid) {
+  constexpr int LPR = C / 8, RPP = 256 / LPR, NP = TT / RPP, GR = NP < LN_GROUP ? NP : LN_GROUP;
   static_assert(TT % RPP == 0, "row phase covers the tile in whole passes");
+  static_assert(NP % GR == 0, "passes come in whole groups");
   const int sub = tid % LPR, prow = tid / LPR;
   float wv[8], bv[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { wv[i] = w[sub * 8 + i]; bv[i] = b[sub * 8 + i]; }
 #pragma unroll
-  for (int pp = 0; pp < TT / RPP; ++pp) {
-    const int p = pp * RPP + prow;
-    float x[8];
-    load8f(Xs + p * LD + sub * 8, x);
-    float mu, rs;
-    ln_stats<8, LPR>(x, mu, rs);
-    float y[8];
+  for (int p0 = 0; p0 < NP; p0 += GR) {
+    float x[GR][8], mu[GR], rs[GR];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = ln_apply(x[i], rs, wv[i], bv[i]);
-    store8f(Ys + p * LD + sub * 8, y);
-    if (sub == 0 && n0 + p < N) { mean[n0 + p] = mu; rstd[n0 + p] = rs; }
+    for (int j = 0; j < GR; ++j) load8f(Xs + ((p0 + j) * RPP + prow) * LD + sub * 8, x[j]);
+#pragma unroll
+    for (int j = 0; j < GR; ++j) ln_stats<8, LPR>(x[j], mu[j], rs[j]);
+#pragma unroll
+    for (int j = 0; j < GR; ++j) {
+      const int p = (p0 + j) * RPP + prow;
+      float y[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) y[i] = ln_apply(x[j][i], rs[j], wv[i], bv[i]);
+      if constexpr (TO_GLOBAL) {
+        if (n0 + p < N) {
+          store8f(G + (n0 + p) * C + sub * 8, y);
+          if (sub == 0) { mean[n0 + p] = mu[j]; rstd[n0 + p] = rs[j]; }
+        }
+      } else {
+        store8f(Ys + p * LD + sub * 8, y);
+        if (sub == 0 && n0 + p < N) { mean[n0 + p] = mu[j]; rstd[n0 + p] = rs[j]; }
+      }
+    }
   }
+}
+template <typename T, int TT, int C, int LD>
+AMT_DEV void chain_ln_rows(const T* Xs, T* Ys, const float* __restrict__ w, const float* __restrict__ b,
+                           float* __restrict__ mean, float* __restrict__ rstd, long n0, long N, int tid) {
+  chain_ln_rows_impl<T, TT, C, LD, false>(Xs, Ys, nullptr, w, b, mean, rstd, n0, N, tid);
 }
 
 // The same, output rows to global memory (row-major, C features; rows >= N are not written): the LayerNorm of rows a
@@ -232,27 +255,7 @@ AMT_DEV void chain_ln_rows(const T* Xs, T* Ys, const float* __restrict__ w, cons
 template <typename T, int TT, int C, int LD>
 AMT_DEV void chain_ln_rows_out(const T* Xs, T* __restrict__ G, const float* __restrict__ w, const float* __restrict__ b,
                                float* __restrict__ mean, float* __restrict__ rstd, long n0, long N, int tid) {
-  constexpr int LPR = C / 8, RPP = 256 / LPR;
-  static_assert(TT % RPP == 0, "row phase covers the tile in whole passes");
-  const int sub = tid % LPR, prow = tid / LPR;
-  float wv[8], bv[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { wv[i] = w[sub * 8 + i]; bv[i] = b[sub * 8 + i]; }
-#pragma unroll
-  for (int pp = 0; pp < TT / RPP; ++pp) {
-    const int p = pp * RPP + prow;
-    float x[8];
-    load8f(Xs + p * LD + sub * 8, x);
-    float mu, rs;
-    ln_stats<8, LPR>(x, mu, rs);
-    float y[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = ln_apply(x[i], rs, wv[i], bv[i]);
-    if (n0 + p < N) {
-      store8f(G + (n0 + p) * C + sub * 8, y);
-      if (sub == 0) { mean[n0 + p] = mu; rstd[n0 + p] = rs; }
-    }
-  }
+  chain_ln_rows_impl<T, TT, C, LD, true>(Xs, nullptr, G, w, b, mean, rstd, n0, N, tid);
 }
 
 // Cooperative L2 warm-up of a weight range.  Every workgroup of a chain kernel streams the SAME

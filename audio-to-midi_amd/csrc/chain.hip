@@ -303,6 +303,14 @@ __global__ __launch_bounds__(256) void block_fwd_fused_kernel(BlockFwdArgs a) {
   block_fwd_tile<T, C, TT, SAVE, false>(a, (long)blockIdx.x * TT, (long)a.B * a.L, chain_smem);
 }
 
+// Inference, two independent workgroups per compute unit (256 registers each): one workgroup's row phase / GELU epilogue
+// runs under the other's products without a barrier tying them together (profiles/r03_notes.md section 7).
+template <typename T, int C, int TT>
+__global__ __launch_bounds__(256, 2) void block_fwd_occ2_kernel(BlockFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  block_fwd_tile<T, C, TT, false, false>(a, (long)blockIdx.x * TT, (long)a.B * a.L, chain_smem);
+}
+
 // ------------------------------------------------------------------ Block forward, a whole run of Blocks per launch
 // XCD-team form (team.h): the n Blocks of a CNN stage in ONE launch.  Clip b belongs to one XCD's team; Block j of
 // every clip of the team is evaluated tile by tile (the same tile body as above), then the team meets at its barrier:
@@ -400,12 +408,33 @@ static void block_fwd_fused_launch_tt(hipStream_t s, const BlockFwdArgs& a) {
   const int grid = (int)((N + TT - 1) / TT);
   hipLaunchKernelGGL((block_fwd_fused_kernel<T, C, TT, SAVE>), dim3(grid), dim3(256), lds, s, a);
 }
+template <typename T, int C, int TT>
+static void block_fwd_occ2_launch(hipStream_t s, const BlockFwdArgs& a) {
+  constexpr size_t lds = sizeof(T) * (size_t)TT * (2 * (C + 8) + (2 * C + 8));
+  static_assert(2 * lds <= 160 * 1024, "two workgroups per compute unit");
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(block_fwd_occ2_kernel<T, C, TT>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+  (void)once;
+  const long N = (long)a.B * a.L;
+  hipLaunchKernelGGL((block_fwd_occ2_kernel<T, C, TT>), dim3((int)((N + TT - 1) / TT)), dim3(256), lds, s, a);
+}
 template <typename T, int C, bool SAVE>
 static void block_fwd_fused_launch(hipStream_t s, const BlockFwdArgs& a) {
   if constexpr (SAVE) {
     block_fwd_fused_launch_tt<T, C, true, BlockTile<C>::TT>(s, a);
   } else {
     using IT = BlockInferTile<C, T>;
+    // AMT_BLOCK_OCC2: bit mask of the widths whose inference form runs as two independent workgroups per compute unit on
+    // half-length tiles (1: C = 16, 2: C = 64, 4: C = 128, 8: C = 256)
+    if constexpr (sizeof(T) == 2 && (C == 16 || C == 64 || C == 128 || C == 256)) {
+      // (default: all but C = 256, whose half-length form spills; measured at 448 windows x 5 s, profiles/r03_notes.md section 7:
+      // C = 128 alone 9.62 -> 9.08 ms per pass, C = 16 / 64 -0.1 ms each, C = 256 +0.5 ms.  Read on every call: the equality test switches it)
+      const char* oe = getenv("AMT_BLOCK_OCC2");
+      const int occ2 = oe ? atoi(oe) : 7;
+      constexpr int bit = C == 16 ? 1 : (C == 64 ? 2 : (C == 128 ? 4 : 8));
+      constexpr int TT2 = IT::LONG / 2;
+      if ((occ2 & bit) && (long)a.B * a.L >= 512L * TT2) { block_fwd_occ2_launch<T, C, TT2>(s, a); return; }
+    }
     // AMT_BLOCK_INF_LONG: bit mask of the widths that take the long tile (1: C = 64, 2: C = 128, 4: C = 256; default all)
     static const int long_mask = getenv("AMT_BLOCK_INF_LONG") ? atoi(getenv("AMT_BLOCK_INF_LONG")) : 7;
     const bool long_tiles = (long_mask & (C == 64 ? 1 : (C == 128 ? 2 : 4))) != 0;

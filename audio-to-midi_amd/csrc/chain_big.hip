@@ -101,8 +101,8 @@ AMT_DEV void big_copy_out(const T* Ps, T* __restrict__ G, int ldg, int c0, long 
 // wave buys is issue: one wave alone issues a vector instruction every 4 cycles, two alternate at 2, and one wave's GLU /
 // LayerNorm epilogues run under the other's products (in-kernel stamps of the WT = 1 form: 45 of 107 thousand cycles per
 // tile were epilogues with idle MFMA pipes, profiles/r03_notes.md).
-template <typename T, int TT, bool SAVE, int WT>
-__global__ __launch_bounds__(256 * WT, WT) void ffn_fwd_big_kernel(FfnFwdArgs a) {
+template <typename T, int TT, bool SAVE, int WT, bool LEAN = false>
+AMT_DEV void ffn_fwd_big_body(FfnFwdArgs& a) {
   a.seed = eff_seed(a.seed, a.seed_dev);
   constexpr int H = 256, I = 512, I2 = 1024, LDX = H + 8, SW = 64, LDG = SW + 8, NT = TT / 16 / WT, NS = I / SW;
   constexpr int KS1 = H / 32, KS2 = I / 32, TH = TT / WT;   // TH: tokens per wave / per 256-thread row-phase group
@@ -191,17 +191,27 @@ __global__ __launch_bounds__(256 * WT, WT) void ffn_fwd_big_kernel(FfnFwdArgs a)
   for (int s = 0; s < NS; ++s) {
     T* Gb = Gs + (s & 1) * TT * LDG;
     // the slice's W2 fragments: requested now, multiplied after the GLU epilogue
+    // (LEAN, two workgroups per compute unit: requested behind stage 1 - 32 registers fewer are live across it, and the
+    // other workgroup's instructions cover the shorter lead)
     Frag<T> w2[2][4];
+    if constexpr (!LEAN) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+      for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) w2[kk][rb] = wfrag(W2, 4 * wave + rb, KS2, 2 * s + kk, lane);
+        for (int rb = 0; rb < 4; ++rb) w2[kk][rb] = wfrag(W2, 4 * wave + rb, KS2, 2 * s + kk, lane);
+    }
     // stage 1: (u1 | u2) rows 128 s + 32 wave .. + 32 of the permuted W1, K = 256
     f32x4 uacc[2][NT];
     chain_zero(uacc);
     BIG_ACC(3);
     big_stage<T, 2, NT, KS1>(uacc, w1, Ah + r * LDX + 8 * g, LDX);
     BIG_ACC(4);
+    if constexpr (LEAN) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) w2[kk][rb] = wfrag(W2, 4 * wave + rb, KS2, 2 * s + kk, lane);
+    }
     // next slice's W1 fragments: on their way during the epilogue and stage 2
     if (s + 1 < NS) {
 #pragma unroll
@@ -276,6 +286,21 @@ __global__ __launch_bounds__(256 * WT, WT) void ffn_fwd_big_kernel(FfnFwdArgs a)
   BIG_ACC(9);
 }
 
+template <typename T, int TT, bool SAVE, int WT>
+__global__ __launch_bounds__(256 * WT, WT) void ffn_fwd_big_kernel(FfnFwdArgs a) { ffn_fwd_big_body<T, TT, SAVE, WT>(a); }
+// two independent four-wave workgroups per compute unit (256 registers each)
+template <typename T, int TT, bool SAVE>
+__global__ __launch_bounds__(256, 2) void ffn_fwd_big_occ2_kernel(FfnFwdArgs a) { ffn_fwd_big_body<T, TT, SAVE, 1, true>(a); }
+
+template <typename T, bool SAVE, int TT>
+static void ffn_fwd_big_occ2_launch(hipStream_t s, const FfnFwdArgs& a) {
+  constexpr size_t lds = sizeof(T) * (size_t)TT * ((256 + 8) + 2 * (64 + 8));
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_fwd_big_occ2_kernel<T, TT, SAVE>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+  (void)once;
+  hipLaunchKernelGGL((ffn_fwd_big_occ2_kernel<T, TT, SAVE>), dim3((a.N + TT - 1) / TT), dim3(256), lds, s, a);
+}
+
 template <typename T, bool SAVE, int TT, int WT>
 static void ffn_fwd_big_launch(hipStream_t s, const FfnFwdArgs& a) {
   constexpr size_t lds = sizeof(T) * (size_t)TT * ((256 + 8) + 2 * (64 + 8));
@@ -290,13 +315,19 @@ bool ffn_fwd_big(hipStream_t s, DType dt, const FfnFwdArgs& a, bool save) {
   const char* e = getenv("AMT_BIG");      // read on every call: the equality test switches it between contexts
   // 0: off; 1: four waves per tile; 2: eight; default: eight on 128-token tiles (measured at 112 000 tokens: 188 against
   // 196 us), four on 64-token tiles (16 000 tokens, training form: 43.8 against 51.3 us; the short-tile chain: 52 us)
-  const int mode = e ? atoi(e) : (a.N >= 49152 ? 2 : 1);
+  // 5: two independent four-wave workgroups per compute unit on 64-token tiles (bf16, from 49 152 tokens on: 175 against 187 us;
+  // at 16 000 tokens there is one tile per compute unit and the leaner register budget only costs: 8.99 against 8.83 ms/step)
+  const int mode = e ? atoi(e) : (a.N >= 49152 ? (dt == DT_F32 ? 2 : 5) : 1);
   if (mode == 0 || a.W1 == nullptr || a.N < 8192) return false;
   const double N = a.N, es = dt == DT_F32 ? 4 : 2;
   ProfScope ps(s, "ffn_fwd_big", 2.0 * N * (256.0 * 256 + 1024.0 * 256 + 256.0 * 512),
                (N * 256.0 * (save ? 6 : 3) + (save ? N * (1024.0 + 512) : 0.0) + 256.0 * 256 + 1024.0 * 256 + 256.0 * 512) * es);
   // 128-token tiles from ~2 tiles per compute unit on, 64-token tiles below (16 000 tokens = 32 clips per GPU: 250 tiles)
   const bool long_tile = a.N >= 49152;
+  if (mode == 5 && dt != DT_F32) {
+    if (save) ffn_fwd_big_occ2_launch<bf16, true, 64>(s, a); else ffn_fwd_big_occ2_launch<bf16, false, 64>(s, a);
+    return true;
+  }
 #define AMT_FFN_BIG(T_, TL_, TS_)                                                                                   \
   do {                                                                                                               \
     if (mode == 1) {                                                                                                 \

@@ -580,6 +580,27 @@ def test_large_n_chains_equal_the_short_tile_chains(small_conf, dtype, monkeypat
     assert rel < (1e-5 if dtype == "float32" else 1e-3), rel
 
 
+def test_streaming_size_inference_forms_equal_the_short_tile_chains(small_conf, monkeypatch):
+    """From 49 152 tokens on (streaming inference, BASELINE configs[3]) the bf16 forward runs `ffn_fwd_big` as two independent
+    workgroups per compute unit on 64-token tiles and the C = 16 / 64 / 128 Blocks as two workgroups per compute unit on
+    half-length tiles (csrc/chain_big.hip mode 5, csrc/chain.hip block_fwd_occ2_kernel).  Same products in the same order:
+    the logits of 200 windows x 5 s (50 000 tokens, ragged last tiles) equal the short-tile chains' bit for bit."""
+    audio, _ = synth.make_batch_fast(200, 80000, seed=21)
+    a = torch.from_numpy(audio).to("cuda", torch.bfloat16)
+    outs = {}
+    for name, big, occ2 in (("new", None, None), ("old", "0", "0")):
+        if big is None:
+            monkeypatch.delenv("AMT_BIG", raising=False); monkeypatch.delenv("AMT_BLOCK_OCC2", raising=False)
+        else:
+            monkeypatch.setenv("AMT_BIG", big); monkeypatch.setenv("AMT_BLOCK_OCC2", occ2)
+        model = amt.OutputSequenceGenerator(small_conf, key=5, dtype="bfloat16", gamma=1.0)
+        logits, _ = model.predict(None, a)
+        outs[name] = logits.clone()
+        model.close()
+    assert torch.isfinite(outs["new"]).all()
+    assert torch.equal(outs["new"], outs["old"])
+
+
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
 def test_attention_backward_keep_bits_equal_the_rehashed_masks(small_conf, dtype, monkeypatch):
     """Round 3: the global-attention forward leaves the keep decisions of its weight dropout as one bit per score and
