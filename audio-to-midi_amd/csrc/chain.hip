@@ -558,8 +558,17 @@ void block_fwd_fused(hipStream_t s, DType dt, const BlockFwdArgs& a) {
 #ifndef AMT_BB256_TT
 #define AMT_BB256_TT 16
 #endif
+#ifndef AMT_BB128_TT
+#define AMT_BB128_TT 32
+#endif
+#ifndef AMT_BB64_TT
+#define AMT_BB64_TT 64
+#endif
 template <typename T, int C> struct BlockBwdTile {   // == DwTile<C>::ROWS of the unfused kernel
-  static constexpr int TT = (C == 16 && sizeof(T) == 2) ? AMT_BB16_TT : (C <= 32 ? 128 : (C <= 64 ? 64 : (C == 256 && (sizeof(T) == 4 || AMT_BB256_TT == 16) ? 16 : 32)));
+  static constexpr int TT = (C == 16 && sizeof(T) == 2) ? AMT_BB16_TT
+                            : (C <= 32 ? 128
+                               : (C <= 64 ? (sizeof(T) == 2 ? AMT_BB64_TT : 64)
+                                  : (C == 256 ? ((sizeof(T) == 4 || AMT_BB256_TT == 16) ? 16 : 32) : (sizeof(T) == 2 ? AMT_BB128_TT : 32))));
 };
 
 template <typename T, int C, int TT>
@@ -857,7 +866,7 @@ static void block_bwd_fused_launch(hipStream_t s, const BlockBwdArgs& a, const W
 
 int block_bwd_fused_tile_len(DType dt, int C) {
   if (dt == DT_F32) return (C <= 32 ? 128 : (C <= 64 ? 64 : (C == 256 ? 16 : 32))) - 6;
-  return (C == 16 ? AMT_BB16_TT : (C <= 32 ? 128 : (C <= 64 ? 64 : (C == 256 ? AMT_BB256_TT : 32)))) - 6;
+  return (C == 16 ? AMT_BB16_TT : (C <= 32 ? 128 : (C <= 64 ? AMT_BB64_TT : (C == 256 ? AMT_BB256_TT : AMT_BB128_TT)))) - 6;
 }
 
 void block_bwd_fused(hipStream_t s, DType dt, const BlockBwdArgs& a_in, float* dlnw, float* dlnb, float* dwdw,

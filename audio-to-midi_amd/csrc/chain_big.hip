@@ -316,7 +316,8 @@ bool ffn_fwd_big(hipStream_t s, DType dt, const FfnFwdArgs& a, bool save) {
   // 0: off; 1: four waves per tile; 2: eight; default: eight on 128-token tiles (measured at 112 000 tokens: 188 against
   // 196 us), four on 64-token tiles (16 000 tokens, training form: 43.8 against 51.3 us; the short-tile chain: 52 us)
   // 5: two independent four-wave workgroups per compute unit on 64-token tiles (bf16, from 49 152 tokens on: 175 against 187 us;
-  // at 16 000 tokens there is one tile per compute unit and the leaner register budget only costs: 8.99 against 8.83 ms/step)
+  // at 16 000 tokens there is one tile per compute unit and the leaner register budget only costs: 8.99 against 8.83 ms/step;
+  // 32-token tiles, two per compute unit, at 16 000 / 32 000 tokens: 41.4 / 76 us against 38.4 / 72 us for mode 1)
   const int mode = e ? atoi(e) : (a.N >= 49152 ? (dt == DT_F32 ? 2 : 5) : 1);
   if (mode == 0 || a.W1 == nullptr || a.N < 8192) return false;
   const double N = a.N, es = dt == DT_F32 ? 4 : 2;
@@ -328,6 +329,7 @@ bool ffn_fwd_big(hipStream_t s, DType dt, const FfnFwdArgs& a, bool save) {
     if (save) ffn_fwd_big_occ2_launch<bf16, true, 64>(s, a); else ffn_fwd_big_occ2_launch<bf16, false, 64>(s, a);
     return true;
   }
+
 #define AMT_FFN_BIG(T_, TL_, TS_)                                                                                   \
   do {                                                                                                               \
     if (mode == 1) {                                                                                                 \

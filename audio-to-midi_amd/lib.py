@@ -139,16 +139,17 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("AMT_HIP_LIB", LIB_PATH)      # (another build of the same sources: tile-size variants for A/B runs, timing builds)
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} not found: the HIP extension is not built.  Run `python __graft_entry__.py` "
+            f"{path} not found: the HIP extension is not built.  Run `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+            raise ImportError(f"{path} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
     _lib = lib

@@ -68,7 +68,7 @@ int main(int argc, char** argv) {
 #ifdef AMT_BIG_TIMING
     (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(amt_big_stamps), st.size() * 8);
 #endif
-    const int tile = (*mp == '3' || *mp == '5') ? 64 : (*mp == '4') ? 128 : (N >= 49152 ? 128 : 64);
+    const int tile = (*mp == '6') ? 32 : (*mp == '3' || *mp == '5') ? 64 : (*mp == '4') ? 128 : (N >= 49152 ? 128 : 64);
     const int nwg = (N + tile - 1) / tile < 4096 ? (N + tile - 1) / tile : 4096;
     double acc[16] = {0};
     for (int w = 0; w < nwg; ++w) for (int k = 0; k < 16; ++k) acc[k] += (double)st[(size_t)w * 16 + k];
