@@ -145,8 +145,11 @@ AMT_DEV size_t keepbits_index(int b, int H, int h, int ntile, int kt, int q) {
 // cycles of VALU issue.
 // DROP: attention dropout compiled in or out (a run-time test per score quad splits the softmax into 16 basic blocks per
 // key tile, which the scheduler cannot move work across)
+#ifndef AMT_ATTN_FWD1_OCC
+#define AMT_ATTN_FWD1_OCC 1
+#endif
 template <typename T, int NG, bool DROP>
-__global__ __launch_bounds__(256 * NG) void attn_global_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256 * NG, NG == 1 ? AMT_ATTN_FWD1_OCC : 1) void attn_global_fwd_kernel(AttnArgs a) {
   a.seed = eff_seed(a.seed, a.seed_dev);   // kernel argument + the context's device seed word (common.h)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid_all = threadIdx.x, half = tid_all >> 8, tid = tid_all & 255;   // half = key-tile group 0 .. NG-1
@@ -853,7 +856,10 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
 
 // blocks [0, ntile) of a (clip, head) compute dQ, blocks [ntile, 2 ntile) dK/dV
 template <typename T, int NG, bool DROP, bool BITS>
-__global__ __launch_bounds__(256 * NG, 2 * NG) void attn_global_bwd_kernel(AttnBwdArgs ba, int ntile) {
+#ifndef AMT_ATTN_BWD_OCC
+#define AMT_ATTN_BWD_OCC 2
+#endif
+__global__ __launch_bounds__(256 * NG, (sizeof(T) == 2 ? AMT_ATTN_BWD_OCC : 2) * NG) void attn_global_bwd_kernel(AttnBwdArgs ba, int ntile) {
   ba.f.seed = eff_seed(ba.f.seed, ba.f.seed_dev);   // kernel argument + the context's device seed word (common.h)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // XCD-aware order: the 2 * ntile workgroups of one (clip, head) share its Q/K/V/dO: same id % 8
