@@ -199,7 +199,9 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? AMT_ATTN_FWD1_OCC : 1) void att
     __syncthreads();
     if (active) kv_store<T>(Ks, Vs, kc, vc, rr, S, kt, tid);
     __syncthreads();
+#ifndef AMT_ABL_NOLOAD
     if (kt + NG < nkt) kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, kt + NG, tid, a.cos, a.sin);
+#endif
 
     if (active) {
       f32x4 sacc[4];
@@ -610,7 +612,9 @@ AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, int b, int
     __syncthreads();
     if (active) kv_store<T>(Ks, Vs, kc, vc, rr, S, kt, tid);
     __syncthreads();
+#ifndef AMT_ABL_NOLOAD
     if (kt + NG < nkt) kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, kt + NG, tid, a.cos, a.sin);
+#endif
     uint32_t kw[2] = {0u, 0u};             // this query's keep bits for the tile, shifted so that bit 16 (st & 1) + e is key (st, e)
     if (DROP && BITS && active) {
       const unsigned long long w = a.keepbits[keepbits_index(b, a.H, h, nkt, kt, qrow)];
@@ -725,54 +729,72 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
   for (int i = 0; i < 4; ++i) { dkacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const int nqt = (S + 63) / 64, niter = (nqt + NG - 1) / NG;
+  // The query tile of iteration it + 1 (q, dO, O rows, their RoPE entries, lse, keep words) is requested while tile it is
+  // multiplied and goes to LDS at the top of the next iteration (as the dQ role does with its K / V tiles): requested at
+  // the top of its own iteration, every one of the 8 tiles exposed a full memory round trip behind a barrier.
+  Chunk8<T> qc8[2], dc8[2], oc8[2];
+  RopeRegs qrr;
+  float lse_r = 0.f;
+  unsigned long long kw_r = 0ull;
+  auto q_load = [&](int qt) {
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+      const int id = tid + 256 * i2, row = id >> 3, c = id & 7;
+      const int q = qt * 64 + row, qcl = q < S ? q : S - 1;
+      qc8[i2] = chunk_load(QC + (size_t)(b * S + qcl) * a.ldqc + h * 64 + 8 * c);
+      dc8[i2] = chunk_load(dO + (size_t)(b * S + qcl) * ba.lddo + h * 64 + 8 * c);
+      oc8[i2] = chunk_load(O + (size_t)(b * S + qcl) * a.ldo + h * 64 + 8 * c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { qrr.c[i2][j] = a.cos[qcl * 32 + 4 * c + j]; qrr.s[i2][j] = a.sin[qcl * 32 + 4 * c + j]; }
+    }
+    if (tid < 64) {
+      const int q = qt * 64 + tid;
+      lse_r = a.LSE[(size_t)(b * a.H + h) * S + (q < S ? q : S - 1)];
+      if (DROP && BITS) kw_r = a.keepbits[keepbits_index(b, a.H, h, nqt, tile, q)];   // this key tile's keep words of the 64 queries: 512 contiguous bytes
+    }
+  };
+  auto q_store = [&](int qt) {
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+      const int id = tid + 256 * i2, row = id >> 3, c = id & 7;
+      const int q = qt * 64 + row;
+      float qx[8], dch[8], och[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { qx[i] = chunk_get(qc8[i2], i); dch[i] = chunk_get(dc8[i2], i); och[i] = chunk_get(oc8[i2], i); }
+      if (q < S) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rope_pair(qx[2 * j], qx[2 * j + 1], qrr.c[i2][j], qrr.s[i2][j], 1.f);   // = rope8
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qx[i] = to_f(from_f<T>(qx[i])) * 0.125f;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { qx[i] = 0.f; dch[i] = 0.f; och[i] = 0.f; }
+      }
+      store8f(Qs + row * ALD + 8 * c, qx);
+      store8f(dOs + row * ALD + 8 * c, dch);
+      // delta[q] = sum_d dO[q][d] O[q][d] (8 lanes share a row), so this role does not depend on
+      // the dQ role and both run in one launch
+      float part = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) part += dch[i] * och[i];
+      part = group_sum<8>(part);
+      if (c == 0) delta_s[row] = part;
+    }
+    if (tid < 64) {
+      lse_s[tid] = (qt * 64 + tid < S) ? lse_r : 0.f;
+      if (DROP && BITS) { kb_s[tid] = (uint32_t)kw_r; kb_s[64 + tid] = (uint32_t)(kw_r >> 32); }
+    }
+  };
+  if (half < nqt) q_load(half);
   for (int it = 0; it < niter; ++it) {
     const int qt = NG * it + half;
     const bool active = qt < nqt;
     __syncthreads();
-    if (active) {
-      float qx[2][8], dch[2][8], och[2][8];
-#pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2) {
-        int id = tid + 256 * i2, row = id >> 3, c = id & 7;
-        int q = qt * 64 + row;
-        int qc = q < S ? q : S - 1;
-        load8f(QC + (size_t)(b * S + qc) * a.ldqc + h * 64 + 8 * c, qx[i2]);
-        load8f(dO + (size_t)(b * S + qc) * ba.lddo + h * 64 + 8 * c, dch[i2]);
-        load8f(O + (size_t)(b * S + qc) * a.ldo + h * 64 + 8 * c, och[i2]);
-      }
-#pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2) {
-        int id = tid + 256 * i2, row = id >> 3, c = id & 7;
-        int q = qt * 64 + row;
-        if (q < S) {
-          rope8(qx[i2], a.cos, a.sin, q, 4 * c, 1.f);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) qx[i2][i] = to_f(from_f<T>(qx[i2][i])) * 0.125f;
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) { qx[i2][i] = 0.f; dch[i2][i] = 0.f; och[i2][i] = 0.f; }
-        }
-        store8f(Qs + row * ALD + 8 * c, qx[i2]);
-        store8f(dOs + row * ALD + 8 * c, dch[i2]);
-        // delta[q] = sum_d dO[q][d] O[q][d] (8 lanes share a row), so this role does not depend on
-        // the dQ role and both run in one launch
-        float part = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) part += dch[i2][i] * och[i2][i];
-        part = group_sum<8>(part);
-        if (c == 0) delta_s[row] = part;
-      }
-      if (tid < 64) {
-        int q = qt * 64 + tid;
-        lse_s[tid] = (q < S) ? a.LSE[(size_t)(b * a.H + h) * S + q] : 0.f;
-        if (DROP && BITS) {       // this key tile's keep words of the 64 queries: 512 contiguous bytes
-          const unsigned long long w = a.keepbits[keepbits_index(b, a.H, h, nqt, tile, q)];
-          kb_s[tid] = (uint32_t)w;
-          kb_s[64 + tid] = (uint32_t)(w >> 32);
-        }
-      }
-    }
+    if (active) q_store(qt);
     __syncthreads();
+#ifndef AMT_ABL_NOLOAD
+    if (qt + NG < nqt) q_load(qt + NG);
+#endif
     if (active) {
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
