@@ -86,7 +86,7 @@ struct RopeRegs { float c[2][4], s[2][4]; };
 
 template <typename T>
 AMT_DEV void kv_load(Chunk8<T> (&kc)[2], Chunk8<T> (&vc)[2], RopeRegs& rr, const T* KV, int ldkv, int b, int h, int S,
-                     int kt, int tid, const float* __restrict__ cs, const float* __restrict__ sn) {
+                     int kt, int tid, const float* __restrict__ cs, const float* __restrict__ sn, bool rot = true) {
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     int id = tid + 256 * it, row = id >> 3, c = id & 7;
@@ -95,13 +95,16 @@ AMT_DEV void kv_load(Chunk8<T> (&kc)[2], Chunk8<T> (&vc)[2], RopeRegs& rr, const
     const T* kp = KV + (size_t)(b * S + keyc) * ldkv + h * 64 + 8 * c;
     kc[it] = chunk_load(kp);
     vc[it] = chunk_load(kp + 256);
+    if (rot) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { rr.c[it][j] = cs[keyc * 32 + 4 * c + j]; rr.s[it][j] = sn[keyc * 32 + 4 * c + j]; }
+      for (int j = 0; j < 4; ++j) { rr.c[it][j] = cs[keyc * 32 + 4 * c + j]; rr.s[it][j] = sn[keyc * 32 + 4 * c + j]; }
+    }
   }
 }
+// rot = false: k arrives rotated and rounded (AttnArgs::prerot): the tile is copied
 template <typename T>
 AMT_DEV void kv_store(T* Ks, T* Vs, const Chunk8<T> (&kc)[2], const Chunk8<T> (&vc)[2], const RopeRegs& rr, int S, int kt,
-                      int tid) {
+                      int tid, bool rot = true) {
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     int id = tid + 256 * it, row = id >> 3, c = id & 7;
@@ -110,9 +113,13 @@ AMT_DEV void kv_store(T* Ks, T* Vs, const Chunk8<T> (&kc)[2], const Chunk8<T> (&
 #pragma unroll
     for (int i = 0; i < 8; ++i) kx[i] = chunk_get(kc[it], i);
     if (key < S) {
+      if (rot) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) rope_pair(kx[2 * j], kx[2 * j + 1], rr.c[it][j], rr.s[it][j], 1.f);   // = rope8
-      store8f(Ks + row * ALD + 8 * c, kx);
+        for (int j = 0; j < 4; ++j) rope_pair(kx[2 * j], kx[2 * j + 1], rr.c[it][j], rr.s[it][j], 1.f);   // = rope8
+        store8f(Ks + row * ALD + 8 * c, kx);
+      } else {
+        chunk_store(Ks + row * ALD + 8 * c, kc[it]);
+      }
       chunk_store(Vs + row * ALD + 8 * c, vc[it]);
     } else {
       chunk_store(Ks + row * ALD + 8 * c, chunk_zero<T>());
@@ -167,6 +174,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? AMT_ATTN_FWD1_OCC : 1) void att
   const T* QC = reinterpret_cast<const T*>(a.QC);
   const T* KV = reinterpret_cast<const T*>(a.KV);
   T* Pw = Ps + wave * 16 * ALD;
+  const bool rot = a.prerot == 0;          // q / k arrive raw: rotate while staging
 
   Frag<T> qf[2];
 #pragma unroll
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? AMT_ATTN_FWD1_OCC : 1) void att
     for (int i = 0; i < 8; ++i) x[i] = 0.f;
     if (qrow < S) {
       load8f(QC + (size_t)(b * S + qrow) * a.ldqc + h * 64 + 32 * ks + 8 * g, x);
-      rope8(x, a.cos, a.sin, qrow, 16 * ks + 4 * g, 1.f);
+      if (rot) rope8(x, a.cos, a.sin, qrow, 16 * ks + 4 * g, 1.f);
       // reference: rope output is cast to the activation dtype, then divided by sqrt(64) (exact)
 #pragma unroll
       for (int i = 0; i < 8; ++i) x[i] = to_f(from_f<T>(x[i])) * 0.125f;
@@ -192,15 +200,15 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? AMT_ATTN_FWD1_OCC : 1) void att
   const int nkt = (S + 63) / 64, niter = (nkt + NG - 1) / NG;
   Chunk8<T> kc[2], vc[2];
   RopeRegs rr;
-  if (half < nkt) kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, half, tid, a.cos, a.sin);
+  if (half < nkt) kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, half, tid, a.cos, a.sin, rot);
   for (int it = 0; it < niter; ++it) {
     const int kt = NG * it + half;
     const bool active = kt < nkt;            // uniform over the group; barriers are taken by all 512 threads
     __syncthreads();
-    if (active) kv_store<T>(Ks, Vs, kc, vc, rr, S, kt, tid);
+    if (active) kv_store<T>(Ks, Vs, kc, vc, rr, S, kt, tid, rot);
     __syncthreads();
 #ifndef AMT_ABL_NOLOAD
-    if (kt + NG < nkt) kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, kt + NG, tid, a.cos, a.sin);
+    if (kt + NG < nkt) kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, kt + NG, tid, a.cos, a.sin, rot);
 #endif
 
     if (active) {
@@ -569,6 +577,7 @@ AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, int b, int
   const T* O = reinterpret_cast<const T*>(a.O);
   const T* dO = reinterpret_cast<const T*>(ba.dO);
   T* Pw = Ps + wave * 16 * ALD;
+  const bool rot = a.prerot == 0;          // q / k arrive raw: rotate while staging
 
   Frag<T> qf[2], dof[2];
   float dl = 0.f;
@@ -580,7 +589,7 @@ AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, int b, int
     if (qrow < S) {
       int off = h * 64 + 32 * ks + 8 * g;
       load8f(QC + (size_t)(b * S + qrow) * a.ldqc + off, x);
-      rope8(x, a.cos, a.sin, qrow, 16 * ks + 4 * g, 1.f);
+      if (rot) rope8(x, a.cos, a.sin, qrow, 16 * ks + 4 * g, 1.f);
 #pragma unroll
       for (int i = 0; i < 8; ++i) x[i] = to_f(from_f<T>(x[i])) * 0.125f;
       load8f(dO + (size_t)(b * S + qrow) * ba.lddo + off, d);
@@ -605,15 +614,15 @@ AMT_DEV void attn_global_bwd_dq_body(const AttnBwdArgs& ba, int tile, int b, int
   const int nkt = (S + 63) / 64, niter = (nkt + NG - 1) / NG;
   Chunk8<T> kc[2], vc[2];
   RopeRegs rr;
-  if (half < nkt) kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, half, tid, a.cos, a.sin);
+  if (half < nkt) kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, half, tid, a.cos, a.sin, rot);
   for (int it = 0; it < niter; ++it) {
     const int kt = NG * it + half;
     const bool active = kt < nkt;          // uniform over the group; every thread of the workgroup takes the barriers
     __syncthreads();
-    if (active) kv_store<T>(Ks, Vs, kc, vc, rr, S, kt, tid);
+    if (active) kv_store<T>(Ks, Vs, kc, vc, rr, S, kt, tid, rot);
     __syncthreads();
 #ifndef AMT_ABL_NOLOAD
-    if (kt + NG < nkt) kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, kt + NG, tid, a.cos, a.sin);
+    if (kt + NG < nkt) kv_load<T>(kc, vc, rr, KV, a.ldkv, b, h, S, kt + NG, tid, a.cos, a.sin, rot);
 #endif
     uint32_t kw[2] = {0u, 0u};             // this query's keep bits for the tile, shifted so that bit 16 (st & 1) + e is key (st, e)
     if (DROP && BITS && active) {
@@ -708,6 +717,7 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
   const T* O = reinterpret_cast<const T*>(a.O);
   T* PTw = PT + wave * 16 * ALD;
   T* dSTw = dST + wave * 16 * ALD;
+  const bool rot = a.prerot == 0;          // q / k arrive raw: rotate while staging
 
   Frag<T> kf[2], vf[2];
 #pragma unroll
@@ -718,7 +728,7 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
     if (key < S) {
       const T* kp = KV + (size_t)(b * S + key) * a.ldkv + h * 64 + 32 * ks + 8 * g;
       load8f(kp, x);
-      rope8(x, a.cos, a.sin, key, 16 * ks + 4 * g, 1.f);
+      if (rot) rope8(x, a.cos, a.sin, key, 16 * ks + 4 * g, 1.f);
       load8f(kp + 256, v);
     }
     kf[ks] = make_frag<T>(x);
@@ -744,8 +754,10 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
       qc8[i2] = chunk_load(QC + (size_t)(b * S + qcl) * a.ldqc + h * 64 + 8 * c);
       dc8[i2] = chunk_load(dO + (size_t)(b * S + qcl) * ba.lddo + h * 64 + 8 * c);
       oc8[i2] = chunk_load(O + (size_t)(b * S + qcl) * a.ldo + h * 64 + 8 * c);
+      if (rot) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { qrr.c[i2][j] = a.cos[qcl * 32 + 4 * c + j]; qrr.s[i2][j] = a.sin[qcl * 32 + 4 * c + j]; }
+        for (int j = 0; j < 4; ++j) { qrr.c[i2][j] = a.cos[qcl * 32 + 4 * c + j]; qrr.s[i2][j] = a.sin[qcl * 32 + 4 * c + j]; }
+      }
     }
     if (tid < 64) {
       const int q = qt * 64 + tid;
@@ -762,8 +774,10 @@ AMT_DEV void attn_global_bwd_dkv_body(const AttnBwdArgs& ba, int tile, int b, in
 #pragma unroll
       for (int i = 0; i < 8; ++i) { qx[i] = chunk_get(qc8[i2], i); dch[i] = chunk_get(dc8[i2], i); och[i] = chunk_get(oc8[i2], i); }
       if (q < S) {
+        if (rot) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rope_pair(qx[2 * j], qx[2 * j + 1], qrr.c[i2][j], qrr.s[i2][j], 1.f);   // = rope8
+          for (int j = 0; j < 4; ++j) rope_pair(qx[2 * j], qx[2 * j + 1], qrr.c[i2][j], qrr.s[i2][j], 1.f);   // = rope8
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) qx[i] = to_f(from_f<T>(qx[i])) * 0.125f;
       } else {

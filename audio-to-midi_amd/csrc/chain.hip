@@ -1163,8 +1163,93 @@ void ffn_fwd_fused(hipStream_t s, DType dt, const FfnFwdArgs& a) {
 // ------------------------------------------------------------------ transformer layer, first half, forward
 // XLDS != nullptr: the tile's x rows are already in LDS (panel [TT][H + 8] left by the chain that produced them in the
 // same launch: ffn_qkv_fwd_fused) and are copied from there instead of from a.X.
-template <typename T, int TT>
-AMT_DEV void qkv_fwd_body(const QkvFwdArgs& a, unsigned char* chain_smem, const T* XLDS) {
+// RoPE table entries of the tile for the rotated form of q / k (QkvFwdArgs::rope_cos): the (cos, sin) pairs of this lane's
+// feature quads, requested where the launch starts (the boundary launch: in front of the FFN body) so that the epilogues
+// that rotate find them in registers.
+// MODE 0: no rotation (local layers; an empty struct: the instantiation carries no registers for it); 1: entries requested
+// at the start of the launch and held in registers (16-token tiles: one workgroup per compute unit, the latency would be
+// exposed in front of the epilogues); 2: entries loaded where the epilogues use them (longer tiles: two workgroups per compute
+// unit, and 100 more registers would leave only one; the tile's table rows are staged in LDS - TT x 64 floats behind the three
+// panels - and read from there: loaded from L2 at every use, the rotated 32-token kernel ran 88 against 65 us at 112 000 tokens).
+template <int TT, int MODE> struct QkvRope {
+  using SQ = ChainSplit<320, TT>;
+  using SK = ChainSplit<512, TT>;
+  static constexpr int NQ = MODE == 1 ? SQ::RB : 1, NQT = MODE == 1 ? SQ::NT : 1, NK = MODE == 1 ? SK::RB : 1, NKT = MODE == 1 ? SK::NT : 1;
+  float2 qc[NQ][NQT], qs[NQ][NQT], kc[NK][NKT], ks[NK][NKT];
+  static AMT_DEV int pos_of(const QkvFwdArgs& a, long row) { return (int)((row < a.N ? row : (long)a.N - 1) % a.rope_S); }
+  AMT_DEV void load(const QkvFwdArgs& a) {
+    if constexpr (MODE == 1) {
+      const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+      const long n0 = (long)blockIdx.x * TT;
+      const int mQ = (wave % SQ::WF) * SQ::RB * 16, tQ = (wave / SQ::WF) * SQ::NT * 16;
+      const int mK = (wave % SK::WF) * SK::RB * 16, tK = (wave / SK::WF) * SK::NT * 16;
+#pragma unroll
+      for (int ti = 0; ti < SQ::NT; ++ti) {
+        const int pos = pos_of(a, n0 + tQ + 16 * ti + r);
+#pragma unroll
+        for (int rb = 0; rb < SQ::RB; ++rb) {
+          const int m = mQ + 16 * rb + 4 * g;
+          if (m < 256) {                                  // uniform over the wave (16-row blocks)
+            qc[rb][ti] = *reinterpret_cast<const float2*>(a.rope_cos + pos * 32 + ((m & 63) >> 1));
+            qs[rb][ti] = *reinterpret_cast<const float2*>(a.rope_sin + pos * 32 + ((m & 63) >> 1));
+          }
+        }
+      }
+      if (mK < 256) {                                     // uniform over the wave: the k half of kv
+#pragma unroll
+        for (int ti = 0; ti < SK::NT; ++ti) {
+          const int pos = pos_of(a, n0 + tK + 16 * ti + r);
+#pragma unroll
+          for (int rb = 0; rb < SK::RB; ++rb) {
+            const int m = mK + 16 * rb + 4 * g;
+            kc[rb][ti] = *reinterpret_cast<const float2*>(a.rope_cos + pos * 32 + ((m & 63) >> 1));
+            ks[rb][ti] = *reinterpret_cast<const float2*>(a.rope_sin + pos * 32 + ((m & 63) >> 1));
+          }
+        }
+      }
+    }
+  }
+  // (cos, sin) pairs of feature quad m .. m + 3 of global row `row`; K selects the k table of MODE 1
+  template <bool K> AMT_DEV void get(const QkvFwdArgs& a, int rb, int ti, long row, int m, float2& c, float2& s) const {
+    if constexpr (MODE == 1) {
+      c = K ? kc[rb][ti] : qc[rb][ti];
+      s = K ? ks[rb][ti] : qs[rb][ti];
+    } else {
+      const float* rp = lds_rows + (int)(row - (long)blockIdx.x * TT) * 64 + ((m & 63) >> 1);
+      c = *reinterpret_cast<const float2*>(rp);
+      s = *reinterpret_cast<const float2*>(rp + 32);
+    }
+  }
+  // MODE 2: [TT][cos 32 | sin 32] of the tile's rows, staged by stage_rows (visible behind the body's first barrier)
+  const float* lds_rows = nullptr;
+  AMT_DEV void stage_rows(const QkvFwdArgs& a, float* dst) {
+    if constexpr (MODE == 2) {
+      lds_rows = dst;
+      const long n0 = (long)blockIdx.x * TT;
+      for (int id = threadIdx.x; id < TT * 16; id += 256) {
+        const int p = id >> 4, q = id & 15;                 // row, 16-byte granule: 0..7 cos, 8..15 sin
+        const int pos = pos_of(a, n0 + p);
+        const float* src = (q < 8 ? a.rope_cos : a.rope_sin) + pos * 32 + 4 * (q & 7);
+        *reinterpret_cast<f32x4*>(dst + p * 64 + 4 * q) = *reinterpret_cast<const f32x4*>(src);
+      }
+    }
+  }
+};
+// rotate the two interleaved pairs of a feature quad as the attention kernels do while staging (attn.hip: rope_pair):
+// the value as stored (rounded to T), the explicit rounding sequence, the result rounded to T by the store that follows
+template <typename T>
+AMT_DEV void rope_quad(float (&v)[4], float2 c, float2 s) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float x1 = to_f(from_f<T>(v[2 * j])), x2 = to_f(from_f<T>(v[2 * j + 1]));
+    const float cj = j == 0 ? c.x : c.y, sj = j == 0 ? s.x : s.y;
+    v[2 * j] = __fmaf_rn(x1, cj, -__fmul_rn(x2, sj));          // (rope_pair's scale is 1 here: the product by it is exact and dropped)
+    v[2 * j + 1] = __fmaf_rn(x1, sj, __fmul_rn(x2, cj));
+  }
+}
+
+template <typename T, int TT, int RM>
+AMT_DEV void qkv_fwd_body(const QkvFwdArgs& a, unsigned char* chain_smem, const T* XLDS, QkvRope<TT, RM>& rope) {
   constexpr int H = 256, QC = 320, CK = 64, KV = 512, LDX = H + 8, LDQ = QC + 8, LDK = KV + 8;
   using SQ = ChainSplit<QC, TT>;
   using SK = ChainSplit<KV, TT>;
@@ -1172,6 +1257,7 @@ AMT_DEV void qkv_fwd_body(const QkvFwdArgs& a, unsigned char* chain_smem, const 
   T* Xs = reinterpret_cast<T*>(chain_smem);   // [TT][LDX]  x, then LN1(x) in place
   T* Qs = Xs + TT * LDX;                      // [TT][LDQ]  qc
   T* Ks = Qs + TT * LDQ;                      // [TT][LDK]  kv
+  rope.stage_rows(a, reinterpret_cast<float*>(Ks + TT * LDK));   // (rotated long-tile form: [TT][64] floats behind the panels)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -1220,6 +1306,13 @@ AMT_DEV void qkv_fwd_body(const QkvFwdArgs& a, unsigned char* chain_smem, const 
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = acc[rb][ti][i];
+        if constexpr (RM != 0) {
+          if (mQ + 16 * rb < 256) {
+            float2 rc, rs;
+            rope.template get<false>(a, rb, ti, n0 + tQ + 16 * ti + r, mQ + 16 * rb + 4 * g, rc, rs);
+            rope_quad<T>(v, rc, rs);
+          }
+        }
         store4f(Qs + (tQ + 16 * ti + r) * LDQ + mQ + 16 * rb + 4 * g, v);
       }
   }
@@ -1239,6 +1332,13 @@ AMT_DEV void qkv_fwd_body(const QkvFwdArgs& a, unsigned char* chain_smem, const 
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = acc[rb][ti][i];
+        if constexpr (RM != 0) {
+          if (mK < 256) {
+            float2 rc, rs;
+            rope.template get<true>(a, rb, ti, n0 + tK + 16 * ti + r, mK + 16 * rb + 4 * g, rc, rs);
+            rope_quad<T>(v, rc, rs);
+          }
+        }
         store4f(Ks + (tK + 16 * ti + r) * LDK + mK + 16 * rb + 4 * g, v);
       }
   }
@@ -1250,38 +1350,47 @@ AMT_DEV void qkv_fwd_body(const QkvFwdArgs& a, unsigned char* chain_smem, const 
   AMT_STAMP_RT(7);
 }
 
-template <typename T, int TT>
-__global__ __launch_bounds__(256) void qkv_fwd_fused_kernel(QkvFwdArgs a) {
+template <typename T, int TT, int RM>
+__global__ __launch_bounds__(256, (RM == 2 && TT == 32 && sizeof(T) == 2) ? 2 : 1) void qkv_fwd_fused_kernel(QkvFwdArgs a) {   // (the rotated long-tile form keeps the raw form's two workgroups per compute unit)
   extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
-  qkv_fwd_body<T, TT>(a, chain_smem, nullptr);
+  QkvRope<TT, RM> rope;
+  rope.load(a);
+  qkv_fwd_body<T, TT, RM>(a, chain_smem, nullptr, rope);
 }
 
 // Layer boundary in one launch: the second half of layer l (ffn_fwd_body, FULL) followed, for the same token tile, by the
 // first half of layer l + 1 up to its attention core (qkv_fwd_body).  Both are per-token chains, the tile's y rows go
 // from one to the other through LDS, and one kernel boundary per layer - with the write-back of what the first kernel
 // stored (profiles/r02_notes.md) - leaves the dependent chain.
-template <typename T, int TT>
+template <typename T, int TT, int RM>
 __global__ __launch_bounds__(256) void ffn_qkv_fwd_fused_kernel(FfnFwdArgs fa, QkvFwdArgs qa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
   constexpr int LDX = 256 + 8;
+  QkvRope<TT, RM> rope;
+  rope.load(qa);
   ffn_fwd_body<T, TT, true>(fa, chain_smem, qa.Wqc, sizeof(T) * (size_t)320 * 256, qa.Wkv, sizeof(T) * (size_t)512 * 64);
   __syncthreads();                                   // the copy-out of y has read its panel; every panel is free
   // y sits in the SECOND [TT][LDX] panel of the FFN body; the q/kv body keeps x in the first: copy, then go on
   const T* ys = reinterpret_cast<const T*>(chain_smem) + TT * LDX;
-  qkv_fwd_body<T, TT>(qa, chain_smem, ys);
+  qkv_fwd_body<T, TT, RM>(qa, chain_smem, ys, rope);
 }
 
 template <typename T, int TT>
 static void qkv_fwd_fused_launch_tt(hipStream_t s, const QkvFwdArgs& a) {
-  constexpr size_t lds = sizeof(T) * (size_t)TT * ((256 + 8) + (320 + 8) + (512 + 8));
+  constexpr int RM = TT <= 16 ? 1 : 2;     // rotated form: table entries in registers on the short tile, staged in LDS on longer ones
+  constexpr size_t lds = sizeof(T) * (size_t)TT * ((256 + 8) + (320 + 8) + (512 + 8)) + (RM == 2 ? (size_t)TT * 64 * sizeof(float) : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
+  static_assert(TT != 32 || sizeof(T) != 2 || 2 * lds <= 160 * 1024, "two workgroups per compute unit on the 32-token bf16 tile");
   static bool once = (lds > 64 * 1024
-                          ? (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_fwd_fused_kernel<T, TT>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                          ? ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_fwd_fused_kernel<T, TT, 0>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_fwd_fused_kernel<T, TT, RM>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
                           : (void)0,
                       true);
   (void)once;
-  hipLaunchKernelGGL((qkv_fwd_fused_kernel<T, TT>), dim3((a.N + TT - 1) / TT), dim3(256), lds, s, a);
+  if (a.rope_cos != nullptr) hipLaunchKernelGGL((qkv_fwd_fused_kernel<T, TT, RM>), dim3((a.N + TT - 1) / TT), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((qkv_fwd_fused_kernel<T, TT, 0>), dim3((a.N + TT - 1) / TT), dim3(256), lds, s, a);
 }
 template <typename T>
 static void qkv_fwd_fused_launch(hipStream_t s, const QkvFwdArgs& a) {
@@ -1301,12 +1410,15 @@ static void ffn_qkv_fwd_fused_launch(hipStream_t s, const FfnFwdArgs& fa, const 
   constexpr size_t lds = lds_f > lds_q ? lds_f : lds_q;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool once = (lds > 64 * 1024
-                          ? (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_qkv_fwd_fused_kernel<T, TT>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                          ? ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_qkv_fwd_fused_kernel<T, TT, 0>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_qkv_fwd_fused_kernel<T, TT, 1>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
                           : (void)0,
                       true);
   (void)once;
-  hipLaunchKernelGGL((ffn_qkv_fwd_fused_kernel<T, TT>), dim3((fa.N + TT - 1) / TT), dim3(256), lds, s, fa, qa);
+  if (qa.rope_cos != nullptr) hipLaunchKernelGGL((ffn_qkv_fwd_fused_kernel<T, TT, 1>), dim3((fa.N + TT - 1) / TT), dim3(256), lds, s, fa, qa);
+  else hipLaunchKernelGGL((ffn_qkv_fwd_fused_kernel<T, TT, 0>), dim3((fa.N + TT - 1) / TT), dim3(256), lds, s, fa, qa);
 }
 
 bool ffn_qkv_fwd_fused(hipStream_t s, DType dt, const FfnFwdArgs& fa, const QkvFwdArgs& qa) {

@@ -234,6 +234,11 @@ struct QkvFwdArgs {
   void* XN; float* mean; float* rstd; void* QC; void* KV;
   int N;
   int dbg_slot;
+  // Optional (global-attention layers): q = QC[:, 0:256] and k = KV[:, 0:256] leave the chain ROTATED (RoPE of the
+  // token's frame index row % rope_S, rounded to T exactly as the attention kernels round what they rotate while staging),
+  // so that the attention kernels (AttnArgs::prerot) copy instead of rotating every K tile once per query tile and every Q
+  // tile once per key tile.  nullptr: raw projections (local layers rotate window-relative positions).
+  const float* rope_cos; const float* rope_sin; int rope_S;
 };
 void qkv_fwd_fused(hipStream_t s, DType dt, const QkvFwdArgs& a);
 // ffn_fwd_fused (full) of layer l and qkv_fwd_fused of layer l + 1 in ONE launch (same token tiles, y handed over
@@ -309,6 +314,7 @@ struct AttnArgs {
   // score - word [(b H + h) * ntile + kt][q] (q < 64 ntile), bit 16 st + 4 g + e = key 64 kt + 16 st + 4 g + e - and both
   // roles of the backward read them back instead of hashing 16 indices per lane and 64 x 64 tile again (attn.hip).
   unsigned long long* keepbits;
+  int prerot;                 // global attention: q and k arrive rotated and rounded (QkvFwdArgs::rope_cos): no RoPE while staging
 };
 struct AttnBwdArgs {
   AttnArgs f;                 // forward tensors (O = forward output, LSE)

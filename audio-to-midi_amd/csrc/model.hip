@@ -258,7 +258,7 @@ struct Arena {
 
 struct BlockSave { void *x, *ln, *u, *h, *z; float *mean, *rstd; };
 struct StageSave { void *x, *ln; float *mean, *rstd; std::vector<BlockSave> blocks; };
-struct LayerSave { void *x, *xn, *qc, *kv, *ao, *h, *hn, *u, *g; float *m1, *r1, *m2, *r2, *lse; unsigned long long* keepbits; };
+struct LayerSave { void *x, *xn, *qc, *kv, *ao, *h, *hn, *u, *g; float *m1, *r1, *m2, *r2, *lse; unsigned long long* keepbits; int prerot; };
 
 }  // namespace
 
@@ -335,6 +335,7 @@ struct amt_ctx {
   TeamState* team = nullptr;    // XCD-team protocol words (team.h); null: team launches disabled (AMT_TEAM=0)
   int cnn_late_max_c = 0;       // AMT_CNN_WGRAD_LATE=C: weight gradients of the CNN stages with <= C channels as one batch of launches after the pass (1 = all)
   bool fuse_ffn = true;         // AMT_FUSE_FFN=0: second half of a layer as chain + two tiled GEMM launches
+  bool prerot = true;           // AMT_PREROT=0: global layers' q / k leave the chain raw, the attention kernels rotate them while staging
 
   const float* P(size_t off) const { return params + off; }
   const void* WC(size_t off) const { return static_cast<const char*>(wc) + off * esz; }
@@ -583,6 +584,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
   c->fn_y = cur;
   const size_t mark1 = A.off;
   bool qkv_done = false;   // the current layer's first half was computed by the previous layer's boundary launch
+  int qkv_prerot = 0;      // ... and left q / k rotated (QkvFwdArgs::rope_cos)
   for (size_t li = 0; li < L.layers.size(); ++li) {
     const LayerP& lp = L.layers[li];
     LayerSave& ls = c->lsave[li];
@@ -622,14 +624,20 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
       qa.X = x; qa.ln_w = c->P(q.ln1_w); qa.ln_b = c->P(q.ln1_b); qa.Wqc = c->WC(q.c_wqcp); qa.Wkv = c->WC(q.c_wkvp);
       qa.XN = save ? t.xn : nullptr;        // LN1(x) is an operand of the backward pass only
       qa.mean = t.m1; qa.rstd = t.r1; qa.QC = t.qc; qa.KV = t.kv; qa.N = N; qa.dbg_slot = 96 + (int)l;
+      // global layers: q and k leave the chain rotated (kernels.h: QkvFwdArgs::rope_cos), the attention kernels copy them.
+      // Not with the fp8 forward (it stages from the raw projections); AMT_PREROT=0 keeps the raw form everywhere.
+      if (l % 2 == 1 && !fp8 && c->prerot) { qa.rope_cos = c->rope_cos; qa.rope_sin = c->rope_sin; qa.rope_S = S; }
       return qa;
     };
     if (qkv_done) {
       qkv_done = false;                 // xn, qc, kv of this layer came out of the previous layer's boundary launch
+      ls.prerot = qkv_prerot;
     } else if (chain_ok && !(c->nochain & 4)) {
       const QkvFwdArgs qa = qkv_args(li, cur);
+      ls.prerot = qa.rope_cos != nullptr;
       RUN(qkv_fwd_fused(s, dt, qa));
     } else {
+      ls.prerot = 0;
       RUN(layernorm_fwd(s, dt, cur, c->P(lp.ln1_w), c->P(lp.ln1_b), ls.xn, ls.m1, ls.r1, N, H));
       GemmArgs gq = gargs(ls.xn, H, c->WC(lp.c_wqc), H, N, L.QC, H, nullptr, ls.qc, L.QC);
       RUN(gemm_nt(s, dt, EPI_STORE, gq));
@@ -643,6 +651,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
     aa.cos = c->rope_cos; aa.sin = c->rope_sin; aa.B = B; aa.S = S; aa.H = cfg.n_heads;
     aa.seed = seed; aa.seed_dev = c->seed_word; aa.stream = stream_attn((int)li); aa.drop_thresh24 = dp.thr; aa.inv_keep = dp.inv_keep;
     aa.keepbits = ls.keepbits;
+    aa.prerot = local ? 0 : ls.prerot;
     if (local) RUN(attn_local_fwd(s, dt, aa));
     else if (fp8) RUN(attn_global_fwd_fp8(s, aa, c->amax + 8 * li, c->amax + 8 * li + 4));
     else RUN(attn_global_fwd(s, dt, aa));
@@ -669,6 +678,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
           nx.qc = A.alloc((size_t)N * L.QC * es);
           nx.kv = A.alloc((size_t)N * L.KVW * es);
           const QkvFwdArgs qa = qkv_args(li + 1, y);
+          qkv_prerot = qa.rope_cos != nullptr;
           if (!dry && !A.overflow) {
             if (!ffn_qkv_fwd_fused(s, dt, fa, qa)) { ffn_fwd_fused(s, dt, fa); qkv_fwd_fused(s, dt, qa); }
           }
@@ -1002,6 +1012,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     ab.f.LSE = ls.lse; ab.f.cos = c->rope_cos; ab.f.sin = c->rope_sin; ab.f.B = B; ab.f.S = S; ab.f.H = cfg.n_heads;
     ab.f.seed = seed; ab.f.seed_dev = c->seed_word; ab.f.stream = stream_attn(li); ab.f.drop_thresh24 = dp.thr; ab.f.inv_keep = dp.inv_keep;
     ab.f.keepbits = local ? nullptr : ls.keepbits;
+    ab.f.prerot = local ? 0 : ls.prerot;
     ab.dO = dao; ab.lddo = H; ab.dQC = dqc; ab.lddqc = L.QC; ab.dKV = dkv; ab.lddkv = L.KVW; ab.delta = delta;
     if (local) RUN(attn_local_bwd(s, dt, ab)); else RUN(attn_global_bwd(s, dt, ab));
     const int ckv = cfg.kv_compress;
@@ -1374,6 +1385,7 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   // measured it slower and left it off; with 16-token forward tiles and the boundary cost understood (it is the write-back
   // of what a kernel stored, profiles/r02_notes.md: the chain saves two boundaries per layer) it is 3.86 vs 3.97 ms/step.
   c->fuse_ffn = !(getenv("AMT_FUSE_FFN") && atoi(getenv("AMT_FUSE_FFN")) == 0);
+  c->prerot = !(getenv("AMT_PREROT") && atoi(getenv("AMT_PREROT")) == 0);
   // XCD-team launches (team.h): opt-in while they are not faster than one launch per Block (profiles/r02_notes.md)
   if (getenv("AMT_TEAM") && atoi(getenv("AMT_TEAM")) != 0) {
     c->team = team_state_create();
