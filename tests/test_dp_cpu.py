@@ -1,4 +1,4 @@
-"""Multi-process (world_size 2, gloo, CPU tensors) test of the data-parallel step protocol:
+"""Multi-process (world_size 2 and 4, gloo, CPU tensors) test of the data-parallel step protocol:
 N ranks on shards of the global batch == 1 rank on the whole batch, the finite
 flag is an AND over ranks, and the loss-scale controller follows train.py:369-382."""
 import os
@@ -122,10 +122,11 @@ def _dp_worker(rank, world, port, q, poison, overlap, accum=1):
     conf = _conf()
     params = np_model.init_params(conf, seed=3, gamma=1.0)
     audio, labels = synth.make_batch(4, 320 * 20, seed=9)
-    shard = slice(rank * 2, rank * 2 + 2)
+    per = 4 // world
+    shard = slice(rank * per, rank * per + per)
     bucket = train.GradBucket(P.param_count(conf), "cpu")
     split = _split_of(conf)
-    be = _OracleBackend(conf, params, audio[shard], labels[shard], bucket, split, poison=poison and rank == 1, accum_steps=accum)
+    be = _OracleBackend(conf, params, audio[shard], labels[shard], bucket, split, poison=poison and rank == world - 1, accum_steps=accum)
     dp = train.DataParallelStep(be, bucket, split, dist=dist, overlap=overlap, graph=True)   # graph is ignored on CPU
     dp.prepare(seed=0)
     dp.step()
@@ -163,6 +164,33 @@ def test_data_parallel_step_two_ranks_equal_one_rank(poison, overlap, accum):
     if not poison:
         grads = outs[0][4]
         assert np.linalg.norm(grads - ref) < 1e-5 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("poison", [False, True])
+def test_data_parallel_step_four_ranks_equal_one_rank(poison):
+    """The same protocol at world size 4 (one clip per rank, two-collective form): the mean all-reduce over four shards equals
+    the one-rank gradient of the global batch, and one poisoned rank closes the optimizer gate on all four."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q, poison, True, 1)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in range(world)], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    conf = _conf()
+    params = np_model.init_params(conf, seed=3, gamma=1.0)
+    audio, labels = synth.make_batch(4, 320 * 20, seed=9)
+    ref_loss, _, g = torch_model.loss_and_grads(params, audio, labels, conf)
+    ref = P.equinox_to_flat(g, conf)
+    for rank, loss, valid, gate, _ in outs:
+        assert valid == (not poison) and gate == (not poison), (rank, valid, gate)
+        assert abs(loss - ref_loss) < 1e-5 * abs(ref_loss)
+    if not poison:
+        assert np.linalg.norm(outs[0][4] - ref) < 1e-5 * np.linalg.norm(ref)
 
 
 def test_grad_bucket_layout_and_single_rank_step():
