@@ -601,6 +601,30 @@ def test_streaming_size_inference_forms_equal_the_short_tile_chains(small_conf, 
     assert torch.equal(outs["new"], outs["old"])
 
 
+def test_streaming_size_training_forward_equals_the_four_wave_form(small_conf, monkeypatch):
+    """The same occupancy-2 FFN form in its TRAINING instantiation (it saves h, hn, u, g for the backward pass): 99 clips x 10 s
+    = 49 500 tokens through `loss_and_grads` with AMT_BIG default (5) against AMT_BIG=1 (four waves, one workgroup per compute
+    unit): identical logits and loss, gradients equal up to the atomic summation order of the weight gradients."""
+    audio, labels = synth.make_batch_fast(99, 160000, seed=23)
+    a = torch.from_numpy(audio).to("cuda", torch.bfloat16)
+    y = torch.from_numpy(labels).cuda()
+    outs = {}
+    for big in (None, "1"):
+        if big is None:
+            monkeypatch.delenv("AMT_BIG", raising=False)
+        else:
+            monkeypatch.setenv("AMT_BIG", big)
+        model = amt.OutputSequenceGenerator(small_conf, key=9, dtype="bfloat16", gamma=1.0)
+        o = model.loss_and_grads(a, y, seed=4, train=True, return_logits=True)
+        outs[big] = (o.logits.clone(), o.loss, o.grads_flat.clone(), o.grads_valid)
+        model.close()
+    assert outs[None][3] and outs["1"][3]
+    assert torch.equal(outs[None][0], outs["1"][0])
+    assert abs(outs[None][1] - outs["1"][1]) <= 1e-6 * abs(outs["1"][1])
+    rel = float((outs[None][2] - outs["1"][2]).norm() / outs["1"][2].norm())
+    assert rel < 1e-3, rel
+
+
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
 def test_attention_backward_keep_bits_equal_the_rehashed_masks(small_conf, dtype, monkeypatch):
     """Round 3: the global-attention forward leaves the keep decisions of its weight dropout as one bit per score and
