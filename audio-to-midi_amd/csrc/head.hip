@@ -369,6 +369,14 @@ AMT_DEV float adamw_update(float gi, float pi, float mo, float vo, float lrs, fl
   u *= -lr * lrs;
   return u;
 }
+// the update from the NEW moments alone (the same expression, so the same bits): the one-launch form keeps m', v' in registers
+// across its grid barrier and forms u a second time behind it
+AMT_DEV float adamw_update_from_moments(float mi, float vi, float pi, float lrs, float lr, float eps, float wd, float ibc1, float ibc2) {
+  float u = (mi * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vi * ibc2) + eps);
+  u += wd * pi;
+  u *= -lr * lrs;
+  return u;
+}
 __global__ __launch_bounds__(256) void adamw_compute_kernel(const float* __restrict__ p, const float* __restrict__ g,
                                                             float* __restrict__ m, float* __restrict__ v,
                                                             float* __restrict__ upd, const float* __restrict__ lr_scale,
@@ -544,11 +552,154 @@ __global__ __launch_bounds__(256) void adamw_commit_kernel(float* __restrict__ p
     g[i] = 0.f;
   }
 }
+// One-launch form of the same protocol: ONE workgroup of 512 threads per compute unit, a grid barrier between the two passes.
+// Pass 1 reads g, p, m, v, forms m', v', u, adds |u|^2 to norm2 and KEEPS m', v' in registers (2 x 4 x NCH floats per
+// lane: the register files of the chip hold two of the four arrays, not more); behind the barrier pass 2 reads p again, forms
+// u from the kept moments (adamw_update_from_moments: the same bits), and writes p, m', v' and the zeroed g: 34.5 instead of
+// 56 bytes per parameter (the learning-rate factor as one byte, below), one launch instead of two.
+// The barrier is an arrival counter that only grows (norm2[4]; the launch index norm2[5] is advanced by workgroup 0 behind
+// it), polled by one thread per workgroup with a spin limit: every workgroup must be RESIDENT for it to open, which holds
+// when the grid is the number of compute units and nothing else runs on the device (the single-rank step; the host takes
+// the two-launch form otherwise).  A limit that expires sets the sticky word norm2[6]: that launch and every later one then
+// skip the update (valid_out = 0, g zeroed: the step reads as "non-finite gradients") and the host, which polls the word
+// where it reads the optimizer count, goes back to the two-launch form.
+constexpr int kAdamPersistChunks = 24;
+template <int NCH>
+__global__ __launch_bounds__(512) void adamw_persist_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                            float* __restrict__ v, const float* __restrict__ lr_scale,
+                                                            const unsigned char* __restrict__ lr_idx, const float* __restrict__ lr_tab, size_t n,
+                                                            float gmul, float lr, float b1, float b2, float eps, float wd, int step,
+                                                            int* __restrict__ count, float* __restrict__ norm2, float clip,
+                                                            const int* __restrict__ gate_i, const float* __restrict__ gate_f,
+                                                            const float* __restrict__ loss, int* __restrict__ valid_out) {
+  __shared__ float red[8];
+  __shared__ float s_nrm2;
+  __shared__ int s_cnt, s_fail;
+  __shared__ unsigned s_epoch;
+  // the per-parameter learning-rate factor takes few distinct values (one per depth of the layer-wise decay): one BYTE per
+  // parameter indexes a table instead of 4 bytes of factor read in both passes (lr_idx[i] -> lr_tab[...] == lr_scale[i], same bits)
+  __shared__ float s_tab[256];
+  unsigned* bar = reinterpret_cast<unsigned*>(norm2 + 4);     // [0] arrivals, [1] launches completed, [2] sticky timeout
+  const int tid = threadIdx.x;
+  if (tid < 256) s_tab[tid] = lr_tab[tid];
+  if (tid == 0) {
+    s_cnt = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_epoch = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_fail = (int)__hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const bool dead = s_fail != 0;                                // an earlier launch timed out: skip, keep the accumulator clean
+  const float t = (float)(step > 0 ? step : s_cnt + 1);
+  const float bc1 = 1.f / (1.f - powf(b1, t)), bc2 = 1.f / (1.f - powf(b2, t));     // reciprocals (adamw_update)
+  const size_t n4 = n >> 2, stride = (size_t)gridDim.x * 512, base = (size_t)blockIdx.x * 512 + tid;
+  f32x4 ms[NCH], vs[NCH];
+  float acc = 0.f;
+  if (!dead) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const size_t i = base + (size_t)k * stride;
+      if (i < n4) {
+        const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i], p4 = reinterpret_cast<const f32x4*>(p)[i];
+        const f32x4 m4 = reinterpret_cast<const f32x4*>(m)[i], v4 = reinterpret_cast<const f32x4*>(v)[i];
+        const unsigned w = reinterpret_cast<const unsigned*>(lr_idx)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float mi, vi;
+          const float u = adamw_update(g4[e] * gmul, p4[e], m4[e], v4[e], s_tab[(w >> (8 * e)) & 255u], lr, b1, b2, eps, wd, bc1, bc2, mi, vi);
+          acc += u * u;
+          ms[k][e] = mi; vs[k][e] = vi;
+        }
+      }
+    }
+  }
+  // the last n % 4 elements: threads 0 .. 2 of workgroup 0
+  const size_t jt = (n4 << 2) + tid;
+  const bool tail = !dead && blockIdx.x == 0 && jt < n;
+  float mt = 0.f, vt = 0.f;
+  if (tail) {
+    const float u = adamw_update(g[jt] * gmul, p[jt], m[jt], v[jt], lr_scale[jt], lr, b1, b2, eps, wd, bc1, bc2, mt, vt);
+    acc += u * u;
+  }
+  acc = group_sum<64>(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    int fail = dead ? 1 : 0;
+    if (!dead) {
+      atomicAdd(norm2, ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])));
+      __threadfence();
+      atomicAdd(bar, 1u);
+      const unsigned target = (s_epoch + 1u) * gridDim.x;
+      unsigned spins = 0;
+      while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++spins > (1u << 21) || __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          fail = 1;
+          break;
+        }
+      }
+      __threadfence();
+    }
+    const float nrm2 = __hip_atomic_load(norm2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the value has ARRIVED before this workgroup counts itself as a reader
+    s_nrm2 = nrm2;
+    s_fail = fail;
+    unsigned* rd = reinterpret_cast<unsigned*>(norm2 + 1);
+    if (atomicAdd(rd, 1u) == gridDim.x - 1) {            // last reader: everybody has norm2
+      const bool open = !fail && adamw_gate_open(gate_i, gate_f) && isfinite(nrm2) && (loss == nullptr || isfinite(loss[0]));
+      __hip_atomic_store(norm2, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rd, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!dead) __hip_atomic_store(bar + 1, s_epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (open) count[0] = step > 0 ? step : s_cnt + 1;
+      if (valid_out != nullptr) valid_out[0] = open ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  const bool open = s_fail == 0 && adamw_gate_open(gate_i, gate_f) && isfinite(s_nrm2) && (loss == nullptr || isfinite(loss[0]));
+  const float nrm = sqrtf(s_nrm2);
+  const float f = (clip > 0.f && nrm > clip) ? clip / nrm : 1.f;
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const size_t i = base + (size_t)k * stride;
+    if (i < n4) {
+      if (open) {
+        f32x4 p4 = reinterpret_cast<f32x4*>(p)[i];
+        const unsigned w = reinterpret_cast<const unsigned*>(lr_idx)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          p4[e] = p4[e] + adamw_update_from_moments(ms[k][e], vs[k][e], p4[e], s_tab[(w >> (8 * e)) & 255u], lr, eps, wd, bc1, bc2) * f;
+        reinterpret_cast<f32x4*>(p)[i] = p4; reinterpret_cast<f32x4*>(m)[i] = ms[k]; reinterpret_cast<f32x4*>(v)[i] = vs[k];
+      }
+      reinterpret_cast<f32x4*>(g)[i] = z4;
+    }
+  }
+  if (blockIdx.x == 0 && jt < n) {
+    if (open && tail) {
+      const float pi = p[jt];
+      p[jt] = pi + adamw_update_from_moments(mt, vt, pi, lr_scale[jt], lr, eps, wd, bc1, bc2) * f;
+      m[jt] = mt;
+      v[jt] = vt;
+    }
+    g[jt] = 0.f;
+  }
+}
+
 void adamw_fused(hipStream_t s, float* params, float* gacc, float* m, float* v, const float* lr_scale, size_t n, float gmul,
                  float lr, float b1, float b2, float eps, float wd, int step, int* count, float* norm2, float clip,
-                 const int* gate_i, const float* gate_f, const float* loss, int* valid_out) {
+                 const int* gate_i, const float* gate_f, const float* loss, int* valid_out, int persist_grid,
+                 const unsigned char* lr_idx, const float* lr_tab) {
   const bool vec = ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(gacc) | reinterpret_cast<uintptr_t>(m) |
                      reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(lr_scale)) & 15) == 0;
+  // one-launch form: every parameter chunk has a register slot (persist_grid workgroups x 512 threads x kAdamPersistChunks)
+  if (vec && persist_grid > 0 && lr_idx != nullptr && (reinterpret_cast<uintptr_t>(lr_idx) & 3) == 0 &&
+      (n >> 2) <= (size_t)persist_grid * 512 * kAdamPersistChunks) {
+    ProfScope ps(s, "adamw_persist", 0, 34.5 * n);
+    hipLaunchKernelGGL(adamw_persist_kernel<kAdamPersistChunks>, dim3(persist_grid), dim3(512), 0, s, params, gacc, m, v, lr_scale, lr_idx, lr_tab, n,
+                       gmul, lr, b1, b2, eps, wd, step, count, norm2, clip, gate_i, gate_f, loss, valid_out);
+    return;
+  }
   {
     ProfScope ps(s, "adamw_norm", 0, 20.0 * n);
     if (vec) hipLaunchKernelGGL(adamw_norm_kernel<true>, dim3(2048), dim3(256), 0, s, params, gacc, m, v, lr_scale, n, gmul, lr, b1, b2, eps, wd, step, count, norm2);

@@ -293,6 +293,8 @@ struct amt_ctx {
   uint64_t plan_gen = 0;
   // optimizer state
   float *adam_m = nullptr, *adam_v = nullptr, *adam_upd = nullptr, *lr_scale = nullptr, *norm2 = nullptr;
+  unsigned char* lr_idx = nullptr;   // lr_scale[i] == lr_tab[lr_idx[i]] (one-launch fused optimizer, head.hip)
+  float* lr_tab = nullptr;           // [256]
   float lr_scale_decay = -1.f;
   // saved forward state
   std::vector<StageSave> ssave;
@@ -335,6 +337,9 @@ struct amt_ctx {
   TeamState* team = nullptr;    // XCD-team protocol words (team.h); null: team launches disabled (AMT_TEAM=0)
   int cnn_late_max_c = 0;       // AMT_CNN_WGRAD_LATE=C: weight gradients of the CNN stages with <= C channels as one batch of launches after the pass (1 = all)
   bool fuse_ffn = true;         // AMT_FUSE_FFN=0: second half of a layer as chain + two tiled GEMM launches
+  bool lr_idx_ok = false;       // lr_idx / lr_tab describe lr_scale (fewer than 255 depths)
+  bool opt_persist = true;      // one-launch fused optimizer (head.hip: adamw_persist_kernel); AMT_OPT_PERSIST=0 or a barrier timeout: two launches
+  int n_cus = 0;                // compute units of the device (grid of the one-launch optimizer)
   bool prerot = true;           // AMT_PREROT=0: global layers' q / k leave the chain raw, the attention kernels rotate them while staging
 
   const float* P(size_t off) const { return params + off; }
@@ -1386,6 +1391,8 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   // of what a kernel stored, profiles/r02_notes.md: the chain saves two boundaries per layer) it is 3.86 vs 3.97 ms/step.
   c->fuse_ffn = !(getenv("AMT_FUSE_FFN") && atoi(getenv("AMT_FUSE_FFN")) == 0);
   c->prerot = !(getenv("AMT_PREROT") && atoi(getenv("AMT_PREROT")) == 0);
+  c->opt_persist = !(getenv("AMT_OPT_PERSIST") && atoi(getenv("AMT_OPT_PERSIST")) == 0);
+  { hipDeviceProp_t pr; c->n_cus = (hipGetDeviceProperties(&pr, c->device) == hipSuccess) ? pr.multiProcessorCount : 0; }
   // XCD-team launches (team.h): opt-in while they are not faster than one launch per Block (profiles/r02_notes.md)
   if (getenv("AMT_TEAM") && atoi(getenv("AMT_TEAM")) != 0) {
     c->team = team_state_create();
@@ -1446,7 +1453,7 @@ void amt_destroy(amt_ctx* c) {
   (void)hipSetDevice(c->device);
   void* ptrs[] = {c->params, c->wc, c->head_bias, c->conv_dev, c->conv_prefix_dev, c->rope_cos, c->rope_sin,
                   c->arena.base, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, c->norm2, c->loss_acc,
-                  c->partials, c->amax, c->gacc, c->team, c->seed_word};
+                  c->partials, c->amax, c->gacc, c->team, c->seed_word, c->lr_idx, c->lr_tab};
   for (const amt_ctx::PlanRec& r : c->plans)
     if (r.desc_dev) (void)hipFree(r.desc_dev);
   for (void* p : ptrs)
@@ -1628,8 +1635,10 @@ int32_t amt_optimizer_init(amt_ctx* c, float layer_lr_decay) {
     HIPCHK(c, hipMalloc(&c->adam_v, n * sizeof(float)));
     HIPCHK(c, hipMalloc(&c->adam_upd, n * sizeof(float)));
     HIPCHK(c, hipMalloc(&c->lr_scale, n * sizeof(float)));
-    HIPCHK(c, hipMalloc(&c->norm2, 4 * sizeof(float)));   // [sum of squares, reader count]: adamw_apply leaves both zero; [2]: int count of applied updates
-    HIPCHK(c, hipMemset(c->norm2, 0, 4 * sizeof(float)));
+    HIPCHK(c, hipMalloc(&c->lr_idx, (n + 3) / 4 * 4));
+    HIPCHK(c, hipMalloc(&c->lr_tab, 256 * sizeof(float)));
+    HIPCHK(c, hipMalloc(&c->norm2, 8 * sizeof(float)));   // [sum of squares, reader count]: adamw_apply leaves both zero; [2]: int count of applied updates; [4..6]: grid barrier of the one-launch fused form (arrivals, launches, sticky timeout)
+    HIPCHK(c, hipMemset(c->norm2, 0, 8 * sizeof(float)));
     HIPCHK(c, hipMemset(c->adam_m, 0, n * sizeof(float)));
     HIPCHK(c, hipMemset(c->adam_v, 0, n * sizeof(float)));
   }
@@ -1637,11 +1646,22 @@ int32_t amt_optimizer_init(amt_ctx* c, float layer_lr_decay) {
     int max_depth = 0;
     for (const Seg& sg : L.segs) if (sg.lr_depth > max_depth) max_depth = sg.lr_depth;
     std::vector<float> sc(n, 1.f);
+    // the same factors as a byte index into a table (entry 0: 1.0; entry d + 1: the factor of depth d)
+    std::vector<unsigned char> idx((n + 3) / 4 * 4, 0);
+    std::vector<float> tab(256, 1.f);
+    const bool idx_ok = max_depth < 255;
     for (const Seg& sg : L.segs) {
       float f = sg.lr_depth >= 0 ? powf(layer_lr_decay, (float)(max_depth - sg.lr_depth)) : 1.f;
       for (size_t i = 0; i < (size_t)sg.rows * sg.cols; ++i) sc[sg.off + i] = f;
+      if (idx_ok && sg.lr_depth >= 0) {
+        tab[sg.lr_depth + 1] = f;
+        for (size_t i = 0; i < (size_t)sg.rows * sg.cols; ++i) idx[sg.off + i] = (unsigned char)(sg.lr_depth + 1);
+      }
     }
     HIPCHK(c, hipMemcpy(c->lr_scale, sc.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->lr_idx, idx.data(), idx.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->lr_tab, tab.data(), 256 * sizeof(float), hipMemcpyHostToDevice));
+    c->lr_idx_ok = idx_ok;
     c->lr_scale_decay = layer_lr_decay;
   }
   HIPCHK(c, hipDeviceSynchronize());
@@ -1664,7 +1684,8 @@ int32_t amt_adamw_step_gated(amt_ctx* c, const float* grads_flat, float lr_base,
     // accumulator; valid_i32 is an OUTPUT here (the all-finite flag of this step, 1 = update applied)
     if (!c->fused_used) { c->err = "amt_adamw_step(grads_flat = NULL): no backward pass has left gradients in the context (call amt_forward_backward* with grads_flat = NULL first)"; return 1; }
     adamw_fused(s, c->params, c->gacc + c->gacc_pad, c->adam_m, c->adam_v, c->lr_scale, n, c->gacc_mul, lr_base, b1, b2, eps,
-                weight_decay, step, count, c->norm2, clip_norm, nullptr, valid_f32, c->loss_acc, const_cast<int32_t*>(valid_i32));
+                weight_decay, step, count, c->norm2, clip_norm, nullptr, valid_f32, c->loss_acc, const_cast<int32_t*>(valid_i32),
+                (c->opt_persist && c->lr_idx_ok) ? c->n_cus : 0, c->lr_idx, c->lr_tab);
     return refresh(c, s);
   }
   adamw_compute(s, c->params, grads_flat, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, n, lr_base, b1, b2, eps,
@@ -1682,9 +1703,13 @@ int32_t amt_grad_accumulator_reset(amt_ctx* c, void* stream) {
 
 int32_t amt_optimizer_count(amt_ctx* c) {
   if (!c->norm2) return 0;
-  int v = 0;
-  if (hipMemcpy(&v, c->norm2 + 2, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return v;
+  int w[5] = {0, 0, 0, 0, 0};     // [0] count, [4] sticky timeout word of the one-launch fused form (head.hip)
+  if (hipMemcpy(w, c->norm2 + 2, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (w[4] != 0 && c->opt_persist) {
+    c->opt_persist = false;         // its grid barrier did not open (workgroups not co-resident): two launches from now on
+    c->err = "the one-launch fused optimizer timed out at its grid barrier (that step was skipped); using the two-launch form";
+  }
+  return w[0];
 }
 
 int32_t amt_adamw_step(amt_ctx* c, const float* grads_flat, float lr_base, float layer_lr_decay, float b1, float b2,

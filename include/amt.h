@@ -217,7 +217,12 @@ int32_t amt_optimizer_count(amt_ctx* ctx);
  * clean between steps by construction (zeroed at creation, by the commit pass, by amt_grad_accumulator_reset, and at the
  * end of every backward pass that does write grads_flat).  A backward pass whose gradients are NOT to be applied (a
  * warm-up run, an aborted step) must be followed by amt_grad_accumulator_reset, otherwise the next one adds to it -
- * which is also how train.py:275-310's accumulation over minibatches looks in this protocol. */
+ * which is also how train.py:275-310's accumulation over minibatches looks in this protocol.
+ * By default the two passes are ONE launch with a grid barrier between them (one workgroup per compute unit; the new moments
+ * stay in registers across it): it needs the device to itself for those ~100 us.  If its barrier does not open within ~1 s
+ * (another stream holds compute units) the update of that step is skipped (valid = 0, accumulator zeroed), a sticky device
+ * word is set, and amt_optimizer_count - which reads it - switches the context to the two launches for good and records
+ * the reason in amt_last_error.  AMT_OPT_PERSIST=0 selects the two launches from the start. */
 int32_t amt_grad_accumulator_reset(amt_ctx* ctx, void* stream);
 
 /* ---- measurement aid (bench.py roofline leg): per-kernel-class timing with HIP events recorded
