@@ -28,7 +28,7 @@ def classify(name):
         return f"gemm_nt<bf16,glu_bwd,{m.group(1)}>"
     if "ffn_fwd_fused_kernel" in name and "ffn_qkv" not in name:
         return "attn_out_fused" if "Lb0" in name else "ffn_fwd_fused"
-    for key, cls in (("ffn_fwd_big_kernel", "ffn_fwd_big"), ("adamw_norm_kernel", "adamw_norm"), ("adamw_commit_kernel", "adamw_commit"),
+    for key, cls in (("ffn_fwd_big_kernel", "ffn_fwd_big"), ("adamw_norm_kernel", "adamw_norm"), ("adamw_commit_kernel", "adamw_commit"), ("adamw_persist_kernel", "adamw_persist"),
                      ("ffn_qkv_fwd_fused_kernel", "ffn_qkv_fwd_fused"), ("ffn_bwd_fused_kernel", "ffn_bwd_fused+wgrad"),
                      ("block_run_fwd_kernel", "block_run_fwd"),
                      ("gemm_tn_group_kernel", "gemm_tn_wgrad_group<bf16>"), ("dwblock_bwd_kernel", "dwblock_bwd"),
