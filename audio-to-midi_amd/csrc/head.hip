@@ -571,7 +571,8 @@ __global__ __launch_bounds__(512) void adamw_persist_kernel(float* __restrict__ 
                                                             float gmul, float lr, float b1, float b2, float eps, float wd, int step,
                                                             int* __restrict__ count, float* __restrict__ norm2, float clip,
                                                             const int* __restrict__ gate_i, const float* __restrict__ gate_f,
-                                                            const float* __restrict__ loss, int* __restrict__ valid_out) {
+                                                            const float* __restrict__ loss, int* __restrict__ valid_out,
+                                                            int* __restrict__ fail_host) {
   __shared__ float red[8];
   __shared__ float s_nrm2;
   __shared__ int s_cnt, s_fail;
@@ -635,6 +636,7 @@ __global__ __launch_bounds__(512) void adamw_persist_kernel(float* __restrict__ 
         __builtin_amdgcn_s_sleep(16);
         if (++spins > (1u << 21) || __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
           __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (fail_host != nullptr) __hip_atomic_store(fail_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // mapped host word: the next call sees it without a sync
           fail = 1;
           break;
         }
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(512) void adamw_persist_kernel(float* __restrict__ 
 void adamw_fused(hipStream_t s, float* params, float* gacc, float* m, float* v, const float* lr_scale, size_t n, float gmul,
                  float lr, float b1, float b2, float eps, float wd, int step, int* count, float* norm2, float clip,
                  const int* gate_i, const float* gate_f, const float* loss, int* valid_out, int persist_grid,
-                 const unsigned char* lr_idx, const float* lr_tab) {
+                 const unsigned char* lr_idx, const float* lr_tab, int* persist_fail_host) {
   const bool vec = ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(gacc) | reinterpret_cast<uintptr_t>(m) |
                      reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(lr_scale)) & 15) == 0;
   // one-launch form: every parameter chunk has a register slot (persist_grid workgroups x 512 threads x kAdamPersistChunks)
@@ -697,7 +699,7 @@ void adamw_fused(hipStream_t s, float* params, float* gacc, float* m, float* v, 
       (n >> 2) <= (size_t)persist_grid * 512 * kAdamPersistChunks) {
     ProfScope ps(s, "adamw_persist", 0, 34.5 * n);
     hipLaunchKernelGGL(adamw_persist_kernel<kAdamPersistChunks>, dim3(persist_grid), dim3(512), 0, s, params, gacc, m, v, lr_scale, lr_idx, lr_tab, n,
-                       gmul, lr, b1, b2, eps, wd, step, count, norm2, clip, gate_i, gate_f, loss, valid_out);
+                       gmul, lr, b1, b2, eps, wd, step, count, norm2, clip, gate_i, gate_f, loss, valid_out, persist_fail_host);
     return;
   }
   {

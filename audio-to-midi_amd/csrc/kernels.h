@@ -368,7 +368,8 @@ void pack_tail(hipStream_t s, const float* loss, const int* valid, float* head_v
 void adamw_fused(hipStream_t s, float* params, float* gacc, float* m, float* v, const float* lr_scale, size_t n, float gmul,
                  float lr, float b1, float b2, float eps, float wd, int step, int* count, float* norm2, float clip,
                  const int* gate_i, const float* gate_f, const float* loss, int* valid_out, int persist_grid = 0,
-                 const unsigned char* lr_idx = nullptr, const float* lr_tab = nullptr);
+                 const unsigned char* lr_idx = nullptr, const float* lr_tab = nullptr,
+                 int* persist_fail_host = nullptr);
 // gate_i / gate_f (device, either may be null): both passes are no-ops unless *gate_i != 0 and *gate_f >= 0.999;
 // step > 0: explicit optimizer step, step < 0: *count + 1 (device count of applied updates, advanced behind an open gate)
 void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, float* norm2, float clip,

@@ -295,6 +295,8 @@ struct amt_ctx {
   float *adam_m = nullptr, *adam_v = nullptr, *adam_upd = nullptr, *lr_scale = nullptr, *norm2 = nullptr;
   unsigned char* lr_idx = nullptr;   // lr_scale[i] == lr_tab[lr_idx[i]] (one-launch fused optimizer, head.hip)
   float* lr_tab = nullptr;           // [256]
+  int* persist_fail = nullptr;       // mapped host word the one-launch optimizer sets when its grid barrier times out
+  int* persist_fail_dev = nullptr;   // ... its device address
   float lr_scale_decay = -1.f;
   // saved forward state
   std::vector<StageSave> ssave;
@@ -340,6 +342,7 @@ struct amt_ctx {
   bool lr_idx_ok = false;       // lr_idx / lr_tab describe lr_scale (fewer than 255 depths)
   bool opt_persist = true;      // one-launch fused optimizer (head.hip: adamw_persist_kernel); AMT_OPT_PERSIST=0 or a barrier timeout: two launches
   int n_cus = 0;                // compute units of the device (grid of the one-launch optimizer)
+  int persist_grid_extra = 0;   // AMT_OPT_PERSIST_EXTRA=<k> (tests): k workgroups more than can be resident, so that the barrier times out
   bool prerot = true;           // AMT_PREROT=0: global layers' q / k leave the chain raw, the attention kernels rotate them while staging
 
   const float* P(size_t off) const { return params + off; }
@@ -1392,6 +1395,7 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   c->fuse_ffn = !(getenv("AMT_FUSE_FFN") && atoi(getenv("AMT_FUSE_FFN")) == 0);
   c->prerot = !(getenv("AMT_PREROT") && atoi(getenv("AMT_PREROT")) == 0);
   c->opt_persist = !(getenv("AMT_OPT_PERSIST") && atoi(getenv("AMT_OPT_PERSIST")) == 0);
+  c->persist_grid_extra = getenv("AMT_OPT_PERSIST_EXTRA") ? atoi(getenv("AMT_OPT_PERSIST_EXTRA")) : 0;
   { hipDeviceProp_t pr; c->n_cus = (hipGetDeviceProperties(&pr, c->device) == hipSuccess) ? pr.multiProcessorCount : 0; }
   // XCD-team launches (team.h): opt-in while they are not faster than one launch per Block (profiles/r02_notes.md)
   if (getenv("AMT_TEAM") && atoi(getenv("AMT_TEAM")) != 0) {
@@ -1458,6 +1462,7 @@ void amt_destroy(amt_ctx* c) {
     if (r.desc_dev) (void)hipFree(r.desc_dev);
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (c->persist_fail) (void)hipHostFree(c->persist_fail);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
@@ -1637,6 +1642,12 @@ int32_t amt_optimizer_init(amt_ctx* c, float layer_lr_decay) {
     HIPCHK(c, hipMalloc(&c->lr_scale, n * sizeof(float)));
     HIPCHK(c, hipMalloc(&c->lr_idx, (n + 3) / 4 * 4));
     HIPCHK(c, hipMalloc(&c->lr_tab, 256 * sizeof(float)));
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->persist_fail), sizeof(int), hipHostMallocMapped) == hipSuccess &&
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&c->persist_fail_dev), c->persist_fail, 0) == hipSuccess) {
+      *c->persist_fail = 0;
+    } else {                                                                                 // no mapped word: two launches
+      c->persist_fail = c->persist_fail_dev = nullptr; (void)hipGetLastError(); c->opt_persist = false;
+    }
     HIPCHK(c, hipMalloc(&c->norm2, 8 * sizeof(float)));   // [sum of squares, reader count]: adamw_apply leaves both zero; [2]: int count of applied updates; [4..6]: grid barrier of the one-launch fused form (arrivals, launches, sticky timeout)
     HIPCHK(c, hipMemset(c->norm2, 0, 8 * sizeof(float)));
     HIPCHK(c, hipMemset(c->adam_m, 0, n * sizeof(float)));
@@ -1683,9 +1694,13 @@ int32_t amt_adamw_step_gated(amt_ctx* c, const float* grads_flat, float lr_base,
     // fused protocol: the gradients are the sums the last amt_forward_backward*(grads_flat = NULL) left in the context's
     // accumulator; valid_i32 is an OUTPUT here (the all-finite flag of this step, 1 = update applied)
     if (!c->fused_used) { c->err = "amt_adamw_step(grads_flat = NULL): no backward pass has left gradients in the context (call amt_forward_backward* with grads_flat = NULL first)"; return 1; }
+    if (c->opt_persist && c->persist_fail != nullptr && *reinterpret_cast<volatile int*>(c->persist_fail) != 0) {
+      c->opt_persist = false;         // its grid barrier did not open (workgroups not co-resident): two launches from now on
+      c->err = "the one-launch fused optimizer timed out at its grid barrier (that step was skipped); using the two-launch form";
+    }
     adamw_fused(s, c->params, c->gacc + c->gacc_pad, c->adam_m, c->adam_v, c->lr_scale, n, c->gacc_mul, lr_base, b1, b2, eps,
                 weight_decay, step, count, c->norm2, clip_norm, nullptr, valid_f32, c->loss_acc, const_cast<int32_t*>(valid_i32),
-                (c->opt_persist && c->lr_idx_ok) ? c->n_cus : 0, c->lr_idx, c->lr_tab);
+                (c->opt_persist && c->lr_idx_ok) ? c->n_cus + c->persist_grid_extra : 0, c->lr_idx, c->lr_tab, c->persist_fail_dev);
     return refresh(c, s);
   }
   adamw_compute(s, c->params, grads_flat, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, n, lr_base, b1, b2, eps,

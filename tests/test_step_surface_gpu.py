@@ -178,6 +178,34 @@ def test_fused_optimizer_protocol_equals_the_three_pass_form(small_conf, dtype):
         fresh.adamw_step(None, lr_base=lr, step=-1)            # nothing has been left in the context
 
 
+def test_one_launch_optimizer_times_out_safely_and_falls_back(small_conf, monkeypatch):
+    """head.hip: adamw_persist_kernel runs its two passes around a grid barrier that only opens when every workgroup is
+    resident.  With more workgroups than the device can hold (AMT_OPT_PERSIST_EXTRA) the barrier cannot open: the launch must
+    end by its spin limit (not hang), skip the update (flag 0, parameters and count untouched, accumulator zeroed), and the
+    next call must take the two-launch form and apply a normal update equal to the three-pass form's."""
+    monkeypatch.setenv("AMT_OPT_PERSIST_EXTRA", "64")
+    audio, labels = synth.make_batch(2, 320 * 48, seed=21)
+    a, y = torch.from_numpy(audio), torch.from_numpy(labels)
+    fused = amt.OutputSequenceGenerator(small_conf, key=3, dtype="float32", gamma=1.0)
+    monkeypatch.delenv("AMT_OPT_PERSIST_EXTRA")
+    plain = amt.OutputSequenceGenerator(small_conf, key=3, dtype="float32", gamma=1.0)
+    fused.init_optimizer(); plain.init_optimizer()
+    flag = torch.full((1,), -7, dtype=torch.int32, device="cuda")
+    p0 = fused.weights_tensor().clone()
+    fused.loss_and_grads(a, y, scale=2.0, seed=10, train=True, fused_optimizer=True)
+    fused.adamw_step(None, lr_base=2e-2, step=-1, valid=flag)            # times out (~1-3 s), skipped
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0 and torch.equal(fused.weights_tensor(), p0)
+    assert fused.optimizer_count() == 0                                   # (also where the host notices the sticky word)
+    fused.loss_and_grads(a, y, scale=2.0, seed=10, train=True, fused_optimizer=True)   # a clean accumulator: not 2x the gradients
+    fused.adamw_step(None, lr_base=2e-2, step=-1, valid=flag)            # two launches now
+    out = plain.loss_and_grads(a, y, scale=2.0, seed=10, train=True)
+    plain.adamw_step(out.grads_flat, lr_base=2e-2, step=1)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1 and fused.optimizer_count() == 1
+    assert float((fused.weights_tensor() - plain.weights_tensor()).abs().max()) < 2e-6
+
+
 def test_data_parallel_step_uses_the_fused_protocol_under_graph_replay(small_conf):
     """DataParallelStep over HipTrainBackend(fused=True), captured and replayed: the rehearsal runs of prepare() are
     discarded, every replay + apply is one optimizer update, and the result equals the unfused backend's."""
