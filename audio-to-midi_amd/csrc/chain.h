@@ -208,10 +208,14 @@ AMT_DEV void chain_copy_store(T* Ps, const ChainCopyRegs<T, TT, W>& regs, int ti
 // lane-group reductions) per pass, in series, with one wave per SIMD and nothing to fill the gaps (in-kernel stamps:
 // 850 cycles per 8-row pass, profiles/r03_notes.md section 7).  Here up to LN_GROUP passes are loaded first, evaluated
 // side by side (independent chains the scheduler interleaves) and stored together; every row's arithmetic is unchanged.
+// TI / TO: element types of the input panel and of the output (panel or global rows): the rows a LayerNorm reads are
+// residual-stream rows (Res<T>, common.h), what it writes is T - or Res<T> again for the final CNN norm.  TI and TO have
+// the same size, so a panel is normalised in place whatever the two types are.
 constexpr int LN_GROUP = 4;
-template <typename T, int TT, int C, int LD, bool TO_GLOBAL>
-AMT_DEV void chain_ln_rows_impl(const T* Xs, T* Ys, T* __restrict__ G, const float* __restrict__ w, const float* __restrict__ b,
+template <typename TI, typename TO, int TT, int C, int LD, bool TO_GLOBAL>
+AMT_DEV void chain_ln_rows_impl(const TI* Xs, TO* Ys, TO* __restrict__ G, const float* __restrict__ w, const float* __restrict__ b,
                                 float* __restrict__ mean, float* __restrict__ rstd, long n0, long N, int tid) {
+  static_assert(sizeof(TI) == sizeof(TO), "in-place panels");
   constexpr int LPR = C / 8, RPP = 256 / LPR, NP = TT / RPP, GR = NP < LN_GROUP ? NP : LN_GROUP;
   static_assert(TT % RPP == 0, "row phase covers the tile in whole passes");
   static_assert(NP % GR == 0, "passes come in whole groups");
@@ -245,17 +249,17 @@ AMT_DEV void chain_ln_rows_impl(const T* Xs, T* Ys, T* __restrict__ G, const flo
   }
 }
 template <typename T, int TT, int C, int LD>
-AMT_DEV void chain_ln_rows(const T* Xs, T* Ys, const float* __restrict__ w, const float* __restrict__ b,
+AMT_DEV void chain_ln_rows(const Res<T>* Xs, T* Ys, const float* __restrict__ w, const float* __restrict__ b,
                            float* __restrict__ mean, float* __restrict__ rstd, long n0, long N, int tid) {
-  chain_ln_rows_impl<T, TT, C, LD, false>(Xs, Ys, nullptr, w, b, mean, rstd, n0, N, tid);
+  chain_ln_rows_impl<Res<T>, T, TT, C, LD, false>(Xs, Ys, nullptr, w, b, mean, rstd, n0, N, tid);
 }
 
 // The same, output rows to global memory (row-major, C features; rows >= N are not written): the LayerNorm of rows a
 // chain holds in LDS, for a consumer that is another launch (kernels.h: TailLn).
-template <typename T, int TT, int C, int LD>
-AMT_DEV void chain_ln_rows_out(const T* Xs, T* __restrict__ G, const float* __restrict__ w, const float* __restrict__ b,
+template <typename T, typename TO, int TT, int C, int LD>
+AMT_DEV void chain_ln_rows_out(const Res<T>* Xs, TO* __restrict__ G, const float* __restrict__ w, const float* __restrict__ b,
                                float* __restrict__ mean, float* __restrict__ rstd, long n0, long N, int tid) {
-  chain_ln_rows_impl<T, TT, C, LD, true>(Xs, nullptr, G, w, b, mean, rstd, n0, N, tid);
+  chain_ln_rows_impl<Res<T>, TO, TT, C, LD, true>(Xs, nullptr, G, w, b, mean, rstd, n0, N, tid);
 }
 
 // Cooperative L2 warm-up of a weight range.  Every workgroup of a chain kernel streams the SAME
@@ -314,12 +318,12 @@ template <int MAXLD> struct L2Warm {
 
 // LayerNorm backward over C = 256 features of TT rows (eqx LayerNorm, fp32 statistics):
 //   dX = dRes + LN'(dY),  aw += dY * xhat,  ab += dY   (column accumulators of this lane, cs[0] / cs[1])
-// dY rows come from an LDS panel (as stored, T), x / dRes rows from global memory; dX goes to an LDS
+// dY rows come from an LDS panel (as stored, T), x (saved forward stream: Res<T>) / dRes rows from global memory; dX goes to an LDS
 // panel (Os, may alias DYs row-for-row) and, if DX != nullptr, to global rows (16 B per lane).
 // If DXD != nullptr a second copy with the FFN-output dropout mask of the consuming layer applied
 // (model.py:237) is written as well: the mask depends only on (seed, stream, row, column).
 template <typename T, int TT, int LD>
-AMT_DEV void chain_ln_bwd_rows(const T* DYs, T* Os, const T* __restrict__ X, const float* __restrict__ mean,
+AMT_DEV void chain_ln_bwd_rows(const T* DYs, T* Os, const Res<T>* __restrict__ X, const float* __restrict__ mean,
                                const float* __restrict__ rstd, const float* __restrict__ w, const T* __restrict__ dRes,
                                T* __restrict__ DX, T* __restrict__ DXD, uint64_t seed, uint32_t stream, uint32_t thr,
                                float inv_keep, float (&cs)[2][8], long n0, long N, int tid) {

@@ -95,15 +95,17 @@ AMT_DEV void block_fwd_tile(const BlockFwdArgs& a_in, const long n0, const long 
   using S1 = ChainSplit<H2, TT>;
   using S2 = ChainSplit<C, TT>;
   constexpr int KC1 = ChainChunk<T, S1::RB, C>::KC, KC2 = ChainChunk<T, S2::RB, H2>::KC;
+  using RT = Res<T>;                                   // the Block's input x and output y: residual stream (common.h)
+  static_assert(sizeof(RT) == sizeof(T), "panels keep their size");
   T* Xs = reinterpret_cast<T*>(chain_smem);            // [TT][LDX]  LN output
-  T* Rs = Xs + TT * LDX;                               // [TT][LDX]  block input (residual)
-  T* Hs = Rs + TT * LDX;                               // [TT][LDH]  gelu(u)
+  RT* Rs = reinterpret_cast<RT*>(Xs + TT * LDX);       // [TT][LDX]  block input (residual), then y
+  T* Hs = reinterpret_cast<T*>(Rs + TT * LDX);         // [TT][LDH]  gelu(u)
   T* Us = Hs + TT * LDH;                               // [TT][LDH]  u (staged for a coalesced copy-out; SAVE only)
 
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // (& 255: the team form runs two tiles per workgroup, 256 threads each)
   const int r = lane & 15, g = lane >> 4;
   const long N = Nlim;
-  const T* X = reinterpret_cast<const T*>(a.X);
+  const RT* X = reinterpret_cast<const RT*>(a.X);
   const __amdgpu_buffer_rsrc_t xrs = team_rsrc(a.X);
   const T* W1 = reinterpret_cast<const T*>(a.W1);
   const T* W2 = reinterpret_cast<const T*>(a.W2);
@@ -157,8 +159,8 @@ AMT_DEV void block_fwd_tile(const BlockFwdArgs& a_in, const long n0, const long 
     // The seven tap rows of pass pp + 1 are requested before pass pp is evaluated (raw chunks, converted at their use):
     // one pass after the other, each pass waited for its own seven loads - eight L2 round trips in series per 128-row
     // inference tile (found in the ISA: `s_waitcnt vmcnt(0)` in front of every pass).
-    Chunk8<T> xa[7], xb[7];
-    auto issue = [&](int pp, Chunk8<T> (&xc)[7]) {
+    Chunk8<RT> xa[7], xb[7];
+    auto issue = [&](int pp, Chunk8<RT> (&xc)[7]) {
       const long row = n0 + pp * RPP + prow;
       const long rc = row < N ? row : N - 1;
       const int b = (int)(rc / a.L), l = (int)(rc % a.L);
@@ -170,13 +172,13 @@ AMT_DEV void block_fwd_tile(const BlockFwdArgs& a_in, const long n0, const long 
         if constexpr (TEAM) {
           float t[8];
           team_load8f<TEAM>(xrs, X, (rowbase + lc) * C + sub * 8, t);
-          store8f(reinterpret_cast<T*>(&xc[k]), t);
+          store8f(reinterpret_cast<RT*>(&xc[k]), t);
         } else {
           xc[k] = chunk_load(X + (rowbase + lc) * C + sub * 8);
         }
       }
     };
-    auto evaluate = [&](int pp, const Chunk8<T> (&xc)[7]) {
+    auto evaluate = [&](int pp, const Chunk8<RT> (&xc)[7]) {
       const int p = pp * RPP + prow;
       const long row = n0 + p;
       const bool valid = row < N;
@@ -284,10 +286,14 @@ AMT_DEV void block_fwd_tile(const BlockFwdArgs& a_in, const long n0, const long 
   if (!(a.dbg_slot & 512))
 #endif
   if constexpr (SAVE) chain_copy_out<T, TT, C, LDX>(Xs, reinterpret_cast<T*>(a.Z), n0, N, tid);
-  chain_copy_out<T, TT, C, LDX>(Rs, reinterpret_cast<T*>(a.Y), n0, N, tid);
+  chain_copy_out<RT, TT, C, LDX>(Rs, reinterpret_cast<RT*>(a.Y), n0, N, tid);
   if constexpr (!TEAM) {   // the LayerNorm the next operator opens with, on the y rows while they are here (kernels.h: TailLn)
-    if (a.tail.w != nullptr)
-      chain_ln_rows_out<T, TT, C, LDX>(Rs, reinterpret_cast<T*>(a.tail.Y), a.tail.w, a.tail.b, a.tail.mean, a.tail.rstd, n0, N, tid);
+    if (a.tail.w != nullptr) {
+      bool res_out = false;      // the final norm (C = 256 only) writes the transformer's stream: Res
+      if constexpr (C == 256) res_out = a.tail.y_res != 0;
+      if (res_out) chain_ln_rows_out<T, RT, TT, C, LDX>(Rs, reinterpret_cast<RT*>(a.tail.Y), a.tail.w, a.tail.b, a.tail.mean, a.tail.rstd, n0, N, tid);
+      else chain_ln_rows_out<T, T, TT, C, LDX>(Rs, reinterpret_cast<T*>(a.tail.Y), a.tail.w, a.tail.b, a.tail.mean, a.tail.rstd, n0, N, tid);
+    }
   }
   if (warm == 0x9e3779b9u && a.L < 0) a.mean[0] = 0.f;   // keeps the warm-up loads alive; never true
   AMT_STAMP(5);
@@ -594,7 +600,8 @@ __global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a, Wg
   T* DYs = reinterpret_cast<T*>(chain_smem);           // [TT][LDX]      dy (zero outside the clip)
   T* Us = DYs + TT * LDX;                              // [TT][LDH]      u, then du in place
   T* DLs = Us + TT * LDH;                              // [TT][LDX]      dln, then dD in place
-  T* Xt = DLs + TT * LDX;                              // [TT + 6][LDX]  block input, rows l0 - 6 .. (zero outside)
+  using RT = Res<T>;                                   // the saved Block input: residual stream (common.h)
+  RT* Xt = reinterpret_cast<RT*>(DLs + TT * LDX);      // [TT + 6][LDX]  block input, rows l0 - 6 .. (zero outside)
   float* part = reinterpret_cast<float*>(chain_smem);   // [4 waves][11 * C], over DYs/Us/DLs once they are dead
   static_assert(sizeof(T) * (TT * (2 * LDX + LDH) + (TT + 6) * LDX) >= sizeof(float) * 44 * C, "column-sum slices fit over the dead panels (Xt included: dead after row phase 2)");
 
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a, Wg
   const int L = a.L;
   const long rb = (long)b * L;
   const T* dY = reinterpret_cast<const T*>(a.dY);
-  const T* X = reinterpret_cast<const T*>(a.X);
+  const RT* X = reinterpret_cast<const RT*>(a.X);
   const T* U = reinterpret_cast<const T*>(a.U);
   const T* WA = reinterpret_cast<const T*>(a.W2tg);
   const T* WB = reinterpret_cast<const T*>(a.W1t);
@@ -649,7 +656,8 @@ __global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a, Wg
   // while the stage-A products run and go to LDS after them - at the start of a launch every workgroup of the chip is
   // waiting for its first bytes at once and that round trip is the longest phase of the tile (profiles/r02_notes.md).
   constexpr int NP = TT / RPP, NPX = (TT + 6 + RPP - 1) / RPP;
-  Chunk8<T> dyc[NP], uc0[NP], uc1[NP], xcr[NPX];
+  Chunk8<T> dyc[NP], uc0[NP], uc1[NP];
+  Chunk8<RT> xcr[NPX];
 #pragma unroll
   for (int pp = 0; pp < NP; ++pp) {
     const int l = l0 - 3 + pp * RPP + prow;
@@ -671,7 +679,7 @@ __global__ __launch_bounds__(256) void block_bwd_fused_kernel(BlockBwdArgs a, Wg
     const bool in = l >= 0 && l < L;
     const int lc = l < 0 ? 0 : (l >= L ? L - 1 : l);
     xcr[pp] = chunk_load(X + (rb + lc) * C + sub * 8);
-    if (!in) xcr[pp] = chunk_zero<T>();
+    if (!in) xcr[pp] = chunk_zero<RT>();
   }
 #pragma unroll
   for (int pp = 0; pp < NP; ++pp) chunk_store(DYs + (pp * RPP + prow) * LDX + sub * 8, dyc[pp]);
@@ -949,10 +957,12 @@ AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem, const void* 
   constexpr int KCO = ChainChunk<T, SO::RB, H, 32>::KC, KC1 = ChainChunk<T, S1::RB, H, 32>::KC,
                 KC2 = ChainChunk<T, SO::RB, I, 32>::KC;
   static_assert(S1::RB % 2 == 0, "a wave owns whole (u1 | u2) row-block pairs");
+  using RT = Res<T>;                          // x, h, y: residual stream (common.h)
+  static_assert(sizeof(RT) == sizeof(T), "panels keep their size");
   T* As = reinterpret_cast<T*>(chain_smem);   // [TT][LDX]  attention output, then LN2(h)
-  T* Xs = As + TT * LDX;                      // [TT][LDX]  x, then y (staged for the copy-out)
-  T* Hs = Xs + TT * LDX;                      // [TT][LDX]  h
-  T* Gs = Hs + TT * LDX;                      // [TT][LDG]  g
+  RT* Xs = reinterpret_cast<RT*>(As + TT * LDX);   // [TT][LDX]  x, then y (staged for the copy-out)
+  RT* Hs = Xs + TT * LDX;                     // [TT][LDX]  h
+  T* Gs = reinterpret_cast<T*>(Hs + TT * LDX);     // [TT][LDG]  g
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -980,8 +990,8 @@ AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem, const void* 
   Frag<T> wo[KCO][SO::RB];
   chain_load_w<T, SO::RB, KCO, H>(wo, Wo, mO, 0, lane);
   chain_copy_in<T, TT, H, LDX>(As, reinterpret_cast<const T*>(a.AO), n0, N, tid);
-  ChainCopyRegs<T, TT, H> xreg;     // x is read by the residual epilogue only: it lands while the products run
-  chain_copy_load<T, TT, H>(xreg, reinterpret_cast<const T*>(a.X), H, n0, N, tid);
+  ChainCopyRegs<RT, TT, H> xreg;    // x is read by the residual epilogue only: it lands while the products run
+  chain_copy_load<RT, TT, H>(xreg, reinterpret_cast<const RT*>(a.X), H, n0, N, tid);
   // The two FFN biases are requested here and parked in LDS.  Read from global memory where the epilogues use them (two
   // 16-byte loads per row-block pair, waited for on the spot), each was an L2 round trip between a stage's products and
   // its stores: ~8 per tile in the ISA.
@@ -1008,7 +1018,7 @@ AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem, const void* 
     f32x4 acc[SO::RB][SO::NT];
     chain_zero(acc);
     chain_stage<T, SO::RB, SO::NT, KCO, H>(acc, wo, Wo, mO, As, LDX, tO, lane);
-    chain_copy_store<T, TT, H, LDX>(Xs, xreg, tid);
+    chain_copy_store<RT, TT, H, LDX>(Xs, xreg, tid);
     __syncthreads();
     if constexpr (FULL) chain_load_w<T, S1::RB, KC1, H>(w1a, W1, m1, 0, lane);   // in flight during the LayerNorm pass
 #pragma unroll
@@ -1029,7 +1039,7 @@ AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem, const void* 
   AMT_STAMP(2);
   // ---- hn = LN2(h) over the panel rows (As is dead: it receives hn)
   chain_ln_rows<T, TT, H, LDX>(Hs, As, a.ln_w, a.ln_b, a.mean, a.rstd, n0, N, tid);
-  chain_copy_out<T, TT, H, LDX>(Hs, reinterpret_cast<T*>(a.Hout), n0, N, tid);
+  chain_copy_out<RT, TT, H, LDX>(Hs, reinterpret_cast<RT*>(a.Hout), n0, N, tid);
   __syncthreads();
   chain_copy_out<T, TT, H, LDX>(As, reinterpret_cast<T*>(a.HN), n0, N, tid);
   AMT_STAMP(3);
@@ -1113,7 +1123,7 @@ AMT_DEV void ffn_fwd_body(FfnFwdArgs& a, unsigned char* chain_smem, const void* 
     }
   }
   __syncthreads();
-  chain_copy_out<T, TT, H, LDX>(Xs, reinterpret_cast<T*>(a.Y), n0, N, tid);
+  chain_copy_out<RT, TT, H, LDX>(Xs, reinterpret_cast<RT*>(a.Y), n0, N, tid);
   if (warm == 0x9e3779b9u && a.N < 0) a.mean[0] = 0.f;   // keeps the warm-up loads alive; never true
   AMT_STAMP(5);
   AMT_STAMP_RT(7);
@@ -1249,12 +1259,14 @@ AMT_DEV void rope_quad(float (&v)[4], float2 c, float2 s) {
 }
 
 template <typename T, int TT, int RM>
-AMT_DEV void qkv_fwd_body(const QkvFwdArgs& a, unsigned char* chain_smem, const T* XLDS, QkvRope<TT, RM>& rope) {
+AMT_DEV void qkv_fwd_body(const QkvFwdArgs& a, unsigned char* chain_smem, const Res<T>* XLDS, QkvRope<TT, RM>& rope) {
   constexpr int H = 256, QC = 320, CK = 64, KV = 512, LDX = H + 8, LDQ = QC + 8, LDK = KV + 8;
   using SQ = ChainSplit<QC, TT>;
   using SK = ChainSplit<KV, TT>;
   constexpr int KCQ = ChainChunk<T, SQ::RB, H, 32>::KC, KCK = ChainChunk<T, SK::RB, CK>::KC;
-  T* Xs = reinterpret_cast<T*>(chain_smem);   // [TT][LDX]  x, then LN1(x) in place
+  using RT = Res<T>;                          // x: residual stream (common.h), same size as T: LN1 runs in place
+  T* Xs = reinterpret_cast<T*>(chain_smem);   // [TT][LDX]  x (as RT), then LN1(x) in place (as T)
+  RT* Xr = reinterpret_cast<RT*>(chain_smem);
   T* Qs = Xs + TT * LDX;                      // [TT][LDQ]  qc
   T* Ks = Qs + TT * LDQ;                      // [TT][LDK]  kv
   rope.stage_rows(a, reinterpret_cast<float*>(Ks + TT * LDK));   // (rotated long-tile form: [TT][64] floats behind the panels)
@@ -1278,17 +1290,17 @@ AMT_DEV void qkv_fwd_body(const QkvFwdArgs& a, unsigned char* chain_smem, const 
   Frag<T> wq[KCQ][SQ::RB], wk[KCK][SK::RB];
   chain_load_w<T, SQ::RB, KCQ, H>(wq, Wq, mQ, 0, lane);
   if (XLDS == nullptr) {
-    chain_copy_in<T, TT, H, LDX>(Xs, reinterpret_cast<const T*>(a.X), n0, N, tid);
+    chain_copy_in<RT, TT, H, LDX>(Xr, reinterpret_cast<const RT*>(a.X), n0, N, tid);
   } else {                                   // rows past N hold zeros there as well (masked when they were computed)
     constexpr int CPR = H / 8;
     for (int id = tid; id < TT * CPR; id += 256) {
       const int p = id / CPR, c = id % CPR;
-      chunk_store(Xs + p * LDX + 8 * c, chunk_load(XLDS + p * LDX + 8 * c));
+      chunk_store(Xr + p * LDX + 8 * c, chunk_load(XLDS + p * LDX + 8 * c));
     }
   }
   __syncthreads();
   AMT_STAMP(1);
-  chain_ln_rows<T, TT, H, LDX>(Xs, Xs, a.ln_w, a.ln_b, a.mean, a.rstd, n0, N, tid);
+  chain_ln_rows<T, TT, H, LDX>(Xr, Xs, a.ln_w, a.ln_b, a.mean, a.rstd, n0, N, tid);
   chain_load_w<T, SK::RB, KCK, CK>(wk, Wk, mK, 0, lane);
   __syncthreads();
   AMT_STAMP(2);
@@ -1371,7 +1383,7 @@ __global__ __launch_bounds__(256) void ffn_qkv_fwd_fused_kernel(FfnFwdArgs fa, Q
   ffn_fwd_body<T, TT, true>(fa, chain_smem, qa.Wqc, sizeof(T) * (size_t)320 * 256, qa.Wkv, sizeof(T) * (size_t)512 * 64);
   __syncthreads();                                   // the copy-out of y has read its panel; every panel is free
   // y sits in the SECOND [TT][LDX] panel of the FFN body; the q/kv body keeps x in the first: copy, then go on
-  const T* ys = reinterpret_cast<const T*>(chain_smem) + TT * LDX;
+  const Res<T>* ys = reinterpret_cast<const Res<T>*>(chain_smem) + TT * LDX;
   qkv_fwd_body<T, TT, RM>(qa, chain_smem, ys, rope);
 }
 
@@ -1527,7 +1539,7 @@ __global__ __launch_bounds__(256, 2) void qkv_bwd_fused_kernel(QkvBwdArgs a, Wgr
   float cs[2][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { cs[0][i] = 0.f; cs[1][i] = 0.f; }
-  chain_ln_bwd_rows<T, TT, LDX>(Xs, Xs, reinterpret_cast<const T*>(a.X), a.mean, a.rstd, a.ln_w,
+  chain_ln_bwd_rows<T, TT, LDX>(Xs, Xs, reinterpret_cast<const Res<T>*>(a.X), a.mean, a.rstd, a.ln_w,
                                 reinterpret_cast<const T*>(a.dH), reinterpret_cast<T*>(a.dX),
                                 a.drop_thresh24 ? reinterpret_cast<T*>(a.dXD) : nullptr, a.seed, a.stream,
                                 a.drop_thresh24, a.inv_keep, cs, n0, N, tid);
@@ -1572,7 +1584,7 @@ __global__ __launch_bounds__(256) void lnout_bwd_fused_kernel(LnOutBwdArgs a, Wg
   float cs[2][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { cs[0][i] = 0.f; cs[1][i] = 0.f; }
-  chain_ln_bwd_rows<T, TT, LDX>(Ds, Ds, reinterpret_cast<const T*>(a.Hres), a.mean, a.rstd, a.ln_w,
+  chain_ln_bwd_rows<T, TT, LDX>(Ds, Ds, reinterpret_cast<const Res<T>*>(a.Hres), a.mean, a.rstd, a.ln_w,
                                 reinterpret_cast<const T*>(a.dY), reinterpret_cast<T*>(a.dH), nullptr, 0, 0, 0, 1.f, cs,
                                 n0, N, tid);
   fold_columns<32, 16>(*reinterpret_cast<float (*)[16]>(&cs[0][0]), part + wave * 2 * H, H, lane);
@@ -1712,7 +1724,7 @@ __global__ __launch_bounds__(256) void ffn_bwd_fused_kernel(FfnBwdArgs a, WgradG
   float cs[2][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { cs[0][i] = 0.f; cs[1][i] = 0.f; }
-  chain_ln_bwd_rows<T, TT, LDX>(Ds, Ds, reinterpret_cast<const T*>(a.Hres), a.mean, a.rstd, a.ln_w,
+  chain_ln_bwd_rows<T, TT, LDX>(Ds, Ds, reinterpret_cast<const Res<T>*>(a.Hres), a.mean, a.rstd, a.ln_w,
                                 reinterpret_cast<const T*>(a.dY), reinterpret_cast<T*>(a.dH), nullptr, 0, 0, 0, 1.f, cs,
                                 n0, N, tid);
   fold_columns<32, 16>(*reinterpret_cast<float (*)[16]>(&cs[0][0]), part + wave * 2 * H, H, lane);

@@ -42,6 +42,7 @@ namespace {
 template <typename T> struct Vec4T;
 template <> struct Vec4T<bf16> { typedef bf16x4 type; };
 template <> struct Vec4T<float> { typedef f32x4 type; };
+template <> struct Vec4T<f16> { typedef f16x4 type; };
 
 template <typename T> AMT_DEV typename Vec4T<T>::type ld4(const T* p) { return *reinterpret_cast<const typename Vec4T<T>::type*>(p); }
 
@@ -106,9 +107,11 @@ AMT_DEV void ffn_fwd_big_body(FfnFwdArgs& a) {
   a.seed = eff_seed(a.seed, a.seed_dev);
   constexpr int H = 256, I = 512, I2 = 1024, LDX = H + 8, SW = 64, LDG = SW + 8, NT = TT / 16 / WT, NS = I / SW;
   constexpr int KS1 = H / 32, KS2 = I / 32, TH = TT / WT;   // TH: tokens per wave / per 256-thread row-phase group
-  typedef typename Vec4T<T>::type V4;
   extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
-  T* As = reinterpret_cast<T*>(big_smem);   // [TT][LDX]     ao, then h, then hn = LN2(h), then y
+  using RT = Res<T>;                        // x, h, y: residual stream (common.h); same size as T, so the token panel holds either
+  static_assert(sizeof(RT) == sizeof(T), "panels keep their size");
+  typedef typename Vec4T<RT>::type RV4;
+  T* As = reinterpret_cast<T*>(big_smem);   // [TT][LDX]     ao (T), then h (RT), then hn = LN2(h) (T), then y (RT)
   T* Gs = As + TT * LDX;                    // [2][TT][LDG]  g slices (double-buffered)
   __shared__ __attribute__((aligned(16))) float s_b1[I2], s_b2[H];
 
@@ -127,13 +130,13 @@ AMT_DEV void ffn_fwd_big_body(FfnFwdArgs& a) {
   constexpr int KCO = ChainChunk<T, 4, H>::KC;
   Frag<T> wo[KCO][4];
   chain_load_w<T, 4, KCO, H>(wo, Wo, mO, 0, lane);
-  V4 hx[4][NT];                                   // x, then h = x + ao . Wo^T (as stored: T), until the last epilogue
+  RV4 hx[4][NT];                                  // x, then h = x + ao . Wo^T (as stored: RT), until the last epilogue
   {
-    const T* X = reinterpret_cast<const T*>(a.X);
+    const RT* X = reinterpret_cast<const RT*>(a.X);
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) {             // token block outer: the four loads of a block share its 128-byte lines
       const long row = nh + 16 * ti + r;
-      const T* xp = X + (row < N ? row : N - 1) * H + mO + 4 * g;
+      const RT* xp = X + (row < N ? row : N - 1) * H + mO + 4 * g;
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) hx[rb][ti] = ld4(xp + 16 * rb);
     }
@@ -158,11 +161,11 @@ AMT_DEV void ffn_fwd_big_body(FfnFwdArgs& a) {
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
       for (int ti = 0; ti < NT; ++ti) {
-        V4 hv;                                    // h as stored (rounded to T): what the residual adds at the end
+        RV4 hv;                                   // h as stored (rounded to RT): what the residual adds at the end
 #pragma unroll
-        for (int i = 0; i < 4; ++i) hv[i] = from_f<T>(acc[rb][ti][i] + to_f(hx[rb][ti][i]));
+        for (int i = 0; i < 4; ++i) hv[i] = from_f<RT>(acc[rb][ti][i] + to_f(hx[rb][ti][i]));
         hx[rb][ti] = hv;
-        *reinterpret_cast<V4*>(Ah + (16 * ti + r) * LDX + mO + 16 * rb + 4 * g) = hv;
+        *reinterpret_cast<RV4*>(reinterpret_cast<RT*>(Ah) + (16 * ti + r) * LDX + mO + 16 * rb + 4 * g) = hv;
       }
   }
   BIG_ACC(1);
@@ -174,10 +177,10 @@ AMT_DEV void ffn_fwd_big_body(FfnFwdArgs& a) {
     for (int q = 0; q < 2; ++q) w1[ks][q] = wfrag(W1, 2 * wave + q, KS1, ks, lane);
   __syncthreads();
   if constexpr (SAVE) {
-    chain_copy_out<T, TH, H, LDX>(Ah, reinterpret_cast<T*>(a.Hout), nh, N, tid);
+    chain_copy_out<RT, TH, H, LDX>(reinterpret_cast<RT*>(Ah), reinterpret_cast<RT*>(a.Hout), nh, N, tid);
     __syncthreads();
   }
-  chain_ln_rows<T, TH, H, LDX>(Ah, Ah, a.ln_w, a.ln_b, a.mean, a.rstd, nh, N, tid);
+  chain_ln_rows<T, TH, H, LDX>(reinterpret_cast<const RT*>(Ah), Ah, a.ln_w, a.ln_b, a.mean, a.rstd, nh, N, tid);
   __syncthreads();
   if constexpr (SAVE) chain_copy_out<T, TH, H, LDX>(Ah, reinterpret_cast<T*>(a.HN), nh, N, tid);
   BIG_ACC(2);
@@ -275,14 +278,14 @@ AMT_DEV void ffn_fwd_big_body(FfnFwdArgs& a) {
           }
           y[i] = v + to_f(hx[rb][ti][i]);
         }
-        store4f(As + p * LDX + m, y);
+        store4f(reinterpret_cast<RT*>(As) + p * LDX + m, y);
       }
     }
   };
   if (a.drop_thresh24) y_epilogue(std::true_type{}); else y_epilogue(std::false_type{});   // one uniform branch, not one per element
   BIG_ACC(8);
   __syncthreads();
-  chain_copy_out<T, TH, H, LDX>(Ah, reinterpret_cast<T*>(a.Y), nh, N, tid);
+  chain_copy_out<RT, TH, H, LDX>(reinterpret_cast<RT*>(Ah), reinterpret_cast<RT*>(a.Y), nh, N, tid);
   BIG_ACC(9);
 }
 

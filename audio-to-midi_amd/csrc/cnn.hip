@@ -5,6 +5,7 @@
 //   scale_bwd                layer-scale gamma                                      model.py:166
 // The pointwise convs of Block and the k2/s2 conv of Downsample are GEMMs (gemm.hip): in
 // channels-last a stride-2 kernel-2 conv is a Linear over two concatenated positions.
+// The Blocks' input x / output y (and the Stem's output) are the forward residual stream: stored as Res<T> (common.h).
 #include "rowops.h"
 #include "kernels.h"
 #include "prof.h"
@@ -39,7 +40,7 @@ AMT_DEV void stem_stage_audio(const T* audio, float (*xs)[STEM_SAMP], int b, lon
 template <typename T>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const T* __restrict__ audio, const float* __restrict__ w,
                                                        const float* __restrict__ bias, const float* __restrict__ lnw,
-                                                       const float* __restrict__ lnb, T* __restrict__ Y, int B, int T_,
+                                                       const float* __restrict__ lnb, Res<T>* __restrict__ Y, int B, int T_,
                                                        int L, int tiles_per_clip) {
   __shared__ float xs[2][STEM_SAMP];
   const int b = blockIdx.x / tiles_per_clip, tile = blockIdx.x % tiles_per_clip;
@@ -155,7 +156,7 @@ void stem_fwd(hipStream_t s, DType dt, const void* audio, const float* w, const 
                        (float*)Y, B, T_, L, tiles);
   else
     hipLaunchKernelGGL((stem_fwd_kernel<bf16>), dim3(B * tiles), dim3(256), 0, s, (const bf16*)audio, w, b, lnw, lnb,
-                       (bf16*)Y, B, T_, L, tiles);
+                       (Res<bf16>*)Y, B, T_, L, tiles);
 }
 
 void stem_bwd(hipStream_t s, DType dt, const void* audio, const void* dY, const float* w, const float* b,
@@ -185,8 +186,8 @@ void stem_bwd(hipStream_t s, DType dt, const void* audio, const void* dY, const 
 
 // ------------------------------------------------------------------ depthwise conv k7 (+ LayerNorm)
 // conv output of row (b, l), feature chunk `sub`: sum_k w[k][c] X[b][l + k - 3][c] + bias[c]
-template <typename T, int VEC>
-AMT_DEV void dwconv_row(const T* __restrict__ X, long rowbase /* b*L */, int l, int L, int C, int sub,
+template <typename TX, int VEC>
+AMT_DEV void dwconv_row(const TX* __restrict__ X, long rowbase /* b*L */, int l, int L, int C, int sub,
                         const float (&wk)[7][VEC], const float (&bv)[VEC], float (&out)[VEC]) {
   // all seven taps are loaded unconditionally from a clamped row and masked afterwards: a branch
   // per tap would serialise seven L2 round trips (measured ~4 us per row visit)
@@ -209,7 +210,7 @@ AMT_DEV void dwconv_row(const T* __restrict__ X, long rowbase /* b*L */, int l, 
 }
 
 template <typename T, int C>
-__global__ __launch_bounds__(256) void dwln_fwd_kernel(const T* __restrict__ X, const float* __restrict__ wdw,
+__global__ __launch_bounds__(256) void dwln_fwd_kernel(const Res<T>* __restrict__ X, const float* __restrict__ wdw,
                                                        const float* __restrict__ bdw, const float* __restrict__ lnw,
                                                        const float* __restrict__ lnb, T* __restrict__ Y,
                                                        float* __restrict__ mean, float* __restrict__ rstd, int B,
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void dwln_fwd_kernel(const T* __restrict__ X, 
   for (long row = ((long)blockIdx.x * 4 + wave) * R::RPW + rw; row < N; row += (long)gridDim.x * R::RPB) {
     int b = (int)(row / L), l = (int)(row % L);
     float d[VEC];
-    dwconv_row<T, VEC>(X, (long)b * L, l, L, C, sub, wk, bv, d);
+    dwconv_row<Res<T>, VEC>(X, (long)b * L, l, L, C, sub, wk, bv, d);
     float mu, rs;
     ln_stats<VEC, LPR>(d, mu, rs);
     float y[VEC];
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void dwln_fwd_kernel(const T* __restrict__ X, 
 }
 
 template <typename T, int C>
-__global__ __launch_bounds__(256) void dwln_bwd_kernel(const T* __restrict__ dY, const T* __restrict__ X,
+__global__ __launch_bounds__(256) void dwln_bwd_kernel(const T* __restrict__ dY, const Res<T>* __restrict__ X,
                                                        const float* __restrict__ wdw, const float* __restrict__ bdw,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ lnw, T* __restrict__ dD,
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void dwln_bwd_kernel(const T* __restrict__ dY,
   for (long row = ((long)blockIdx.x * 4 + wave) * R::RPW + rw; row < N; row += (long)gridDim.x * R::RPB) {
     int b = (int)(row / L), l = (int)(row % L);
     float d[VEC], dy[VEC];
-    dwconv_row<T, VEC>(X, (long)b * L, l, L, C, sub, wk, bv, d);
+    dwconv_row<Res<T>, VEC>(X, (long)b * L, l, L, C, sub, wk, bv, d);
     loadvf<VEC>(dY + row * C + sub * VEC, dy);
     float mu = mean[row], rs = rstd[row];
     float s1 = 0.f, s2 = 0.f, gy[VEC];
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256) void dwln_bwd_kernel(const T* __restrict__ dY,
 }
 
 template <typename T, int C>
-__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ dD, const T* __restrict__ X,
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ dD, const Res<T>* __restrict__ X,
                                                          const float* __restrict__ wdw, const T* dRes, T* dX,
                                                          float* __restrict__ dwdw, float* __restrict__ dbdw, int B,
                                                          int L, int pstride) {
@@ -377,7 +378,7 @@ template <int C> struct DwTile {
 
 template <typename T, int C>
 __global__ __launch_bounds__(256) void dwblock_bwd_kernel(
-    const T* __restrict__ dLN, const T* __restrict__ X, const T* __restrict__ dY, const T* __restrict__ Z,
+    const T* __restrict__ dLN, const Res<T>* __restrict__ X, const T* __restrict__ dY, const T* __restrict__ Z,
     const float* __restrict__ wdw, const float* __restrict__ bdw, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ lnw, T* __restrict__ dX, float* dlnw, float* dlnb,
     float* dwdw, float* dbdw, float* dgamma, int B, int L, int tiles_per_clip, int total_tiles, int pstride) {
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(256) void dwblock_bwd_kernel(
       const bool valid = (l >= 0) && (l < L);
       const int lcl = l < 0 ? 0 : (l >= L ? L - 1 : l);
       float d[VEC], dl[VEC], o[VEC];
-      dwconv_row<T, VEC>(X, rb, lcl, L, C, sub, wk, bv, d);
+      dwconv_row<Res<T>, VEC>(X, rb, lcl, L, C, sub, wk, bv, d);
       loadvf<VEC>(dLN + (rb + lcl) * C + sub * VEC, dl);
       const float mu = mean[rb + lcl], rs = rstd[rb + lcl];
       const float fin = (valid && p >= 3 && p < TL + 3) ? 1.f : 0.f;
@@ -506,7 +507,7 @@ static void dwblock_bwd_t(hipStream_t s, const void* dLN, const void* X, const v
                           void* dX, float* dlnw, float* dlnb, float* dwdw, float* dbdw, float* dgamma, int B, int L, int C,
                           int nb, int tiles_per_clip, int total, int pstride) {
   AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwblock_bwd_kernel<T, CC>), dim3(nb), dim3(256), 0, s, (const T*)dLN,
-                                       (const T*)X, (const T*)dY, (const T*)Z, wdw, bdw, mean, rstd, lnw, (T*)dX, dlnw,
+                                       (const Res<T>*)X, (const T*)dY, (const T*)Z, wdw, bdw, mean, rstd, lnw, (T*)dX, dlnw,
                                        dlnb, dwdw, dbdw, dgamma, B, L, tiles_per_clip, total, pstride));
 }
 
@@ -555,11 +556,11 @@ void dwblock_bwd(hipStream_t s, DType dt, const void* dLN, const void* X, const 
 // and predict() stopped matching the training forward bit for bit.)
 template <typename T, int C>
 __global__ __launch_bounds__(256, 2) void block_small_fwd_kernel(
-    const T* __restrict__ X, const float* __restrict__ wdw, const float* __restrict__ bdw,
+    const Res<T>* __restrict__ X, const float* __restrict__ wdw, const float* __restrict__ bdw,
     const float* __restrict__ lnw, const float* __restrict__ lnb, const T* __restrict__ w1, const float* __restrict__ b1,
     const T* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ gamma, T* __restrict__ LN,
     float* __restrict__ mean, float* __restrict__ rstd, T* __restrict__ U, T* __restrict__ Hh, T* __restrict__ Z,
-    T* __restrict__ Y, int B, int L, TailLn tail, int save) {
+    Res<T>* __restrict__ Y, int B, int L, TailLn tail, int save) {
   constexpr int H2 = 2 * C;
   __shared__ __attribute__((aligned(16))) float sw1[H2 * C], sw2[C * H2], sb1[H2], sb2[C], sg[C], sdw[7 * C], sbd[C], slw[C], slb[C];
   __shared__ __attribute__((aligned(16))) float stw[C], stb[C];
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void block_small_fwd_kernel(
     if (tail.w != nullptr) {   // LayerNorm of the stored y row (kernels.h: TailLn), the roundings of ln_fwd_kernel
       float t[C], tm, tr;
 #pragma unroll
-      for (int c = 0; c < C; ++c) t[c] = to_f(from_f<T>(y[c]));
+      for (int c = 0; c < C; ++c) t[c] = to_f(from_f<Res<T>>(y[c]));
       ln_stats<C, 1>(t, tm, tr);
 #pragma unroll
       for (int c = 0; c < C; ++c) t[c] = ln_apply(t[c], tr, stw[wz + c], stb[wz + c]);
@@ -737,7 +738,7 @@ template <int C> struct SmallBwd {
 // two waves per SIMD (512 workgroups resident at once instead of two rounds of 256).
 template <typename T, int C, bool ONE>
 __global__ __launch_bounds__(256, ONE ? 2 : 1) void block_small_bwd_full_kernel(
-    const T* __restrict__ dY, const T* __restrict__ X, const T* __restrict__ U, const T* __restrict__ Hh,
+    const T* __restrict__ dY, const Res<T>* __restrict__ X, const T* __restrict__ U, const T* __restrict__ Hh,
     const T* __restrict__ Z, const T* __restrict__ LNs, const float* __restrict__ mean, const float* __restrict__ rstd,
     const T* __restrict__ w2tg, const T* __restrict__ w1t, const float* __restrict__ wdw, const float* __restrict__ bdw,
     const float* __restrict__ lnw, const float* __restrict__ gamma, T* __restrict__ dX, float* __restrict__ rec, int B,
@@ -951,7 +952,7 @@ static void block_small_bwd_full_launch(hipStream_t s, const SmallBwdArgs& a, fl
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), true);
     (void)once;
   }
-  hipLaunchKernelGGL((block_small_bwd_full_kernel<T, C, ONE>), dim3(nb), dim3(256), lds, s, (const T*)a.dY, (const T*)a.X,
+  hipLaunchKernelGGL((block_small_bwd_full_kernel<T, C, ONE>), dim3(nb), dim3(256), lds, s, (const T*)a.dY, (const Res<T>*)a.X,
                      (const T*)a.U, (const T*)a.Hh, (const T*)a.Z, (const T*)a.LN, a.mean, a.rstd, (const T*)a.w2tg,
                      (const T*)a.w1t, a.wdw, a.bdw, a.lnw, a.gamma, (T*)a.dX, rec, a.B, a.L, tiles_per_clip, total);
 }
@@ -1001,8 +1002,8 @@ void block_small_fwd(hipStream_t s, DType dt, const void* X, const float* wdw, c
   const bool save = U != nullptr;      // inference passes no save tensors
   ProfScope ps(s, "block_small_fwd", 2.0 * N * (7 * C + 4 * C * C), (save ? 8.0 : 2.0) * N * C * (dt == DT_F32 ? 4 : 2));
 #define AMT_LAUNCH_SF(TT, CC_)                                                                                         \
-  hipLaunchKernelGGL((block_small_fwd_kernel<TT, CC_>), dim3(grid), dim3(256), 0, s, (const TT*)X, wdw, bdw, lnw, lnb,  \
-                     (const TT*)w1, b1, (const TT*)w2, b2, gamma, (TT*)LN, mean, rstd, (TT*)U, (TT*)Hh, (TT*)Z, (TT*)Y, \
+  hipLaunchKernelGGL((block_small_fwd_kernel<TT, CC_>), dim3(grid), dim3(256), 0, s, (const Res<TT>*)X, wdw, bdw, lnw, lnb,  \
+                     (const TT*)w1, b1, (const TT*)w2, b2, gamma, (TT*)LN, mean, rstd, (TT*)U, (TT*)Hh, (TT*)Z, (Res<TT>*)Y, \
                      B, L, tl, save ? 1 : 0)
   if (dt == DT_F32) { if (C == 4) AMT_LAUNCH_SF(float, 4); else AMT_LAUNCH_SF(float, 8); }
   else { if (C == 4) AMT_LAUNCH_SF(bf16, 4); else AMT_LAUNCH_SF(bf16, 8); }
@@ -1026,20 +1027,20 @@ static void dwln_fwd_t(hipStream_t s, const void* X, const float* wdw, const flo
                        const float* lnb, void* Y, float* mean, float* rstd, int B, int L, int C) {
   long N = (long)B * L;
   AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwln_fwd_kernel<T, CC>), dim3(row_grid(N, RowCfg<CC>::RPB)), dim3(256), 0, s,
-                                       (const T*)X, wdw, bdw, lnw, lnb, (T*)Y, mean, rstd, B, L));
+                                       (const Res<T>*)X, wdw, bdw, lnw, lnb, (T*)Y, mean, rstd, B, L));
 }
 template <typename T>
 static void dwln_bwd_t(hipStream_t s, const void* dY, const void* X, const float* wdw, const float* bdw,
                        const float* mean, const float* rstd, const float* lnw, void* dD, float* dlnw, float* dlnb,
                        int B, int L, int C, int nb, int pstride) {
-  AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwln_bwd_kernel<T, CC>), dim3(nb), dim3(256), 0, s, (const T*)dY, (const T*)X,
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwln_bwd_kernel<T, CC>), dim3(nb), dim3(256), 0, s, (const T*)dY, (const Res<T>*)X,
                                        wdw, bdw, mean, rstd, lnw, (T*)dD, dlnw, dlnb, B, L, pstride));
 }
 template <typename T>
 static void dwconv_bwd_t(hipStream_t s, const void* dD, const void* X, const float* wdw, const void* dRes, void* dX,
                          float* dwdw, float* dbdw, int B, int L, int C, int nb, int pstride) {
   AMT_DISPATCH_C(C, hipLaunchKernelGGL((dwconv_bwd_kernel<T, CC>), dim3(nb), dim3(256), 0, s, (const T*)dD,
-                                       (const T*)X, wdw, (const T*)dRes, (T*)dX, dwdw, dbdw, B, L, pstride));
+                                       (const Res<T>*)X, wdw, (const T*)dRes, (T*)dX, dwdw, dbdw, B, L, pstride));
 }
 template <typename T>
 static void scale_bwd_t(hipStream_t s, const void* dY, const void* Z, const float* gamma, void* dZ, float* dgamma,

@@ -9,11 +9,28 @@ namespace amt {
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define AMT_DEV __device__ __forceinline__
 constexpr int WAVE = 64;
+
+// ------------------------------------------------------------------ the forward RESIDUAL STREAM's storage type
+// Res<T>: how a context with activation type T stores the tensors of its forward residual stream - the CNN stream (Stem /
+// Downsample / Block outputs: x and y = x + gamma z of model.py:160-167) and the transformer stream (x, h = x + attn,
+// y = h + ffn of model.py:545-556, and the final CNN LayerNorm output that starts it).  float contexts: float.  bf16
+// contexts: IEEE half - the reference's own activation type (train.py:35-37), 11 significand bits in the same two bytes:
+// every LDS panel, copy loop and allocation keeps its size.  The stream is re-rounded at each of its 39 + 32 additions and
+// every branch reads it through a LayerNorm; stored as bf16 (8 bits) those roundings alone put 2.4e-2 + 2.2e-2 of the
+// 3.7e-2 maximum logit error of the bf16 path at the benchmark shape (profiles/r04_bf16_rounding_study.txt), against
+// SURVEY 8(c)'s bound of 3e-2; as half they are below 2e-3.  Everything a GEMM multiplies (LayerNorm outputs, q, k, v,
+// attention output, u, g, h = gelu(u)), every gradient (bf16's range: no loss scale) and the audio stay T.
+template <typename T> struct ResOf { typedef T type; };
+template <> struct ResOf<bf16> { typedef f16 type; };
+template <typename T> using Res = typename ResOf<T>::type;
 
 // ------------------------------------------------------------------ scalar conversions
 template <typename T> AMT_DEV float to_f(T x) { return (float)x; }
@@ -24,11 +41,34 @@ template <typename T> AMT_DEV T from_f(float x) { return (T)x; }
 template <typename T> struct V8;
 template <> struct V8<bf16> { bf16x8 v; };
 template <> struct V8<float> { f32x4 a, b; };
+template <> struct V8<f16> { f16x8 v; };
 
 AMT_DEV void load8f(const bf16* p, float (&o)[8]) {
   bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
   for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+}
+AMT_DEV void load8f(const f16* p, float (&o)[8]) {
+  f16x8 v = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+}
+AMT_DEV void store8f(f16* p, const float (&o)[8]) {
+  f16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (f16)o[i];
+  *reinterpret_cast<f16x8*>(p) = v;
+}
+AMT_DEV void load4f(const f16* p, float (&o)[4]) {
+  f16x4 v = *reinterpret_cast<const f16x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (float)v[i];
+}
+AMT_DEV void store4f(f16* p, const float (&o)[4]) {
+  f16x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = (f16)o[i];
+  *reinterpret_cast<f16x4*>(p) = v;
 }
 AMT_DEV void load8f(const float* p, float (&o)[8]) {
   f32x4 a = *reinterpret_cast<const f32x4*>(p);
@@ -83,8 +123,13 @@ template <int VEC, typename T> AMT_DEV void storevf(T* p, const float (&o)[VEC])
 template <typename T> struct Chunk8;
 template <> struct Chunk8<bf16> { bf16x8 v; };
 template <> struct Chunk8<float> { f32x4 a, b; };
+template <> struct Chunk8<f16> { f16x8 v; };
 
 template <typename T> AMT_DEV Chunk8<T> chunk_zero();
+template <> AMT_DEV Chunk8<f16> chunk_zero<f16>() { Chunk8<f16> c; for (int i = 0; i < 8; ++i) c.v[i] = (f16)0.f; return c; }
+AMT_DEV Chunk8<f16> chunk_load(const f16* p) { Chunk8<f16> c; c.v = *reinterpret_cast<const f16x8*>(p); return c; }
+AMT_DEV void chunk_store(f16* p, const Chunk8<f16>& c) { *reinterpret_cast<f16x8*>(p) = c.v; }
+AMT_DEV float chunk_get(const Chunk8<f16>& c, int i) { return (float)c.v[i]; }
 template <> AMT_DEV Chunk8<bf16> chunk_zero<bf16>() { Chunk8<bf16> c; for (int i = 0; i < 8; ++i) c.v[i] = (bf16)0.f; return c; }
 template <> AMT_DEV Chunk8<float> chunk_zero<float>() { Chunk8<float> c; c.a = f32x4{0, 0, 0, 0}; c.b = f32x4{0, 0, 0, 0}; return c; }
 

@@ -37,9 +37,11 @@ AMT_DEV void epi_apply(const GemmArgs& a, int n, int m, float (&v)[4]) {
     store4f(reinterpret_cast<T*>(a.Y) + (size_t)n * a.ldy + m, v);
   } else if constexpr (EPI == EPI_STORE_F32) {
     store4f(reinterpret_cast<float*>(a.Y) + (size_t)n * a.ldy + m, v);
+  } else if constexpr (EPI == EPI_STORE_RES) {
+    store4f(reinterpret_cast<Res<T>*>(a.Y) + (size_t)n * a.ldy + m, v);
   } else if constexpr (EPI == EPI_RESID) {
     float r[4];
-    load4f(reinterpret_cast<const T*>(a.R) + (size_t)n * a.ldr + m, r);
+    load4f(reinterpret_cast<const Res<T>*>(a.R) + (size_t)n * a.ldr + m, r);
     if (a.drop_thresh24) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -49,7 +51,7 @@ AMT_DEV void epi_apply(const GemmArgs& a, int n, int m, float (&v)[4]) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += r[i];
-    store4f(reinterpret_cast<T*>(a.Y) + (size_t)n * a.ldy + m, v);
+    store4f(reinterpret_cast<Res<T>*>(a.Y) + (size_t)n * a.ldy + m, v);
   } else if constexpr (EPI == EPI_GELU) {
     float h[4];
 #pragma unroll
@@ -58,11 +60,11 @@ AMT_DEV void epi_apply(const GemmArgs& a, int n, int m, float (&v)[4]) {
     store4f(reinterpret_cast<T*>(a.Y2) + (size_t)n * a.ldy2 + m, h);
   } else if constexpr (EPI == EPI_SCALE_RESID) {
     float r[4], y[4];
-    load4f(reinterpret_cast<const T*>(a.R) + (size_t)n * a.ldr + m, r);
+    load4f(reinterpret_cast<const Res<T>*>(a.R) + (size_t)n * a.ldr + m, r);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { v[i] = to_f(from_f<T>(v[i])); y[i] = r[i] + a.gamma[m + i] * v[i]; }
     store4f(reinterpret_cast<T*>(a.Y2) + (size_t)n * a.ldy2 + m, v);
-    store4f(reinterpret_cast<T*>(a.Y) + (size_t)n * a.ldy + m, y);
+    store4f(reinterpret_cast<Res<T>*>(a.Y) + (size_t)n * a.ldy + m, y);
   } else if constexpr (EPI == EPI_GLU_BWD) {
     // m indexes dg columns j (0..M-1); u lives in the permuted [.. 16 x u1 | 16 x u2 ..] layout
     int pm = (m >> 4) * 32 + (m & 15);
@@ -241,7 +243,7 @@ static void launch_nt_cfg(hipStream_t s, const GemmArgs& a, const char* name, do
 template <typename T, int EPI>
 static void launch_nt(hipStream_t s, const GemmArgs& a) {
   static const char* const epi_names[EPI_COUNT] = {"store", "store_f32", "resid", "gelu", "scale_resid", "glu",
-                                                   "glu_bwd", "gelu_bwd"};
+                                                   "glu_bwd", "gelu_bwd", "store_res"};
   constexpr size_t es = sizeof(T);
   constexpr int B0 = es == 2 ? 64 : 32;     // panel sizes: {64,128,256} for bf16, {32,64,128} for f32
   const double fl = 2.0 * a.N * (double)a.M * a.K;
@@ -271,6 +273,7 @@ static void dispatch_nt(hipStream_t s, EpiKind epi, const GemmArgs& a) {
     case EPI_GLU: launch_nt<T, EPI_GLU>(s, a); break;
     case EPI_GLU_BWD: launch_nt<T, EPI_GLU_BWD>(s, a); break;
     case EPI_GELU_BWD: launch_nt<T, EPI_GELU_BWD>(s, a); break;
+    case EPI_STORE_RES: launch_nt<T, EPI_STORE_RES>(s, a); break;
     default: break;
   }
 }

@@ -1,6 +1,9 @@
 // Host-side launcher declarations for every HIP kernel of the hot path.
 // All tensors are channels-last / token-major: [rows][features], row-major.
 // T (activation dtype) is float (verification mode) or bf16 (production mode).
+// "Res" below marks a tensor of the forward RESIDUAL STREAM (the CNN stream: Stem / Downsample / Block outputs; the
+// transformer stream: layer inputs x, h = x + attention, layer outputs y, and the final CNN LayerNorm output that starts
+// it): stored as Res<T> (common.h) - float in float contexts, IEEE half in bf16 contexts.  Everything else is T.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -15,12 +18,13 @@ enum DType { DT_F32 = 0, DT_BF16 = 1 };
 enum EpiKind {
   EPI_STORE = 0,        // Y(T)   = acc + bias
   EPI_STORE_F32 = 1,    // Y(f32) = acc + bias
-  EPI_RESID = 2,        // Y(T)   = R + dropout(acc + bias)
+  EPI_RESID = 2,        // Y(Res) = R(Res) + dropout(acc + bias)
   EPI_GELU = 3,         // Y(T)   = u = acc + bias ; Y2(T) = gelu(u)
-  EPI_SCALE_RESID = 4,  // Y2(T)  = z = acc + bias ; Y(T)  = R + gamma[m] * z
+  EPI_SCALE_RESID = 4,  // Y2(T)  = z = acc + bias ; Y(Res) = R(Res) + gamma[m] * z
   EPI_GLU = 5,          // rows of W in (16 x u1 | 16 x u2) blocks: Y2 = u (permuted), Y = gelu(u1) * u2
   EPI_GLU_BWD = 6,      // acc = dg ; Y(T)[.. permuted ..] = (dg*u2*gelu'(u1), dg*gelu(u1)), u read from U
   EPI_GELU_BWD = 7,     // Y(T) = acc * gelu'(U)
+  EPI_STORE_RES = 8,    // Y(Res) = acc + bias   (Downsample conv: its output starts a stage's residual stream)
   EPI_COUNT
 };
 
@@ -31,7 +35,7 @@ struct GemmArgs {
   const float* bias;        // [M] or nullptr
   void* Y; int ldy;
   void* Y2; int ldy2;
-  const void* R; int ldr;   // residual (T)
+  const void* R; int ldr;   // residual (Res)
   const void* U; int ldu;   // saved pre-activation (T)
   const float* gamma;       // [M]
   uint64_t seed; uint32_t stream; uint32_t drop_thresh24; float inv_keep;
@@ -88,16 +92,17 @@ struct PartialSink {
 void reduce_partials(hipStream_t s, const PartDesc* descs_dev, int n_desc, const float* ws, float* grads);
 
 // ----------------------------------------------------------------------------- LayerNorm over the last dim
-// C in {4, 8, 16, 32, 64, 128, 256}
+// C in {4, 8, 16, 32, 64, 128, 256}.  X: Res (every LayerNorm of the model reads the residual stream); Y: T, or Res when
+// y_res (the final CNN norm: its output is the transformer's stream).
 void layernorm_fwd(hipStream_t s, DType dt, const void* X, const float* w, const float* b,
-                   void* Y, float* mean, float* rstd, int N, int C);
-// dX = (dRes ? dRes : 0) + LN'(dY) ; dw += sum dY*xhat ; db += sum dY
+                   void* Y, float* mean, float* rstd, int N, int C, bool y_res = false);
+// dX = (dRes ? dRes : 0) + LN'(dY) ; dw += sum dY*xhat ; db += sum dY.  X: Res (saved forward stream); gradients: T
 void layernorm_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const float* mean, const float* rstd,
                    const float* w, const void* dRes, void* dX, float* dw, float* db, int N, int C,
                    PartialSink* sink = nullptr);
 
 // ----------------------------------------------------------------------------- CNN pieces
-// audio [B][2][T] (T dtype) -> Y [B][T/5][4] = LN(conv k5 s5)
+// audio [B][2][T] (T dtype) -> Y [B][T/5][4] (Res) = LN(conv k5 s5)
 void stem_fwd(hipStream_t s, DType dt, const void* audio, const float* w /*[4][2][5]*/, const float* b,
               const float* lnw, const float* lnb, void* Y, int B, int T);
 void stem_bwd(hipStream_t s, DType dt, const void* audio, const void* dY, const float* w, const float* b,
@@ -106,7 +111,7 @@ void stem_bwd(hipStream_t s, DType dt, const void* audio, const void* dY, const 
 // `sink`, every parameter gradient of the Block (pw1 / pw2 weights + biases with the layer scale folded into pw2's,
 // LayerNorm, depthwise taps + bias, gamma).  Pointers d* are the destinations inside the gradient buffer.
 struct SmallBwdArgs {
-  const void *dY, *X, *U, *Hh, *Z, *LN;
+  const void *dY, *X /* Res */, *U, *Hh, *Z, *LN;
   const float *mean, *rstd;
   const void *w2tg, *w1t;
   const float *wdw, *bdw, *lnw, *gamma;
@@ -115,22 +120,22 @@ struct SmallBwdArgs {
   int B, L, C;
 };
 void block_small_bwd_full(hipStream_t s, DType dt, const SmallBwdArgs& a, PartialSink* sink);
-// Y = LN(dwconv7(X) + bdw) ; X,Y [B][L][C]; saves mean/rstd [B*L]
+// Y = LN(dwconv7(X) + bdw) ; X (Res), Y (T) [B][L][C]; saves mean/rstd [B*L]
 void dwln_fwd(hipStream_t s, DType dt, const void* X, const float* wdw /*[7][C]*/, const float* bdw,
               const float* lnw, const float* lnb, void* Y, float* mean, float* rstd, int B, int L, int C);
-// dD = LN'(dY) w.r.t. the conv output (recomputed from X) ; dlnw,dlnb accumulated
+// dD = LN'(dY) w.r.t. the conv output (recomputed from X: Res) ; dlnw,dlnb accumulated
 void dwln_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const float* wdw, const float* bdw,
               const float* mean, const float* rstd, const float* lnw, void* dD, float* dlnw, float* dlnb,
               int B, int L, int C, PartialSink* sink = nullptr);
-// dX = dRes + conv^T(dD) ; dwdw[k][c] += sum dD[l][c] X[l+k-3][c] ; dbdw[c] += sum dD
+// dX = dRes + conv^T(dD) ; dwdw[k][c] += sum dD[l][c] X[l+k-3][c] ; dbdw[c] += sum dD.  X: Res; dRes is a GRADIENT (T)
 void dwconv_bwd(hipStream_t s, DType dt, const void* dD, const void* X, const float* wdw, const void* dRes,
                 void* dX, float* dwdw, float* dbdw, int B, int L, int C, PartialSink* sink = nullptr);
 // LayerNorm of a Block's OUTPUT rows, evaluated by the launch that produces them (the LayerNorm a Downsample or the final
 // norm opens with, model.py:107-118, 759-762: row-local, so the tile that holds y can finish it): Y = LN(y), mean, rstd
-// exactly as layernorm_fwd writes them.  w == nullptr: off.
-struct TailLn { const float* w; const float* b; void* Y; float* mean; float* rstd; };
+// exactly as layernorm_fwd writes them.  w == nullptr: off.  y_res: Y is stored as Res (the final norm), else T.
+struct TailLn { const float* w; const float* b; void* Y; float* mean; float* rstd; int y_res; };
 // Whole Block forward per position for C in {4, 8} (dwconv + LN + pw1 + GELU + pw2 + gamma + residual);
-// w1 [2C][C], w2 [C][2C] are the T compute copies.  Writes LN, mean, rstd, U, H = gelu(U), Z, Y.
+// w1 [2C][C], w2 [C][2C] are the T compute copies.  Writes LN, mean, rstd, U, H = gelu(U), Z (T) and Y (Res); X: Res.
 void block_small_fwd(hipStream_t s, DType dt, const void* X, const float* wdw, const float* bdw, const float* lnw,
                      const float* lnb, const void* w1, const float* b1, const void* w2, const float* b2,
                      const float* gamma, void* LN, float* mean, float* rstd, void* U, void* Hh, void* Z, void* Y, int B,
@@ -140,7 +145,7 @@ void block_small_bwd(hipStream_t s, DType dt, const void* dY, const void* U, con
                      void* dLN, long N, int C);
 // Fused tail of the Block backward (replaces dwln_bwd + dwconv_bwd [+ scale_bwd's dgamma]):
 //   dD = LN'(dLN) w.r.t. the depthwise-conv output (recomputed from X), kept in LDS with a 3-row halo;
-//   dX = dY + conv^T(dD); dlnw, dlnb, dwdw[7][C], dbdw, and dgamma[c] += sum dY * Z (if Z != null).
+//   dX = dY + conv^T(dD); dlnw, dlnb, dwdw[7][C], dbdw, and dgamma[c] += sum dY * Z (if Z != null).  X: Res.
 void dwblock_bwd(hipStream_t s, DType dt, const void* dLN, const void* X, const void* dY, const void* Z,
                  const float* wdw, const float* bdw, const float* mean, const float* rstd, const float* lnw,
                  void* dX, float* dlnw, float* dlnb, float* dwdw, float* dbdw, float* dgamma, int B, int L, int C,
@@ -153,9 +158,9 @@ void scale_bwd(hipStream_t s, DType dt, const void* dY, const void* Z, const flo
 // Whole Block forward (C >= 16) in one launch; writes LN, mean, rstd, U, H = gelu(U), Z, Y exactly
 // as dwln_fwd + gemm_nt<gelu> + gemm_nt<scale_resid> do.  W1 [2C][C], W2 [C][2C] are fragment-PACKED T copies.
 struct BlockFwdArgs {
-  const void* X; const float* wdw; const float* bdw; const float* lnw; const float* lnb;
+  const void* X /* Res */; const float* wdw; const float* bdw; const float* lnw; const float* lnb;
   const void* W1; const float* b1; const void* W2; const float* b2; const float* gamma;
-  void* LN; float* mean; float* rstd; void* U; void* Hh; void* Z; void* Y;
+  void* LN; float* mean; float* rstd; void* U; void* Hh; void* Z; void* Y /* Res */;
   int B, L, C;
   int dbg_slot;   // micro-benchmark only (AMT_CHAIN_TIMING)
   TailLn tail;
@@ -189,7 +194,7 @@ int team_state_timeout(const TeamState* st);
 // records of dlnw, dlnb, dwdw[7][C], dbdw, dgamma (summed by reduce_partials; `sink` is mandatory).
 // W2tg [2C][C] (pw2^T, columns scaled by gamma) and W1t [C][2C] are fragment-PACKED T copies.
 struct BlockBwdArgs {
-  const void* dY; const void* X; const void* U; const void* Z;   // Z may be null (no dgamma)
+  const void* dY; const void* X /* Res */; const void* U; const void* Z;   // Z may be null (no dgamma)
   const void* W2tg; const void* W1t;
   const float* wdw; const float* bdw; const float* lnw; const float* mean; const float* rstd;
   void* dU; void* dX;
@@ -210,7 +215,7 @@ void block_bwd_fused(hipStream_t s, DType dt, const BlockBwdArgs& a, float* dlnw
 // W1 == nullptr: stop after the LayerNorm (h, hn, mean, rstd) — the production form; the full chain is
 // an opt-in (AMT_FUSE_FFN=1) that measured slower at 8 clips per GPU (chain.hip).
 struct FfnFwdArgs {
-  const void* AO; const void* X;
+  const void* AO; const void* X;   // X, Hout, Y: Res
   const void* Wo; const float* ln_w; const float* ln_b;
   const void* W1; const float* b1; const void* W2; const float* b2;
   void* Hout; void* HN; float* mean; float* rstd; void* U; void* G; void* Y;
@@ -230,7 +235,7 @@ bool ffn_fwd_big(hipStream_t s, DType dt, const FfnFwdArgs& a, bool save);
 // Writes xn, mean, rstd, qc, kv exactly as layernorm_fwd + gemm_nt + gemm_nt do.  Wqc [320][256],
 // Wkv [512][64]: fragment-PACKED.
 struct QkvFwdArgs {
-  const void* X; const float* ln_w; const float* ln_b; const void* Wqc; const void* Wkv;
+  const void* X /* Res */; const float* ln_w; const float* ln_b; const void* Wqc; const void* Wkv;
   void* XN; float* mean; float* rstd; void* QC; void* KV;
   int N;
   int dbg_slot;
@@ -253,7 +258,7 @@ bool ffn_qkv_fwd_fused(hipStream_t s, DType dt, const FfnFwdArgs& fa, const QkvF
 struct QkvBwdArgs {
   const void* dKV; void* dQC;                 // dQC[:, 0:256] in, [:, 256:320] out
   const void* Wkvt; const void* Wqct;
-  const void* X; const float* mean; const float* rstd; const float* ln_w; const void* dH;
+  const void* X /* Res */; const float* mean; const float* rstd; const float* ln_w; const void* dH;
   void* dX; void* dXD;
   float* rec; int rec_stride;                 // set by the launcher
   int N;
@@ -269,7 +274,7 @@ void qkv_bwd_fused(hipStream_t s, DType dt, const QkvBwdArgs& a, float* dlnw, fl
 // layernorm_bwd + gemm_nt (output-projection^T)):  dh = dy + LN2'(dhn) ; dao = dh . Wo ; dln2 w/b records.
 // Wot [256][256]: fragment-PACKED.
 struct LnOutBwdArgs {
-  const void* dHN; const void* Hres; const float* mean; const float* rstd; const float* ln_w; const void* dY;
+  const void* dHN; const void* Hres /* Res */; const float* mean; const float* rstd; const float* ln_w; const void* dY;
   const void* Wot;
   void* dH; void* dAO;
   float* rec; int rec_stride;
@@ -290,7 +295,7 @@ void lnout_bwd_fused(hipStream_t s, DType dt, const LnOutBwdArgs& a, float* dlnw
 struct FfnBwdArgs {
   const void* dYD; const void* dY; const void* U;
   const void* W2t; const void* W1t; const void* Wot;
-  const void* Hres; const float* mean; const float* rstd; const float* ln_w;
+  const void* Hres /* Res */; const float* mean; const float* rstd; const float* ln_w;
   void* dU; void* dH; void* dAO;
   float* rec; int rec_stride;      // set by the launcher
   int N;

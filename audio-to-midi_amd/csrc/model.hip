@@ -477,7 +477,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
       tail_done = false;
       void* y = out_buf((size_t)B * Lcur * C);
       GemmArgs g = gargs(sv.ln, 2 * Cin, c->WC(st.c_w), 2 * Cin, B * Lcur, C, 2 * Cin, c->P(st.conv_b), y, C);
-      RUN(gemm_nt(s, dt, EPI_STORE, g));
+      RUN(gemm_nt(s, dt, EPI_STORE_RES, g));   // the stage's residual stream starts here: stored as Res (common.h)
       cur = y;
     }
     const int N = B * Lcur;
@@ -535,12 +535,12 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
           nsv.ln = A.alloc((size_t)N * C * es);
           nsv.mean = (float*)A.alloc((size_t)N * sizeof(float));
           nsv.rstd = (float*)A.alloc((size_t)N * sizeof(float));
-          tl = TailLn{c->P(nx.ln_w), c->P(nx.ln_b), nsv.ln, nsv.mean, nsv.rstd};
+          tl = TailLn{c->P(nx.ln_w), c->P(nx.ln_b), nsv.ln, nsv.mean, nsv.rstd, 0};
         } else if (C == L.H) {                // the final norm (model.py:759-762)
           c->fn_mean = (float*)A.alloc((size_t)N * sizeof(float));
           c->fn_rstd = (float*)A.alloc((size_t)N * sizeof(float));
           fn_y_tail = A.alloc((size_t)N * C * es);
-          tl = TailLn{c->P(L.fn_w), c->P(L.fn_b), fn_y_tail, c->fn_mean, c->fn_rstd};
+          tl = TailLn{c->P(L.fn_w), c->P(L.fn_b), fn_y_tail, c->fn_mean, c->fn_rstd, 1};   // the transformer's stream: Res
         }
         tail_done = tl.w != nullptr;
       }
@@ -586,7 +586,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
     c->fn_mean = (float*)A.alloc((size_t)N * sizeof(float));
     c->fn_rstd = (float*)A.alloc((size_t)N * sizeof(float));
     void* y = out_buf((size_t)N * H);
-    RUN(layernorm_fwd(s, dt, cur, c->P(L.fn_w), c->P(L.fn_b), y, c->fn_mean, c->fn_rstd, N, H));
+    RUN(layernorm_fwd(s, dt, cur, c->P(L.fn_w), c->P(L.fn_b), y, c->fn_mean, c->fn_rstd, N, H, true));   // output: Res
     cur = y;
   }
   c->fn_y = cur;

@@ -1,15 +1,17 @@
 // Row LayerNorm forward / backward (fp32 statistics via wavefront shuffles).
 // Reference: eqx.nn.LayerNorm under jax.vmap over positions / tokens, computed in float32
 // (model.py:100,117,162,190,539,546,759).
+// Every LayerNorm of the model reads the forward residual stream: X is stored as Res<T> (common.h); the output is T (an
+// operand of the GEMM that follows) except for the final CNN norm, whose output IS the transformer's stream (y_res).
 #include "rowops.h"
 #include "kernels.h"
 #include "prof.h"
 
 namespace amt {
 
-template <typename T, int C>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, const float* __restrict__ w,
-                                                     const float* __restrict__ b, T* __restrict__ Y,
+template <typename T, typename TY, int C>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const Res<T>* __restrict__ X, const float* __restrict__ w,
+                                                     const float* __restrict__ b, TY* __restrict__ Y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int N) {
   using R = RowCfg<C>;
   constexpr int VEC = R::VEC, LPR = R::LPR;
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ X, co
 }
 
 template <typename T, int C>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dY, const T* __restrict__ X,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dY, const Res<T>* __restrict__ X,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ w, const T* dRes,
                                                      T* dX, float* __restrict__ dw,
@@ -80,25 +82,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dY, c
   reduce_cols_to_global<VEC, LPR>(ab, db, smem, pstride);
 }
 
-template <typename T>
+template <typename T, typename TY>
 static void ln_fwd_t(hipStream_t s, const void* X, const float* w, const float* b, void* Y, float* mean, float* rstd,
                      int N, int C) {
-  AMT_DISPATCH_C(C, hipLaunchKernelGGL((ln_fwd_kernel<T, CC>), dim3(row_grid(N, RowCfg<CC>::RPB)), dim3(256), 0, s,
-                                       (const T*)X, w, b, (T*)Y, mean, rstd, N));
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((ln_fwd_kernel<T, TY, CC>), dim3(row_grid(N, RowCfg<CC>::RPB)), dim3(256), 0, s,
+                                       (const Res<T>*)X, w, b, (TY*)Y, mean, rstd, N));
 }
 template <typename T>
 static void ln_bwd_t(hipStream_t s, const void* dY, const void* X, const float* mean, const float* rstd,
                      const float* w, const void* dRes, void* dX, float* dw, float* db, int N, int C, int nb,
                      int pstride) {
-  AMT_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd_kernel<T, CC>), dim3(nb), dim3(256), 0, s, (const T*)dY, (const T*)X,
+  AMT_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd_kernel<T, CC>), dim3(nb), dim3(256), 0, s, (const T*)dY, (const Res<T>*)X,
                                        mean, rstd, w, (const T*)dRes, (T*)dX, dw, db, N, pstride));
 }
 
 void layernorm_fwd(hipStream_t s, DType dt, const void* X, const float* w, const float* b, void* Y, float* mean,
-                   float* rstd, int N, int C) {
+                   float* rstd, int N, int C, bool y_res) {
   ProfScope ps(s, "layernorm_fwd", 0, 2.0 * N * C * (dt == DT_F32 ? 4 : 2));
-  if (dt == DT_F32) ln_fwd_t<float>(s, X, w, b, Y, mean, rstd, N, C);
-  else ln_fwd_t<bf16>(s, X, w, b, Y, mean, rstd, N, C);
+  if (dt == DT_F32) ln_fwd_t<float, float>(s, X, w, b, Y, mean, rstd, N, C);
+  else if (y_res) ln_fwd_t<bf16, Res<bf16>>(s, X, w, b, Y, mean, rstd, N, C);
+  else ln_fwd_t<bf16, bf16>(s, X, w, b, Y, mean, rstd, N, C);
 }
 void layernorm_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const float* mean, const float* rstd,
                    const float* w, const void* dRes, void* dX, float* dw, float* db, int N, int C,

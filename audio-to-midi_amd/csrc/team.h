@@ -84,6 +84,16 @@ template <bool SC1> AMT_DEV void team_load8f(__amdgpu_buffer_rsrc_t rs, const bf
     load8f(base + elem, o);
   }
 }
+template <bool SC1> AMT_DEV void team_load8f(__amdgpu_buffer_rsrc_t rs, const f16* base, long elem, float (&o)[8]) {
+  if constexpr (SC1) {
+    const team_u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 2), 0, 16);
+    const f16x8 v = __builtin_bit_cast(f16x8, raw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  } else {
+    load8f(base + elem, o);
+  }
+}
 template <bool SC1> AMT_DEV void team_load8f(__amdgpu_buffer_rsrc_t rs, const float* base, long elem, float (&o)[8]) {
   if constexpr (SC1) {
     const team_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 4), 0, 16);

@@ -4,6 +4,9 @@
  * against the oracle in isolation (same conventions as amt.h: device pointers, row-major,
  * channels-last activations, asynchronous on `stream`, return 0 on success).  `dtype` is the
  * activation dtype (AMT_F32 | AMT_BF16) of every `void*` tensor unless stated otherwise.
+ * "Res" marks a tensor of the forward RESIDUAL STREAM (Block / layer inputs and outputs, the residual operand of a
+ * GEMM epilogue): float32 in AMT_F32 contexts, IEEE half (float16) in AMT_BF16 contexts - the reference's own activation
+ * type (train.py:35-37) in the same two bytes (csrc/common.h: Res<T>).
  * Reference op for each entry point is cited in the kernel sources (audio-to-midi_amd/csrc/).
  */
 #ifndef AMT_OPS_H_
@@ -16,7 +19,9 @@
 extern "C" {
 #endif
 
-/* Y = epilogue(X[N,K] . W[M,K]^T)  — eqx.nn.Linear / 1x1 Conv1d (model.py:141-153, 213-222, 300-334) */
+/* Y = epilogue(X[N,K] . W[M,K]^T)  — eqx.nn.Linear / 1x1 Conv1d (model.py:141-153, 213-222, 300-334)
+ * epi: 0 store, 1 store f32, 2 Y(Res) = R(Res) + dropout(.), 3 GELU (Y = u, Y2 = gelu(u)), 4 Y2 = z, Y(Res) = R(Res) + gamma z,
+ * 5 GLU, 6 GLU', 7 GELU', 8 store Res */
 int32_t amt_op_gemm_nt(int32_t dtype, int32_t epi, const void* X, int32_t ldx, const void* W, int32_t ldw,
                        int32_t N, int32_t M, int32_t K, const float* bias, void* Y, int32_t ldy, void* Y2,
                        int32_t ldy2, const void* R, int32_t ldr, const void* U, int32_t ldu, const float* gamma,
@@ -25,16 +30,19 @@ int32_t amt_op_gemm_nt(int32_t dtype, int32_t epi, const void* X, int32_t ldx, c
 int32_t amt_op_gemm_tn_wgrad(int32_t dtype, const void* G, int32_t ldg, const void* A, int32_t lda, int32_t N,
                              int32_t M, int32_t Kp, float* dW, int32_t ldw, float* dbias, int32_t M_store,
                              void* stream);
+/* X: Res (every LayerNorm of the model reads the residual stream); Y, dY, dRes, dX: activation dtype */
 int32_t amt_op_layernorm_fwd(int32_t dtype, const void* X, const float* w, const float* b, void* Y, float* mean,
                              float* rstd, int32_t N, int32_t C, void* stream);
 int32_t amt_op_layernorm_bwd(int32_t dtype, const void* dY, const void* X, const float* mean, const float* rstd,
                              const float* w, const void* dRes, void* dX, float* dw, float* db, int32_t N, int32_t C,
                              void* stream);
+/* Y: Res */
 int32_t amt_op_stem_fwd(int32_t dtype, const void* audio, const float* w, const float* b, const float* lnw,
                         const float* lnb, void* Y, int32_t B, int32_t T, void* stream);
 int32_t amt_op_stem_bwd(int32_t dtype, const void* audio, const void* dY, const float* w, const float* b,
                         const float* lnw, float* dw, float* db, float* dlnw, float* dlnb, int32_t B, int32_t T,
                         void* stream);
+/* the four depthwise-conv entry points: X (the Block's input) is Res; everything else the activation dtype */
 int32_t amt_op_dwln_fwd(int32_t dtype, const void* X, const float* wdw, const float* bdw, const float* lnw,
                         const float* lnb, void* Y, float* mean, float* rstd, int32_t B, int32_t L, int32_t C,
                         void* stream);

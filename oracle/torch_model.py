@@ -49,18 +49,24 @@ def _sdpa(q, k, v, keep=None, keep_prob=1.0):
     return w @ v
 
 
-def _self_attention(lp, x, cos, sin, nh, keep=None, keep_prob=1.0):
-    """model.py:340-369.  x (B, S, H) -> (B, S, H)."""
+def _no_tap(name, t):
+    return t
+
+
+def _self_attention(lp, x, cos, sin, nh, keep=None, keep_prob=1.0, tap=_no_tap, tag=""):
+    """model.py:340-369.  x (B, S, H) -> (B, S, H).  `tap(name, tensor) -> tensor` (default: identity) sees every tensor
+    an implementation would store between operators (tests: intermediates, rounding-point studies)."""
     B, S, _ = x.shape
-    q = _rope(F.linear(x, lp["Wq"]).view(B, S, nh, -1), cos[:S], sin[:S])
-    c = F.linear(x, lp["Wkvd"])
-    k = _rope(F.linear(c, lp["Wku"]).view(B, S, nh, -1), cos[:S], sin[:S])
-    v = F.linear(c, lp["Wvu"]).view(B, S, nh, -1)
+    q = tap(tag + "q", _rope(tap(tag + "q_raw", F.linear(x, lp["Wq"])).view(B, S, nh, -1), cos[:S], sin[:S]))
+    c = tap(tag + "c", F.linear(x, lp["Wkvd"]))
+    k = tap(tag + "k", _rope(tap(tag + "k_raw", F.linear(c, lp["Wku"])).view(B, S, nh, -1), cos[:S], sin[:S]))
+    v = tap(tag + "v", F.linear(c, lp["Wvu"])).view(B, S, nh, -1)
     o = _sdpa(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), keep, keep_prob)
-    return F.linear(o.transpose(1, 2).reshape(B, S, -1), lp["Wo"])
+    o = tap(tag + "ao", o.transpose(1, 2).reshape(B, S, -1))
+    return F.linear(o, lp["Wo"])
 
 
-def _local_attention(lp, x, cos, sin, nh, keep=None, keep_prob=1.0):
+def _local_attention(lp, x, cos, sin, nh, keep=None, keep_prob=1.0, tap=_no_tap, tag=""):
     """model.py:409-471.  keep: optional (B, nwin, nh, W, W)."""
     B, S, H = x.shape
     W = LOCAL_CONTEXT_WINDOW
@@ -68,7 +74,7 @@ def _local_attention(lp, x, cos, sin, nh, keep=None, keep_prob=1.0):
     xp = F.pad(x, (0, 0, pl, pr))
     win = xp.unfold(1, W, stride).permute(0, 1, 3, 2)          # (B, nwin, W, H)
     kp = None if keep is None else keep.reshape(B * nwin, nh, W, W)
-    ow = _self_attention(lp, win.reshape(B * nwin, W, H), cos, sin, nh, kp, keep_prob)
+    ow = _self_attention(lp, win.reshape(B * nwin, W, H), cos, sin, nh, kp, keep_prob, tap, tag)
     ow = ow.view(B, nwin, W, H)
     idx = (torch.arange(nwin)[:, None] * stride + torch.arange(W)[None, :]).reshape(-1)
     valid = idx < S                                           # OOB scatter updates dropped
@@ -96,8 +102,9 @@ def _layer_params(p, kind, i):
     }
 
 
-def cnn_frontend(p, x, conf=MODEL_CONFIG):
-    """model.py:755-762.  x (B, 2, T) -> (B, S, H)."""
+def cnn_frontend(p, x, conf=MODEL_CONFIG, tap=_no_tap):
+    """model.py:755-762.  x (B, 2, T) -> (B, S, H).  Tap names: "cnn.{s}.0.y" (Stem / Downsample output), "cnn.{s}.0.ln"
+    (the LayerNorm a Downsample opens with), "cnn.{s}.{j}.{ln,u,h,z,y}" per Block, "cnn.norm" (final LayerNorm)."""
     dims, depths = conf["dims"], conf["depths"]
     h = x
     for s in range(len(dims)):
@@ -106,25 +113,28 @@ def cnn_frontend(p, x, conf=MODEL_CONFIG):
             h = F.conv1d(h, p[pre + "conv.weight"], p[pre + "conv.bias"][:, 0], stride=5)
             h = _chan_ln(h, p[pre + "norm.weight"], p[pre + "norm.bias"])
         else:
-            h = _chan_ln(h, p[pre + "norm.weight"], p[pre + "norm.bias"])
+            h = tap(f"cnn.{s}.0.ln", _chan_ln(h, p[pre + "norm.weight"], p[pre + "norm.bias"]))
             h = F.conv1d(h, p[pre + "conv.weight"], p[pre + "conv.bias"][:, 0], stride=2)
+        h = tap(f"cnn.{s}.0.y", h)
         C = dims[s]
         for j in range(1, depths[s] + 1):
             q = f"layers.{s}.{j}."
+            t = f"cnn.{s}.{j}."
             o = F.conv1d(h, p[q + "depth_conv.weight"], p[q + "depth_conv.bias"][:, 0], padding=3, groups=C)
-            o = _chan_ln(o, p[q + "norm.weight"], p[q + "norm.bias"])
-            o = F.conv1d(o, p[q + "point_conv_1.weight"], p[q + "point_conv_1.bias"][:, 0])
-            o = F.gelu(o, approximate="tanh")
-            o = F.conv1d(o, p[q + "point_conv_2.weight"], p[q + "point_conv_2.bias"][:, 0])
-            h = p[q + "gamma"][None, :, None] * o + h
-    h = _chan_ln(h, p["norm.weight"], p["norm.bias"])
+            o = tap(t + "ln", _chan_ln(o, p[q + "norm.weight"], p[q + "norm.bias"]))
+            o = tap(t + "u", F.conv1d(o, p[q + "point_conv_1.weight"], p[q + "point_conv_1.bias"][:, 0]))
+            o = tap(t + "h", F.gelu(o, approximate="tanh"))
+            o = tap(t + "z", F.conv1d(o, p[q + "point_conv_2.weight"], p[q + "point_conv_2.bias"][:, 0]))
+            h = tap(t + "y", p[q + "gamma"][None, :, None] * o + h)
+    h = tap("cnn.norm", _chan_ln(h, p["norm.weight"], p["norm.bias"]))
     return h.transpose(1, 2)
 
 
-def forward(p, audio, conf=MODEL_CONFIG, rope=None, dropout_masks=None, return_intermediates=False):
-    """Batched OutputSequenceGenerator (model.py:740-769 under vmap).  audio (B,2,T)."""
+def forward(p, audio, conf=MODEL_CONFIG, rope=None, dropout_masks=None, return_intermediates=False, tap=_no_tap):
+    """Batched OutputSequenceGenerator (model.py:740-769 under vmap).  audio (B,2,T).  Tap names of layer l: "tl.{l}.{xn,
+    q_raw,q,c,k_raw,k,v,ao,h,hn,u,g,y}" (local layers: q .. ao are per window); "head.hn"."""
     dtype = audio.dtype
-    h = cnn_frontend(p, audio, conf)
+    h = cnn_frontend(p, audio, conf, tap)
     inter = {"cnn": h}
     B, S, H = h.shape
     nh, hd = conf["num_transformer_heads"], conf["attention_size"]
@@ -139,22 +149,23 @@ def forward(p, audio, conf=MODEL_CONFIG, rope=None, dropout_masks=None, return_i
             dm = None if dropout_masks is None else dropout_masks[li]
             kp = 1.0 if dm is None else dm["keep"]
             am = None if dm is None else dm["attn"]
-            xn = F.layer_norm(h, (H,), lp["ln1w"], lp["ln1b"], LN_EPS)
+            tg = f"tl.{li}."
+            xn = tap(tg + "xn", F.layer_norm(h, (H,), lp["ln1w"], lp["ln1b"], LN_EPS))
             if kind == "local_attention":
-                r = _local_attention(lp, xn, cos, sin, nh, am, kp)
+                r = _local_attention(lp, xn, cos, sin, nh, am, kp, tap, tg)
             else:
-                r = _self_attention(lp, xn, cos, sin, nh, am, kp)
-            h = h + r
-            hn = F.layer_norm(h, (H,), lp["ln2w"], lp["ln2b"], LN_EPS)
-            y = F.linear(hn, lp["W1"], lp["b1"])
+                r = _self_attention(lp, xn, cos, sin, nh, am, kp, tap, tg)
+            h = tap(tg + "h", h + r)
+            hn = tap(tg + "hn", F.layer_norm(h, (H,), lp["ln2w"], lp["ln2b"], LN_EPS))
+            y = tap(tg + "u", F.linear(hn, lp["W1"], lp["b1"]))
             y1, y2 = y.chunk(2, dim=-1)
-            r = F.linear(F.gelu(y1, approximate="tanh") * y2, lp["W2"], lp["b2"])
+            r = F.linear(tap(tg + "g", F.gelu(y1, approximate="tanh") * y2), lp["W2"], lp["b2"])
             if dm is not None:
                 r = r * dm["ffn"] / kp
-            h = h + r
+            h = tap(tg + "y", h + r)
             inter[f"layer{li}"] = h
             li += 1
-    hn = F.layer_norm(h, (H,), p["decoder.norm.weight"], p["decoder.norm.bias"], LN_EPS)
+    hn = tap("head.hn", F.layer_norm(h, (H,), p["decoder.norm.weight"], p["decoder.norm.bias"], LN_EPS))
     logits = F.linear(hn, p["decoder.decoder_pooling.weight"], p["decoder.decoder_pooling.bias"])
     probs = torch.sigmoid(logits)
     if return_intermediates:

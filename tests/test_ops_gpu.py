@@ -10,10 +10,10 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from util import (DT, P, call, check, dev, f32, host, keep_mask, rel_l2, rounded, stream)  # noqa: E402
+from util import (DT, RES_TD, TD, P, call, check, dev, dev_res, f32, host, keep_mask, rel_l2, rounded, stream)  # noqa: E402
 
 DTYPES = ["float32", "bfloat16"]
-EPI = dict(STORE=0, STORE_F32=1, RESID=2, GELU=3, SCALE_RESID=4, GLU=5, GLU_BWD=6, GELU_BWD=7)
+EPI = dict(STORE=0, STORE_F32=1, RESID=2, GELU=3, SCALE_RESID=4, GLU=5, GLU_BWD=6, GELU_BWD=7, STORE_RES=8)
 
 
 def gelu(x):
@@ -94,12 +94,12 @@ def test_gemm_nt_epilogues(dtype):
     M = 64
     W = rounded(rng.standard_normal((M, K)) / 8, dtype); b = rng.standard_normal(M).astype(np.float32)
     R = rounded(rng.standard_normal((N, M)), dtype)
-    Y = torch.zeros((N, M), device="cuda", dtype=td)
-    gemm_nt(dtype, EPI["RESID"], Xd, dev(W, dtype), f32(b), Y, R=dev(R, dtype))
+    Y = torch.zeros((N, M), device="cuda", dtype=RES_TD[dtype])       # residual operand and output: residual-stream storage type
+    gemm_nt(dtype, EPI["RESID"], Xd, dev(W, dtype), f32(b), Y, R=dev_res(R, dtype))
     check(host(Y), R + X @ W.T + b, dtype, what="resid")
     # RESID + dropout: mask must be the counter-based one
     Y.zero_()
-    gemm_nt(dtype, EPI["RESID"], Xd, dev(W, dtype), f32(b), Y, R=dev(R, dtype), seed=1234567890123, sid=7, p=0.1)
+    gemm_nt(dtype, EPI["RESID"], Xd, dev(W, dtype), f32(b), Y, R=dev_res(R, dtype), seed=1234567890123, sid=7, p=0.1)
     keep, kp = keep_mask(1234567890123, 7, np.arange(N * M).reshape(N, M), 0.1)
     assert 0.85 < keep.mean() < 0.95
     check(host(Y), R + (X @ W.T + b) * keep / kp, dtype, what="resid+dropout")
@@ -115,10 +115,14 @@ def test_gemm_nt_epilogues(dtype):
     M = 64
     W = rounded(rng.standard_normal((M, K)) / 8, dtype); b = rng.standard_normal(M).astype(np.float32)
     g = rng.standard_normal(M).astype(np.float32)
-    Z = torch.zeros((N, M), device="cuda", dtype=td); Y = torch.zeros_like(Z)
-    gemm_nt(dtype, EPI["SCALE_RESID"], Xd, dev(W, dtype), f32(b), Y, Y2=Z, R=dev(R, dtype), gamma=f32(g))
+    Z = torch.zeros((N, M), device="cuda", dtype=td); Y = torch.zeros((N, M), device="cuda", dtype=RES_TD[dtype])
+    gemm_nt(dtype, EPI["SCALE_RESID"], Xd, dev(W, dtype), f32(b), Y, Y2=Z, R=dev_res(R, dtype), gamma=f32(g))
     check(host(Z), X @ W.T + b, dtype, what="z")
     check(host(Y), R + g * host(Z), dtype, what="scale resid")
+    # STORE_RES (Downsample conv: the output starts a stage's residual stream)
+    Y = torch.zeros((N, M), device="cuda", dtype=RES_TD[dtype])
+    gemm_nt(dtype, EPI["STORE_RES"], Xd, dev(W, dtype), f32(b), Y)
+    check(host(Y), X @ W.T + b, dtype, what="store res")
     # GELU_BWD
     M = 128
     W = rounded(rng.standard_normal((M, K)) / 8, dtype)
@@ -181,8 +185,8 @@ def test_layernorm(dtype, C):
     N = 1000 + C
     X = rounded(rng.standard_normal((N, C)) * 2 + 0.5, dtype)
     w = rng.standard_normal(C).astype(np.float32); b = rng.standard_normal(C).astype(np.float32)
-    Xd = dev(X, dtype)
-    Y = torch.zeros_like(Xd); mean = torch.zeros(N, device="cuda"); rstd = torch.zeros(N, device="cuda")
+    Xd = dev_res(X, dtype)                    # every LayerNorm of the model reads the residual stream
+    Y = torch.zeros((N, C), device="cuda", dtype=TD[dtype]); mean = torch.zeros(N, device="cuda"); rstd = torch.zeros(N, device="cuda")
     call("amt_op_layernorm_fwd", DT[dtype], P(Xd), P(f32(w)), P(f32(b)), P(Y), P(mean), P(rstd), N, C, stream())
     xt = torch.tensor(X, requires_grad=True)
     wt = torch.tensor(w, dtype=torch.float64, requires_grad=True); bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
@@ -191,7 +195,7 @@ def test_layernorm(dtype, C):
     dY = rounded(rng.standard_normal((N, C)), dtype)
     dR = rounded(rng.standard_normal((N, C)), dtype)
     yt.backward(torch.tensor(dY))
-    dX = torch.zeros_like(Xd); dw = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
+    dX = torch.zeros_like(Y); dw = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
     call("amt_op_layernorm_bwd", DT[dtype], P(dev(dY, dtype)), P(Xd), P(mean), P(rstd), P(f32(w)), P(dev(dR, dtype)),
          P(dX), P(dw), P(db), N, C, stream())
     check(host(dX), dR + xt.grad.numpy(), dtype, scale=4.0, what="ln dX")
@@ -208,7 +212,7 @@ def test_stem(dtype):
     w = (rng.standard_normal((4, 2, 5)) * 0.3).astype(np.float32); b = rng.standard_normal(4).astype(np.float32)
     lw = rng.standard_normal(4).astype(np.float32); lb = rng.standard_normal(4).astype(np.float32)
     ad = dev(a, dtype)
-    Y = torch.zeros((B, L, 4), device="cuda", dtype=ad.dtype)
+    Y = torch.zeros((B, L, 4), device="cuda", dtype=RES_TD[dtype])      # the Stem's output starts the residual stream
     call("amt_op_stem_fwd", DT[dtype], P(ad), P(f32(w)), P(f32(b)), P(f32(lw)), P(f32(lb)), P(Y), B, T, stream())
     tw = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (w, b, lw, lb)]
     c = F.conv1d(torch.tensor(a), tw[0], tw[1], stride=5)
@@ -233,8 +237,8 @@ def test_block_conv_pieces(dtype, C, L):
     wdw = (rng.standard_normal((C, 1, 7)) * 0.4).astype(np.float32); bdw = rng.standard_normal(C).astype(np.float32)
     lw = rng.standard_normal(C).astype(np.float32); lb = rng.standard_normal(C).astype(np.float32)
     wdev = f32(wdw[:, 0, :].T.copy())
-    Xd = dev(X, dtype)
-    Y = torch.zeros_like(Xd); mean = torch.zeros(B * L, device="cuda"); rstd = torch.zeros(B * L, device="cuda")
+    Xd = dev_res(X, dtype)                    # Block input: residual stream
+    Y = torch.zeros((B, L, C), device="cuda", dtype=TD[dtype]); mean = torch.zeros(B * L, device="cuda"); rstd = torch.zeros(B * L, device="cuda")
     call("amt_op_dwln_fwd", DT[dtype], P(Xd), P(wdev), P(f32(bdw)), P(f32(lw)), P(f32(lb)), P(Y), P(mean), P(rstd), B, L,
          C, stream())
     xt = torch.tensor(X, requires_grad=True)
@@ -245,7 +249,7 @@ def test_block_conv_pieces(dtype, C, L):
     check(host(Y), y.detach().numpy(), dtype, scale=3.0, what="dwln fwd")
     dY = rounded(rng.standard_normal((B, L, C)), dtype)
     y.backward(torch.tensor(dY))
-    dD = torch.zeros_like(Xd); dlw = torch.zeros(C, device="cuda"); dlb = torch.zeros(C, device="cuda")
+    dD = torch.zeros_like(Y); dlw = torch.zeros(C, device="cuda"); dlb = torch.zeros(C, device="cuda")
     call("amt_op_dwln_bwd", DT[dtype], P(dev(dY, dtype)), P(Xd), P(wdev), P(f32(bdw)), P(mean), P(rstd), P(f32(lw)), P(dD),
          P(dlw), P(dlb), B, L, C, stream())
     dD_ref = d.grad.transpose(1, 2).numpy()
@@ -260,7 +264,7 @@ def test_block_conv_pieces(dtype, C, L):
     d2 = F.conv1d(xt2.transpose(1, 2), w2, b2, padding=3, groups=C)
     d2.backward(torch.tensor(dDr).transpose(1, 2))
     dR = rounded(rng.standard_normal((B, L, C)), dtype)
-    dX = torch.zeros_like(Xd); dwd = torch.zeros((7, C), device="cuda"); dbd = torch.zeros(C, device="cuda")
+    dX = torch.zeros_like(Y); dwd = torch.zeros((7, C), device="cuda"); dbd = torch.zeros(C, device="cuda")
     call("amt_op_dwconv_bwd", DT[dtype], P(dD), P(Xd), P(wdev), P(dev(dR, dtype)), P(dX), P(dwd), P(dbd), B, L, C,
          stream())
     check(host(dX), dR + xt2.grad.numpy(), dtype, scale=4.0, what="dwconv dX")
@@ -268,7 +272,7 @@ def test_block_conv_pieces(dtype, C, L):
     check(host(dbd), b2.grad.numpy(), "float32", scale=sc, what="dwconv db")
     # fused tail (dwln_bwd + dwconv_bwd + dgamma in one kernel, dD kept in LDS) against the same references
     Zt = rounded(rng.standard_normal((B, L, C)), dtype)
-    dX2 = torch.zeros_like(Xd); outs = [torch.zeros(n, device="cuda") for n in (C, C, 7 * C, C, C)]
+    dX2 = torch.zeros_like(Y); outs = [torch.zeros(n, device="cuda") for n in (C, C, 7 * C, C, C)]
     call("amt_op_dwblock_bwd", DT[dtype], P(dev(dY, dtype)), P(Xd), P(dev(dR, dtype)), P(dev(Zt, dtype)), P(wdev),
          P(f32(bdw)), P(mean), P(rstd), P(f32(lw)), P(dX2), *[P(o) for o in outs], B, L, C, stream())
     check(host(dX2), dR + xt2.grad.numpy(), dtype, scale=4.0, what="fused dX")
@@ -279,7 +283,7 @@ def test_block_conv_pieces(dtype, C, L):
     check(host(outs[4]), (dR * Zt).sum((0, 1)), "float32", scale=sc, what="fused dgamma")
     # layer scale
     Z = rounded(rng.standard_normal((B * L, C)), dtype); g = rng.standard_normal(C).astype(np.float32)
-    dZ = torch.zeros((B * L, C), device="cuda", dtype=Xd.dtype); dg = torch.zeros(C, device="cuda")
+    dZ = torch.zeros((B * L, C), device="cuda", dtype=Y.dtype); dg = torch.zeros(C, device="cuda")
     dYf = dY.reshape(B * L, C)
     call("amt_op_scale_bwd", DT[dtype], P(dev(dYf, dtype)), P(dev(Z, dtype)), P(f32(g)), P(dZ), P(dg), B * L, C, stream())
     check(host(dZ), g * dYf, dtype, scale=3.0, what="scale dZ")

@@ -9,12 +9,19 @@ from audio_to_midi_amd import lib as L
 
 TD = {"float32": torch.float32, "bfloat16": torch.bfloat16}
 DT = {"float32": L.AMT_F32, "bfloat16": L.AMT_BF16}
+# storage type of the forward RESIDUAL STREAM per activation dtype (csrc/common.h: Res<T>): IEEE half in bf16 contexts
+RES_TD = {"float32": torch.float32, "bfloat16": torch.float16}
 # (abs + rel*|ref|) tolerances per activation dtype for single ops
 TOL = {"float32": (2e-5, 2e-5), "bfloat16": (2e-2, 2e-2)}
 
 
 def dev(x, dtype="float32"):
     return torch.as_tensor(np.ascontiguousarray(x)).to(device="cuda", dtype=TD[dtype] if isinstance(dtype, str) else dtype).contiguous()
+
+
+def dev_res(x, dtype):
+    """a residual-stream tensor (block / layer input x, residual operand R) on the device, in its storage type"""
+    return dev(x, RES_TD[dtype])
 
 
 def f32(x):
