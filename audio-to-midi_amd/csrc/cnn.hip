@@ -19,6 +19,9 @@ namespace amt {
 constexpr int STEM_POS = 256;
 constexpr int STEM_SAMP = STEM_POS * 5;   // 1280 samples per channel per block
 
+// The audio is the model's INPUT: it has the residual stream's storage type (common.h: Res<T>) - IEEE half in bf16 contexts,
+// which is what the reference feeds its model (grain_loader.py:88 casts the samples to float16; python.rs:251-261 rounds them
+// through f16 at load time): no input quantisation on top of the reference's own.
 template <typename T>
 AMT_DEV void stem_stage_audio(const T* audio, float (*xs)[STEM_SAMP], int b, long t0, int T_) {
   // 2 channels x 1280 samples = 320 chunks of 8
@@ -38,7 +41,7 @@ AMT_DEV void stem_stage_audio(const T* audio, float (*xs)[STEM_SAMP], int b, lon
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void stem_fwd_kernel(const T* __restrict__ audio, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const Res<T>* __restrict__ audio, const float* __restrict__ w,
                                                        const float* __restrict__ bias, const float* __restrict__ lnw,
                                                        const float* __restrict__ lnb, Res<T>* __restrict__ Y, int B, int T_,
                                                        int L, int tiles_per_clip) {
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const T* __restrict__ aud
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void stem_bwd_kernel(const T* __restrict__ audio, const T* __restrict__ dY,
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const Res<T>* __restrict__ audio, const T* __restrict__ dY,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        const float* __restrict__ lnw, float* __restrict__ dw,
                                                        float* __restrict__ db, float* __restrict__ dlnw,
@@ -155,7 +158,7 @@ void stem_fwd(hipStream_t s, DType dt, const void* audio, const float* w, const 
     hipLaunchKernelGGL((stem_fwd_kernel<float>), dim3(B * tiles), dim3(256), 0, s, (const float*)audio, w, b, lnw, lnb,
                        (float*)Y, B, T_, L, tiles);
   else
-    hipLaunchKernelGGL((stem_fwd_kernel<bf16>), dim3(B * tiles), dim3(256), 0, s, (const bf16*)audio, w, b, lnw, lnb,
+    hipLaunchKernelGGL((stem_fwd_kernel<bf16>), dim3(B * tiles), dim3(256), 0, s, (const Res<bf16>*)audio, w, b, lnw, lnb,
                        (Res<bf16>*)Y, B, T_, L, tiles);
 }
 
@@ -180,7 +183,7 @@ void stem_bwd(hipStream_t s, DType dt, const void* audio, const void* dY, const 
     hipLaunchKernelGGL((stem_bwd_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)audio, (const float*)dY, w,
                        b, lnw, dw, db, dlnw, dlnb, B, T_, L, tiles, total, rec);
   else
-    hipLaunchKernelGGL((stem_bwd_kernel<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)audio, (const bf16*)dY, w, b,
+    hipLaunchKernelGGL((stem_bwd_kernel<bf16>), dim3(grid), dim3(256), 0, s, (const Res<bf16>*)audio, (const bf16*)dY, w, b,
                        lnw, dw, db, dlnw, dlnb, B, T_, L, tiles, total, rec);
 }
 

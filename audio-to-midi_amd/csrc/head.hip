@@ -557,12 +557,19 @@ __global__ __launch_bounds__(256) void adamw_commit_kernel(float* __restrict__ p
 // lane: the register files of the chip hold two of the four arrays, not more); behind the barrier pass 2 reads p again, forms
 // u from the kept moments (adamw_update_from_moments: the same bits), and writes p, m', v' and the zeroed g: 34.5 instead of
 // 56 bytes per parameter (the learning-rate factor as one byte, below), one launch instead of two.
-// The barrier is an arrival counter that only grows (norm2[4]; the launch index norm2[5] is advanced by workgroup 0 behind
-// it), polled by one thread per workgroup with a spin limit: every workgroup must be RESIDENT for it to open, which holds
-// when the grid is the number of compute units and nothing else runs on the device (the single-rank step; the host takes
-// the two-launch form otherwise).  A limit that expires sets the sticky word norm2[6]: that launch and every later one then
-// skip the update (valid_out = 0, g zeroed: the step reads as "non-finite gradients") and the host, which polls the word
-// where it reads the optimizer count, goes back to the two-launch form.
+// The barrier is an arrival counter that only grows (norm2[4]; the launch index norm2[5] is advanced behind it) plus ONE
+// DECISION WORD per launch (norm2[7]): the arrival that completes the count proposes "open", a workgroup whose spin limit
+// expires proposes "failed", both by compare-and-swap from "undecided" - the first proposal stands - and EVERY workgroup,
+// the one that completed the count and any that becomes resident later included, takes its verdict from that word.  The
+// update is therefore all-or-nothing (round 3 let each workgroup judge by its own spin: a workgroup that gave up while a
+// late arrival let the others through left a partially applied step).  Every workgroup must be RESIDENT for the
+// barrier to open, which holds when the grid is the number of compute units and nothing else runs on the device (the
+// optimizer is issued behind the step's collectives in stream order; the host takes the two-launch form under stream
+// capture and after a time-out).  A "failed" decision sets the sticky word norm2[6] and a mapped host word: that launch
+// and every later one skip the update (valid_out = 0, g zeroed), amt_optimizer_status reports it - a time-out is NOT a
+// non-finite step - and the host goes back to the two-launch form at its next call.
+// spin_limit / delay_wg / delay_spins: the limit (polls of ~0.5 us) and a test hook that holds one workgroup back in front
+// of its arrival (tests/test_step_surface_gpu.py: a late arrival inside and outside the limit).
 constexpr int kAdamPersistChunks = 24;
 template <int NCH>
 __global__ __launch_bounds__(512) void adamw_persist_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
@@ -572,7 +579,8 @@ __global__ __launch_bounds__(512) void adamw_persist_kernel(float* __restrict__ 
                                                             int* __restrict__ count, float* __restrict__ norm2, float clip,
                                                             const int* __restrict__ gate_i, const float* __restrict__ gate_f,
                                                             const float* __restrict__ loss, int* __restrict__ valid_out,
-                                                            int* __restrict__ fail_host) {
+                                                            int* __restrict__ fail_host, unsigned spin_limit, int delay_wg,
+                                                            unsigned delay_spins) {
   __shared__ float red[8];
   __shared__ float s_nrm2;
   __shared__ int s_cnt, s_fail;
@@ -580,7 +588,7 @@ __global__ __launch_bounds__(512) void adamw_persist_kernel(float* __restrict__ 
   // the per-parameter learning-rate factor takes few distinct values (one per depth of the layer-wise decay): one BYTE per
   // parameter indexes a table instead of 4 bytes of factor read in both passes (lr_idx[i] -> lr_tab[...] == lr_scale[i], same bits)
   __shared__ float s_tab[256];
-  unsigned* bar = reinterpret_cast<unsigned*>(norm2 + 4);     // [0] arrivals, [1] launches completed, [2] sticky timeout
+  unsigned* bar = reinterpret_cast<unsigned*>(norm2 + 4);     // [0] arrivals, [1] launches completed, [2] sticky timeout, [3] decision word
   const int tid = threadIdx.x;
   if (tid < 256) s_tab[tid] = lr_tab[tid];
   if (tid == 0) {
@@ -629,17 +637,21 @@ __global__ __launch_bounds__(512) void adamw_persist_kernel(float* __restrict__ 
     if (!dead) {
       atomicAdd(norm2, ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])));
       __threadfence();
-      atomicAdd(bar, 1u);
+      if ((int)blockIdx.x == delay_wg)                      // test hook: this workgroup arrives late
+        for (unsigned w = 0; w < delay_spins; ++w) __builtin_amdgcn_s_sleep(16);
+      // decision word of launch e: 2 e = undecided (the previous launch's "open"), 2 e + 2 = open, 2 e + 3 = failed
+      const unsigned undecided = 2u * s_epoch, open_v = undecided + 2u, fail_v = undecided + 3u;
       const unsigned target = (s_epoch + 1u) * gridDim.x;
-      unsigned spins = 0;
-      while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      if (atomicAdd(bar, 1u) + 1u == target) atomicCAS(bar + 3, undecided, open_v);   // the arrival that completes the count proposes "open"
+      unsigned spins = 0, d;
+      while ((d = __hip_atomic_load(bar + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == undecided) {
         __builtin_amdgcn_s_sleep(16);
-        if (++spins > (1u << 21) || __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-          __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (fail_host != nullptr) __hip_atomic_store(fail_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // mapped host word: the next call sees it without a sync
-          fail = 1;
-          break;
-        }
+        if (++spins > spin_limit) atomicCAS(bar + 3, undecided, fail_v);              // an expired limit proposes "failed"; the first proposal stands
+      }
+      if (d != open_v) {                                    // the launch's verdict, the same word for every workgroup
+        __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fail_host != nullptr) __hip_atomic_store(fail_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // mapped host word: the next call sees it without a sync
+        fail = 1;
       }
       __threadfence();
     }
@@ -691,7 +703,8 @@ __global__ __launch_bounds__(512) void adamw_persist_kernel(float* __restrict__ 
 void adamw_fused(hipStream_t s, float* params, float* gacc, float* m, float* v, const float* lr_scale, size_t n, float gmul,
                  float lr, float b1, float b2, float eps, float wd, int step, int* count, float* norm2, float clip,
                  const int* gate_i, const float* gate_f, const float* loss, int* valid_out, int persist_grid,
-                 const unsigned char* lr_idx, const float* lr_tab, int* persist_fail_host) {
+                 const unsigned char* lr_idx, const float* lr_tab, int* persist_fail_host, unsigned spin_limit, int delay_wg,
+                 unsigned delay_spins) {
   const bool vec = ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(gacc) | reinterpret_cast<uintptr_t>(m) |
                      reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(lr_scale)) & 15) == 0;
   // one-launch form: every parameter chunk has a register slot (persist_grid workgroups x 512 threads x kAdamPersistChunks)
@@ -699,7 +712,8 @@ void adamw_fused(hipStream_t s, float* params, float* gacc, float* m, float* v, 
       (n >> 2) <= (size_t)persist_grid * 512 * kAdamPersistChunks) {
     ProfScope ps(s, "adamw_persist", 0, 34.5 * n);
     hipLaunchKernelGGL(adamw_persist_kernel<kAdamPersistChunks>, dim3(persist_grid), dim3(512), 0, s, params, gacc, m, v, lr_scale, lr_idx, lr_tab, n,
-                       gmul, lr, b1, b2, eps, wd, step, count, norm2, clip, gate_i, gate_f, loss, valid_out, persist_fail_host);
+                       gmul, lr, b1, b2, eps, wd, step, count, norm2, clip, gate_i, gate_f, loss, valid_out, persist_fail_host,
+                       spin_limit > 0 ? spin_limit : (1u << 21), delay_wg, delay_spins);
     return;
   }
   {

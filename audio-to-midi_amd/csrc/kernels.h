@@ -102,7 +102,7 @@ void layernorm_bwd(hipStream_t s, DType dt, const void* dY, const void* X, const
                    PartialSink* sink = nullptr);
 
 // ----------------------------------------------------------------------------- CNN pieces
-// audio [B][2][T] (T dtype) -> Y [B][T/5][4] (Res) = LN(conv k5 s5)
+// audio [B][2][T] (Res: the model's input has the residual stream's storage type) -> Y [B][T/5][4] (Res) = LN(conv k5 s5)
 void stem_fwd(hipStream_t s, DType dt, const void* audio, const float* w /*[4][2][5]*/, const float* b,
               const float* lnw, const float* lnb, void* Y, int B, int T);
 void stem_bwd(hipStream_t s, DType dt, const void* audio, const void* dY, const float* w, const float* b,
@@ -374,7 +374,7 @@ void adamw_fused(hipStream_t s, float* params, float* gacc, float* m, float* v, 
                  float lr, float b1, float b2, float eps, float wd, int step, int* count, float* norm2, float clip,
                  const int* gate_i, const float* gate_f, const float* loss, int* valid_out, int persist_grid = 0,
                  const unsigned char* lr_idx = nullptr, const float* lr_tab = nullptr,
-                 int* persist_fail_host = nullptr);
+                 int* persist_fail_host = nullptr, unsigned spin_limit = 0, int delay_wg = -1, unsigned delay_spins = 0);
 // gate_i / gate_f (device, either may be null): both passes are no-ops unless *gate_i != 0 and *gate_f >= 0.999;
 // step > 0: explicit optimizer step, step < 0: *count + 1 (device count of applied updates, advanced behind an open gate)
 void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, float* norm2, float clip,

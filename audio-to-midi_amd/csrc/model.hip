@@ -343,6 +343,10 @@ struct amt_ctx {
   bool opt_persist = true;      // one-launch fused optimizer (head.hip: adamw_persist_kernel); AMT_OPT_PERSIST=0 or a barrier timeout: two launches
   int n_cus = 0;                // compute units of the device (grid of the one-launch optimizer)
   int persist_grid_extra = 0;   // AMT_OPT_PERSIST_EXTRA=<k> (tests): k workgroups more than can be resident, so that the barrier times out
+  unsigned persist_spins = 0;   // AMT_OPT_PERSIST_SPINS=<n> (tests): spin limit of the grid barrier in polls (0: the default, ~1 s)
+  int persist_delay_wg = -1;    // AMT_OPT_PERSIST_DELAY=<wg>:<polls> (tests): workgroup <wg> arrives <polls> polls late
+  unsigned persist_delay_spins = 0;
+  int persist_timeouts = 0;     // launches of the one-launch optimizer that this context has seen time out (amt_optimizer_status)
   bool prerot = true;           // AMT_PREROT=0: global layers' q / k leave the chain raw, the attention kernels rotate them while staging
 
   const float* P(size_t off) const { return params + off; }
@@ -1396,6 +1400,11 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   c->prerot = !(getenv("AMT_PREROT") && atoi(getenv("AMT_PREROT")) == 0);
   c->opt_persist = !(getenv("AMT_OPT_PERSIST") && atoi(getenv("AMT_OPT_PERSIST")) == 0);
   c->persist_grid_extra = getenv("AMT_OPT_PERSIST_EXTRA") ? atoi(getenv("AMT_OPT_PERSIST_EXTRA")) : 0;
+  c->persist_spins = getenv("AMT_OPT_PERSIST_SPINS") ? (unsigned)atol(getenv("AMT_OPT_PERSIST_SPINS")) : 0u;
+  if (const char* d = getenv("AMT_OPT_PERSIST_DELAY")) {
+    int wg = -1; unsigned polls = 0;
+    if (sscanf(d, "%d:%u", &wg, &polls) == 2) { c->persist_delay_wg = wg; c->persist_delay_spins = polls; }
+  }
   { hipDeviceProp_t pr; c->n_cus = (hipGetDeviceProperties(&pr, c->device) == hipSuccess) ? pr.multiProcessorCount : 0; }
   // XCD-team launches (team.h): opt-in while they are not faster than one launch per Block (profiles/r02_notes.md)
   if (getenv("AMT_TEAM") && atoi(getenv("AMT_TEAM")) != 0) {
@@ -1431,14 +1440,18 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   if ((he = hipMalloc(&c->loss_acc, 2 * sizeof(float))) != hipSuccess) return fail("hipMalloc(loss)", he);
   if ((he = hipMalloc(reinterpret_cast<void**>(&c->seed_word), sizeof(uint64_t))) != hipSuccess) return fail("hipMalloc(seed word)", he);
   if ((he = hipMemset(c->seed_word, 0, sizeof(uint64_t))) != hipSuccess) return fail("hipMemset", he);
-  if ((he = hipMalloc(reinterpret_cast<void**>(&c->gacc), (L.n_params + 64) * sizeof(float))) != hipSuccess)
+  // The accumulator is bucket-shaped (amt_grad_bucket): [.. | 4 control floats | n gradients | 2 control floats | ..], so that a
+  // data-parallel host can run its collectives ON it (no copy into a bucket of its own).  64 floats of room in front of the
+  // shift that aligns layer 0, 64 behind the gradients.
+  if ((he = hipMalloc(reinterpret_cast<void**>(&c->gacc), (L.n_params + 192) * sizeof(float))) != hipSuccess)
     return fail("hipMalloc(gradient accumulator)", he);
-  if ((he = hipMemset(c->gacc, 0, (L.n_params + 64) * sizeof(float))) != hipSuccess) return fail("hipMemset", he);
+  if ((he = hipMemset(c->gacc, 0, (L.n_params + 192) * sizeof(float))) != hipSuccess) return fail("hipMemset", he);
+  c->gacc_pad = 64;
   if (!L.layers.empty()) {
     const LayerP& l0 = L.layers[0];
     size_t a0 = l0.ln1_w;
     for (size_t o : {l0.ln1_b, l0.wqc, l0.wkv, l0.wo, l0.ln2_w, l0.ln2_b, l0.w1, l0.b1, l0.w2, l0.b2}) a0 = o < a0 ? o : a0;
-    c->gacc_pad = (int)((64 - a0 % 64) % 64);
+    c->gacc_pad = 64 + (int)((64 - a0 % 64) % 64);
   }
   std::vector<int> prefix(L.conv.size() + 1, 0);
   for (size_t i = 0; i < L.conv.size(); ++i)
@@ -1679,6 +1692,33 @@ int32_t amt_optimizer_init(amt_ctx* c, float layer_lr_decay) {
   return 0;
 }
 
+namespace {
+// the fused protocol's optimizer (include/amt.h): norm pass + commit pass over the context's accumulator
+int adamw_from_accumulator(amt_ctx* c, hipStream_t s, float lr_base, float b1, float b2, float eps, float weight_decay,
+                           float clip_norm, int step, float grad_mul, const float* loss_dev, const float* valid_f32,
+                           int32_t* valid_out) {
+  const size_t n = c->L.n_params;
+  int* count = reinterpret_cast<int*>(c->norm2 + 2);
+  if (!c->fused_used) { c->err = "amt_adamw_step(grads_flat = NULL): no backward pass has left gradients in the context (call amt_forward_backward* with grads_flat = NULL first)"; return 1; }
+  if (c->opt_persist && c->persist_fail != nullptr && *reinterpret_cast<volatile int*>(c->persist_fail) != 0) {
+    c->opt_persist = false;         // its grid barrier did not open (workgroups not co-resident): two launches from now on
+    c->persist_timeouts++;
+    *reinterpret_cast<volatile int*>(c->persist_fail) = 0;
+    c->err = "the one-launch fused optimizer timed out at its grid barrier (that step was skipped); using the two-launch form";
+  }
+  // A captured launch would replay whatever the barrier words hold at replay time with no host in between to see a
+  // time-out: under stream capture the step takes the two launches.
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cs);
+  const bool persist = c->opt_persist && c->lr_idx_ok && cs == hipStreamCaptureStatusNone;
+  adamw_fused(s, c->params, c->gacc + c->gacc_pad, c->adam_m, c->adam_v, c->lr_scale, n, c->gacc_mul * grad_mul, lr_base, b1, b2,
+              eps, weight_decay, step, count, c->norm2, clip_norm, nullptr, valid_f32, loss_dev ? loss_dev : c->loss_acc, valid_out,
+              persist ? c->n_cus + c->persist_grid_extra : 0, c->lr_idx, c->lr_tab, c->persist_fail_dev, c->persist_spins,
+              c->persist_delay_wg, c->persist_delay_spins);
+  return refresh(c, s);
+}
+}  // namespace
+
 int32_t amt_adamw_step_gated(amt_ctx* c, const float* grads_flat, float lr_base, float layer_lr_decay, float b1, float b2,
                              float eps, float weight_decay, float clip_norm, int32_t step, const int32_t* valid_i32,
                              const float* valid_f32, void* stream) {
@@ -1690,23 +1730,46 @@ int32_t amt_adamw_step_gated(amt_ctx* c, const float* grads_flat, float lr_base,
     if (amt_optimizer_init(c, layer_lr_decay)) return 1;
   }
   int* count = reinterpret_cast<int*>(c->norm2 + 2);
-  if (grads_flat == nullptr) {
+  if (grads_flat == nullptr)
     // fused protocol: the gradients are the sums the last amt_forward_backward*(grads_flat = NULL) left in the context's
     // accumulator; valid_i32 is an OUTPUT here (the all-finite flag of this step, 1 = update applied)
-    if (!c->fused_used) { c->err = "amt_adamw_step(grads_flat = NULL): no backward pass has left gradients in the context (call amt_forward_backward* with grads_flat = NULL first)"; return 1; }
-    if (c->opt_persist && c->persist_fail != nullptr && *reinterpret_cast<volatile int*>(c->persist_fail) != 0) {
-      c->opt_persist = false;         // its grid barrier did not open (workgroups not co-resident): two launches from now on
-      c->err = "the one-launch fused optimizer timed out at its grid barrier (that step was skipped); using the two-launch form";
-    }
-    adamw_fused(s, c->params, c->gacc + c->gacc_pad, c->adam_m, c->adam_v, c->lr_scale, n, c->gacc_mul, lr_base, b1, b2, eps,
-                weight_decay, step, count, c->norm2, clip_norm, nullptr, valid_f32, c->loss_acc, const_cast<int32_t*>(valid_i32),
-                (c->opt_persist && c->lr_idx_ok) ? c->n_cus + c->persist_grid_extra : 0, c->lr_idx, c->lr_tab, c->persist_fail_dev);
-    return refresh(c, s);
-  }
+    return adamw_from_accumulator(c, s, lr_base, b1, b2, eps, weight_decay, clip_norm, step, 1.f, nullptr, valid_f32,
+                                  const_cast<int32_t*>(valid_i32));
   adamw_compute(s, c->params, grads_flat, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, n, lr_base, b1, b2, eps,
                 weight_decay, step, count, c->norm2, valid_i32, valid_f32);
   adamw_apply(s, c->params, c->adam_upd, n, c->norm2, clip_norm, valid_i32, valid_f32, step, count);
   return refresh(c, s);
+}
+
+int32_t amt_adamw_step_reduced(amt_ctx* c, float lr_base, float layer_lr_decay, float b1, float b2, float eps,
+                               float weight_decay, float clip_norm, int32_t step, float grad_mul, const float* loss_sum,
+                               int32_t* valid_out, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (step < 1 && step != -1) { c->err = "amt_adamw_step: step must be >= 1 (the first optimizer step is step 1), or -1 for the device count"; return 1; }
+  if (!(grad_mul > 0.f)) { c->err = "amt_adamw_step_reduced: grad_mul must be positive (1 / world size)"; return 1; }
+  if (!c->adam_m || c->lr_scale_decay != layer_lr_decay) {
+    if (amt_optimizer_init(c, layer_lr_decay)) return 1;
+  }
+  return adamw_from_accumulator(c, s, lr_base, b1, b2, eps, weight_decay, clip_norm, step, grad_mul, loss_sum, nullptr, valid_out);
+}
+
+float* amt_grad_bucket(amt_ctx* c, uint64_t* head, uint64_t* n, uint64_t* tail) {
+  if (head) *head = 4;
+  if (n) *n = c->L.n_params;
+  if (tail) *tail = 2;
+  return c->gacc + c->gacc_pad - 4;
+}
+
+int32_t amt_optimizer_status(amt_ctx* c) {
+  if (c->persist_fail != nullptr && *reinterpret_cast<volatile int*>(c->persist_fail) != 0) {
+    c->persist_timeouts++;
+    *reinterpret_cast<volatile int*>(c->persist_fail) = 0;      // counted; the device's sticky word keeps later launches of the one-launch form dead
+    if (c->opt_persist) {
+      c->opt_persist = false;
+      c->err = "the one-launch fused optimizer timed out at its grid barrier (that step was skipped); using the two-launch form";
+    }
+  }
+  return c->persist_timeouts;
 }
 
 int32_t amt_grad_accumulator_reset(amt_ctx* c, void* stream) {
@@ -1720,10 +1783,7 @@ int32_t amt_optimizer_count(amt_ctx* c) {
   if (!c->norm2) return 0;
   int w[5] = {0, 0, 0, 0, 0};     // [0] count, [4] sticky timeout word of the one-launch fused form (head.hip)
   if (hipMemcpy(w, c->norm2 + 2, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  if (w[4] != 0 && c->opt_persist) {
-    c->opt_persist = false;         // its grid barrier did not open (workgroups not co-resident): two launches from now on
-    c->err = "the one-launch fused optimizer timed out at its grid barrier (that step was skipped); using the two-launch form";
-  }
+  if (w[4] != 0) (void)amt_optimizer_status(c);      // the sticky word: switch to the two launches, count the time-out
   return w[0];
 }
 

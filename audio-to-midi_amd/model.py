@@ -41,6 +41,9 @@ model_config = {
 }
 
 _TORCH_DTYPE = {"float32": torch.float32, "bfloat16": torch.bfloat16}
+# dtype of the audio a context takes (include/amt.h, Conventions): bf16 contexts read IEEE half samples - what the reference
+# feeds its model (grain_loader.py:88) - so the input is not quantised a second time
+_AUDIO_DTYPE = {"float32": torch.float32, "bfloat16": torch.float16}
 
 
 class StepOutput(NamedTuple):
@@ -66,6 +69,7 @@ class OutputSequenceGenerator:
         self.conf = conf
         self.dtype = dtype
         self.torch_dtype = _TORCH_DTYPE[dtype]
+        self.audio_dtype = _AUDIO_DTYPE[dtype]
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("OutputSequenceGenerator runs on an AMD GPU only (device must be cuda:N)")
@@ -163,7 +167,7 @@ class OutputSequenceGenerator:
         T = samples.shape[2]
         if T % 320 != 0 or T // 320 < 16:
             raise ValueError("T must be a multiple of 320 samples and at least 16 frames long")
-        return samples.to(device=self.device, dtype=self.torch_dtype).contiguous()
+        return samples.to(device=self.device, dtype=self.audio_dtype).contiguous()
 
     def _ensure_rope(self, rope_freqs, S):
         if rope_freqs is not None:
@@ -253,9 +257,12 @@ class OutputSequenceGenerator:
     def loss_and_grads_phase(self, phase: int, audio, labels, grads_out: torch.Tensor, loss_out: torch.Tensor,
                              valid_out: torch.Tensor, scale: float = 1.0, seed: int = 0, train: bool = True, accum=(0, 1)):
         """Asynchronous half of ``loss_and_grads`` (include/amt.h: amt_forward_backward_phase).  All tensors are
-        caller-owned device tensors (audio in the activation dtype, labels fp32); nothing is synchronised."""
+        caller-owned device tensors (audio in ``model.audio_dtype``, labels fp32); nothing is synchronised."""
         if int(phase) not in (1, 2):
             raise RuntimeError("amt_forward_backward_phase failed: phase must be 1 or 2")
+        if audio.dtype != self.audio_dtype or not audio.is_cuda or not audio.is_contiguous():
+            raise ValueError(f"audio must be a contiguous device tensor of dtype {self.audio_dtype} (model.audio_dtype): "
+                             "this entry point converts nothing")
         self._check(self._L.amt_forward_backward_accum(self._h, _lib.ptr(audio), _lib.ptr(labels), audio.shape[0],
                                                        audio.shape[2], float(scale), int(seed), 1 if train else 0,
                                                        _lib.ptr(loss_out), _lib.ptr(grads_out), _lib.ptr(valid_out), None,
@@ -286,6 +293,35 @@ class OutputSequenceGenerator:
                                                  float(b1), float(b2), float(eps), float(weight_decay), float(clip_norm),
                                                  int(step), _lib.ptr(valid), _lib.ptr(valid_mean), self._stream()),
                     "amt_adamw_step")
+
+    def adamw_step_reduced(self, lr_base, step, grad_mul: float, loss_sum: torch.Tensor, layer_lr_decay=0.7, b1=0.9,
+                           b2=0.999, eps=1e-3, weight_decay=0.005, clip_norm=1.0, valid: Optional[torch.Tensor] = None):
+        """The fused protocol's optimizer behind a SUM all-reduce that ran on the context's own accumulator
+        (include/amt.h: amt_adamw_step_reduced): reads sums * grad_mul (1 / world size), gate = isfinite(|update|^2) and
+        isfinite(loss_sum[0]); ``valid`` (device int32[1]) is an output, 1 iff the update was applied."""
+        if valid is not None and (valid.dtype != torch.int32 or not valid.is_cuda):
+            raise ValueError("valid must be a device int32 tensor")
+        if loss_sum.dtype != torch.float32 or not loss_sum.is_cuda:
+            raise ValueError("loss_sum must be a device float32 tensor")
+        self._check(self._L.amt_adamw_step_reduced(self._h, float(lr_base), float(layer_lr_decay), float(b1), float(b2),
+                                                   float(eps), float(weight_decay), float(clip_norm), int(step),
+                                                   float(grad_mul), _lib.ptr(loss_sum), _lib.ptr(valid), self._stream()),
+                    "amt_adamw_step_reduced")
+
+    def grad_bucket(self):
+        """(tensor, head, n, tail): the context's gradient accumulator as ONE float32 device tensor
+        ``[head control floats | n gradient sums | tail control floats]`` (include/amt.h: amt_grad_bucket) - collectives run
+        on views of it, nothing is copied.  The tensor does not own the memory: keep the model alive."""
+        h, n, t = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        ptr = self._L.amt_grad_bucket(self._h, C.byref(h), C.byref(n), C.byref(t))
+        if not ptr:
+            raise RuntimeError("amt_grad_bucket returned NULL")
+        total = int(h.value + n.value + t.value)
+        return _DevView(ptr, total, self.device).tensor(), int(h.value), int(n.value), int(t.value)
+
+    def optimizer_status(self) -> int:
+        """Optimizer steps lost to a barrier time-out of the one-launch form (include/amt.h: amt_optimizer_status)."""
+        return int(self._L.amt_optimizer_status(self._h))
 
     def reset_grad_accumulator(self):
         """Zero the context's gradient accumulator (after a fused backward pass whose gradients are not to be applied)."""

@@ -81,12 +81,26 @@ class GradBucket:
     HEAD = 4
     TAIL = 2
 
-    def __init__(self, n_params: int, device):
+    def __init__(self, n_params: int, device, buf: Optional[torch.Tensor] = None):
         self.n = int(n_params)
-        self.buf = torch.zeros(self.HEAD + self.n + self.TAIL, dtype=torch.float32, device=device)
+        if buf is None:
+            buf = torch.zeros(self.HEAD + self.n + self.TAIL, dtype=torch.float32, device=device)
+        if buf.dtype != torch.float32 or buf.numel() != self.HEAD + self.n + self.TAIL:
+            raise ValueError("a gradient bucket is HEAD + n + TAIL float32 values")
+        self.buf = buf
+        self.loss_div = 1.0       # the loss word holds loss * loss_div (in-place protocol: the SUM over ranks)
         self.head = self.buf[:self.HEAD]
         self.grads = self.buf[self.HEAD:self.HEAD + self.n]
         self.tail = self.buf[self.HEAD + self.n:]
+
+    @classmethod
+    def of_model(cls, model) -> "GradBucket":
+        """The model's OWN gradient accumulator as the bucket (include/amt.h: amt_grad_bucket): the in-place protocol -
+        backward sums, collectives and optimizer all work on this one buffer, nothing is copied or unscaled in between."""
+        buf, head, n, tail = model.grad_bucket()
+        if head != cls.HEAD or tail != cls.TAIL:
+            raise RuntimeError("amt_grad_bucket layout differs from GradBucket's")
+        return cls(n, buf.device, buf=buf)
 
     def first_range(self, split: int) -> torch.Tensor:
         """complete after phase 1: gradients [split, n), loss, valid_first"""
@@ -106,11 +120,16 @@ class HipTrainBackend:
 
     def __init__(self, model, audio: torch.Tensor, labels: torch.Tensor, bucket: GradBucket, scale: float = 1.0,
                  use_optimizer: bool = True, accum_steps: int = 1, fused: bool = False):
+        audio = audio.to(dtype=model.audio_dtype)      # once, here: no conversion launch inside a captured step
         self.model, self.audio, self.labels, self.bucket, self.scale = model, audio, labels, bucket, float(scale)
         self.use_optimizer = use_optimizer
-        # fused = the single-rank protocol (include/amt.h): the gradients never leave the context, AdamW reads the raw
-        # sums (norm pass + commit pass) and leaves the accumulator zeroed; no collective can see them, so world size 1 only
+        # fused = the fused protocol (include/amt.h): the gradients never leave the context's accumulator, AdamW reads the
+        # raw sums (norm pass + commit pass, one launch) and leaves the accumulator zeroed.  With more than one rank the
+        # bucket must BE that accumulator (GradBucket.of_model): the collectives then run on it in place and the rank runs
+        # the single-rank program plus the collectives (in_place).
         self.fused = bool(fused) and use_optimizer
+        self.in_place = self.fused and bucket.buf.data_ptr() == model.grad_bucket()[0].data_ptr()
+        self.world = 1            # set by DataParallelStep: 1 / world multiplies the SUM-reduced gradients in the optimizer
         # train.py:275-310: the rank's batch in `accum_steps` minibatches, gradients accumulated in fp32 ON THE DEVICE (the
         # context's accumulator: amt_forward_backward_accum), grads / (grad_scale * steps) in the last minibatch's final pass
         self.accum_steps = int(accum_steps)
@@ -127,11 +146,16 @@ class HipTrainBackend:
 
     def full(self, seed: int):
         b, k = self.bucket, self.accum_steps
-        for i, (a, y) in enumerate(self._mb):      # one dropout seed per minibatch (train.py:277 splits the key)
-            self.model.loss_and_grads(a, y, scale=self.scale, seed=seed + i, train=True, grads_out=None if self.fused else b.grads,
+        # Every minibatch of a step draws its masks from the SAME key, as the reference does: compute_training_step splits
+        # the key once per step (train.py:274) and minibatch_scan_body hands that one `key` to compute_loss in every scan
+        # iteration (train.py:283-290), which splits it per sample of the minibatch (train.py:53).
+        for i, (a, y) in enumerate(self._mb):
+            self.model.loss_and_grads(a, y, scale=self.scale, seed=seed, train=True, grads_out=None if self.fused else b.grads,
                                       sync=False, accum=(i, k), loss_out=self.loss_buf, valid_out=self.valid_buf,
                                       fused_optimizer=self.fused)
-        if not self.fused:      # (fused: the flag is an output of the optimizer's commit pass, packed by apply())
+        if self.in_place:       # the rank's loss next to its gradient sums: reduced with them (the flags come out of the optimizer)
+            self.model.pack_tail(self.loss_buf, self.valid_buf, tail_loss=b.tail[0:1])
+        elif not self.fused:    # (fused: the flag is an output of the optimizer's commit pass, packed by apply())
             self.model.pack_tail(self.loss_buf, self.valid_buf, head_valid=b.head[0:1], tail_loss=b.tail[0:1], tail_valid=b.tail[1:2])
 
     def discard(self):
@@ -141,26 +165,41 @@ class HipTrainBackend:
 
     def half(self, phase: int, seed: int):
         b, k = self.bucket, self.accum_steps
+        if self.fused and not self.in_place:
+            raise RuntimeError("the two-phase step of the fused protocol needs the model's own bucket (GradBucket.of_model)")
+        gout = None if self.in_place else b.grads      # in place: raw sums stay in the accumulator, which IS the bucket
         if phase == 1:      # all minibatches but the last run whole; the last one is the step that is cut in two
             for i, (a, y) in enumerate(self._mb[:-1]):
-                self.model.loss_and_grads(a, y, scale=self.scale, seed=seed + i, train=True, grads_out=b.grads, sync=False,
-                                          accum=(i, k), loss_out=self.loss_buf, valid_out=self.valid_buf)
+                self.model.loss_and_grads(a, y, scale=self.scale, seed=seed, train=True, grads_out=gout, sync=False,
+                                          accum=(i, k), loss_out=self.loss_buf, valid_out=self.valid_buf,
+                                          fused_optimizer=self.in_place)
         a, y = self._mb[-1]
-        self.model.loss_and_grads_phase(phase, a, y, b.grads, self.loss_buf, self.valid_buf,
-                                        scale=self.scale, seed=seed + k - 1, train=True, accum=(k - 1, k))
-        if phase == 1:      # captured with the half: no eager launches between the graphs and the collectives
+        self.model.loss_and_grads_phase(phase, a, y, gout, self.loss_buf, self.valid_buf,
+                                        scale=self.scale, seed=seed, train=True, accum=(k - 1, k))
+        if self.in_place:
+            if phase == 1:
+                self.model.pack_tail(self.loss_buf, self.valid_buf, tail_loss=b.tail[0:1])
+        elif phase == 1:    # captured with the half: no eager launches between the graphs and the collectives
             self.model.pack_tail(self.loss_buf, self.valid_buf, tail_loss=b.tail[0:1], tail_valid=b.tail[1:2])
         else:
             self.model.pack_tail(self.loss_buf, self.valid_buf, head_valid=b.head[0:1])
 
     def advance_seed(self):
-        self.model.advance_seed(self.accum_steps)
+        self.model.advance_seed(1)      # one key per step (train.py:274), whatever the number of minibatches
 
     def apply(self, step: int, lr_base: float):
         # Gated on the all-reduced flag, on the device.  step = -1: the bias corrections come from the context's DEVICE
         # count of applied updates, which a skipped (non-finite) step does not advance - optax's count behaves the same
         # way and the reference rolls its optimizer state back (train.py:369-377); `step` on the host would drift.
-        if self.fused:
+        if self.in_place:
+            # the accumulator holds the SUM over ranks of the raw sums, the loss word the sum of the ranks' losses: the
+            # optimizer multiplies by 1 / world and gates on isfinite(|update|^2) && isfinite(loss sum) - the same verdict on
+            # every rank, no flag collective (include/amt.h: amt_adamw_step_reduced)
+            b = self.bucket
+            b.loss_div = float(self.world)
+            self.model.adamw_step_reduced(lr_base, -1, 1.0 / self.world, b.tail[0:1], valid=self.valid_buf)
+            self.model.pack_tail(b.tail[0:1], self.valid_buf, head_valid=b.head[0:1], tail_valid=b.tail[1:2])
+        elif self.fused:
             b = self.bucket
             self.model.adamw_step(None, lr_base=lr_base, step=-1, valid=self.valid_buf)
             self.model.pack_tail(self.loss_buf, self.valid_buf, head_valid=b.head[0:1], tail_loss=b.tail[0:1], tail_valid=b.tail[1:2])
@@ -190,6 +229,13 @@ class DataParallelStep:
                  lr_base: float = 1e-4):
         self.backend, self.bucket, self.split, self.dist = backend, bucket, int(split), dist
         self.world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
+        # in-place protocol (HipTrainBackend(fused=True) over GradBucket.of_model): the collectives are SUMs over the
+        # gradient sums and the loss word on the context's own accumulator; 1 / world goes into the optimizer
+        self.in_place = bool(getattr(backend, "in_place", False))
+        if hasattr(backend, "world"):
+            backend.world = self.world
+        if getattr(backend, "fused", False) and self.world > 1 and not self.in_place:
+            raise ValueError("more than one rank with the fused optimizer needs the model's own bucket: GradBucket.of_model(model)")
         # the optimizer gate tests the MEAN of the ranks' 0/1 flags against 0.999 (csrc/head.hip: adamw_gate_open): one
         # bad rank among N gives (N - 1) / N, which must stay below the threshold
         if self.world >= 1000:
@@ -200,6 +246,7 @@ class DataParallelStep:
         self.graph = bool(graph) and self.cuda
         self.step_no = 0
         self.applied = 0          # optimizer updates actually applied (device count, refreshed by result())
+        self.optimizer_timeouts = 0   # steps lost to a barrier time-out of the one-launch optimizer (refreshed by result())
         self._graphs = None
         self._gen = None
         self._comm = torch.cuda.Stream(device=bucket.buf.device) if self.cuda else None
@@ -213,11 +260,28 @@ class DataParallelStep:
     def _mean_allreduce(self, t: torch.Tensor):
         if self.dist is None or not self.dist.is_initialized():
             return
+        if self.in_place:          # raw sums: 1 / world is applied by the optimizer (and by result() to the loss)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            return
         if self._avg is not None:
             self.dist.all_reduce(t, op=self._avg)
         else:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
             t.mul_(1.0 / self.world)
+
+    # what a collective covers.  Legacy protocol: the control words travel with the gradients.  In place: the gradient sums
+    # and the loss word only (the flags are outputs of the optimizer, identical on every rank by construction).
+    def _whole_range(self):
+        b = self.bucket
+        return b.buf[b.HEAD:b.HEAD + b.n + 1] if self.in_place else b.buf
+
+    def _first_range(self):
+        b = self.bucket
+        return b.buf[b.HEAD + self.split:b.HEAD + b.n + 1] if self.in_place else b.first_range(self.split)
+
+    def _second_range(self):
+        b = self.bucket
+        return b.buf[b.HEAD:b.HEAD + self.split] if self.in_place else b.second_range(self.split)
 
     # ---- capture -----------------------------------------------------------------------------------
     def prepare(self, seed: int = 0):
@@ -228,6 +292,7 @@ class DataParallelStep:
         discard()
         if self.overlap:
             be.half(1, seed); be.half(2, seed)
+            discard()
         if self.cuda:
             torch.cuda.synchronize()
         if not self.graph:
@@ -239,6 +304,7 @@ class DataParallelStep:
             discard()
             if self.overlap:
                 be.half(1, seed); be.half(2, seed)
+                discard()
         torch.cuda.current_stream().wait_stream(side)
         if self.overlap:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -278,14 +344,14 @@ class DataParallelStep:
                 main = torch.cuda.current_stream()
                 self._comm.wait_stream(main)
                 with torch.cuda.stream(self._comm):
-                    self._mean_allreduce(b.first_range(self.split))     # transformer + decoder range, loss, first flag
+                    self._mean_allreduce(self._first_range())           # transformer + decoder range, loss, first flag
             else:
-                self._mean_allreduce(b.first_range(self.split))
+                self._mean_allreduce(self._first_range())
             if self._graphs is not None:
                 self._graphs[1].replay()
             else:
                 be.half(2, seed)
-            self._mean_allreduce(b.second_range(self.split))             # whole-step flag + CNN range
+            self._mean_allreduce(self._second_range())                   # whole-step flag + CNN range
             if self.cuda:
                 torch.cuda.current_stream().wait_stream(self._comm)
         else:
@@ -294,7 +360,7 @@ class DataParallelStep:
             else:
                 be.full(seed)
             if self.world > 1:
-                self._mean_allreduce(b.buf)                               # ONE bucket: flag, gradients, loss, flag
+                self._mean_allreduce(self._whole_range())                 # ONE bucket: flag, gradients, loss, flag
         be.apply(self.step_no, self.lr_base)
 
     def result(self) -> Tuple[float, bool]:
@@ -303,10 +369,14 @@ class DataParallelStep:
         host's step count is re-aligned with the device's count of APPLIED updates, so the learning-rate schedule
         (``schedule(applied)``) does not run ahead after skipped steps."""
         v = self.bucket.buf[[0, self.bucket.HEAD + self.bucket.n, self.bucket.HEAD + self.bucket.n + 1]].tolist()
+        v[1] /= self.bucket.loss_div
         valid = v[0] >= 0.999 and v[2] >= 0.999
         if hasattr(self.backend, "applied_steps"):
             self.applied = int(self.backend.applied_steps())
         m = getattr(self.backend, "model", None)
+        # a barrier time-out of the one-launch optimizer skipped that step as a whole: reported as such, NOT as non-finite
+        # gradients (a loss-scale controller must not halve its scale for it); the context has taken the two launches since
+        self.optimizer_timeouts = int(m.optimizer_status()) if (m is not None and hasattr(m, "optimizer_status")) else 0
         if m is not None and hasattr(m, "team_status") and m.team_status() != 0:     # polled where the loop synchronises anyway
             raise RuntimeError("an in-launch XCD-team hand-off timed out (amt_team_status != 0): the outputs of that step are "
                                "undefined; the context has switched its CNN stages back to one launch per Block")

@@ -244,7 +244,7 @@ def main_infer(args):
     full = rng.standard_normal((2, int(seconds * 16000))).astype(np.float32)
     windows, _ = amt_infer.slice_full_audio(amt_infer.normalize_audio(full), overlap)
     n_win = windows.shape[0]
-    batch = torch.from_numpy(np.tile(windows, (clips, 1, 1))).to(dev, torch.bfloat16)     # resident in HBM
+    batch = torch.from_numpy(np.tile(windows, (clips, 1, 1))).to(dev, model.audio_dtype)     # resident in HBM
     B = batch.shape[0]
 
     def step():
@@ -358,7 +358,7 @@ def main():
     if args.attn_fp8:
         model.set_attn_fp8(True)
     audio_np, labels_np = amt.synth.make_batch_fast(B_PER_GPU, T_SAMPLES, seed=100 + rank)
-    audio = torch.from_numpy(audio_np).to(dev, torch.bfloat16)       # inputs resident in HBM
+    audio = torch.from_numpy(audio_np).to(dev, model.audio_dtype)    # inputs resident in HBM
     labels = torch.from_numpy(labels_np).to(dev)
     # One flat fp32 bucket (audio_to_midi_amd.train.GradBucket): [finite flag of the whole step, 3 pad | gradients
     # (amt layout) | loss, finite flag of the first half].  With N > 1 it is averaged over the ranks (ReduceOp.AVG:
@@ -366,8 +366,13 @@ def main():
     # overlap, graph capture, collectives, device-gated AdamW - is audio_to_midi_amd.train.DataParallelStep, the same
     # code the gloo world-2 test drives (tests/test_dp_cpu.py).
     from audio_to_midi_amd import train as amt_train
-    bucket = amt_train.GradBucket(model.n_params, dev)
-    gflat = bucket.grads
+    # The fused protocol (include/amt.h) at every N: the bucket IS the context's gradient accumulator
+    # (GradBucket.of_model), the backward pass leaves its raw fp32 sums there, the collectives (SUM) run on it in place and
+    # one optimizer launch reads sums * 1 / world, tests finiteness, clips, commits and zeroes it.  The N > 1 rank runs the
+    # N = 1 program plus the collectives.  --no-fused-optimizer: the round-3 form (unscale pass into a separate bucket,
+    # ReduceOp.AVG, three-pass optimizer).
+    fused = not args.no_optimizer and not args.no_fused_optimizer
+    bucket = amt_train.GradBucket.of_model(model) if fused else amt_train.GradBucket(model.n_params, dev)
     # N > 1: the step runs in two halves (include/amt.h: amt_forward_backward_phase).  The gradients of the
     # decoder + transformer + final CNN norm (37 of the 46 MB) are complete after the first half and their
     # all-reduce (with the loss and the first half's finite flag behind them) runs on a side stream while the CNN
@@ -379,9 +384,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    # one rank, one collective-free step: the fused protocol (include/amt.h) - AdamW reads the gradient sums where the
-    # backward pass left them (grads / scale, the finite check and the clip are all still computed, train.py:319-325)
-    fused = world == 1 and not overlap and not args.no_optimizer and not args.no_fused_optimizer
+    # (AdamW reads the gradient sums where the backward pass - and the collectives - left them: grads / scale, the
+    # finite check and the clip are all still computed, train.py:319-325)
     backend = amt_train.HipTrainBackend(model, audio, labels, bucket, scale=1.0, use_optimizer=not args.no_optimizer, fused=fused)
     dp = amt_train.DataParallelStep(backend, bucket, backend.split, dist=dist, overlap=overlap, graph=not args.no_graph,
                                     lr_base=1e-4)
@@ -400,6 +404,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    host_issue_ms = 1e3 * (time.perf_counter() - t0) / args.steps     # how long the HOST needs to issue a step (diagnostic)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -459,10 +464,12 @@ def main():
                                    + ("" if args.no_optimizer else ", AdamW + global-norm clip + bf16 weight refresh"),
                        "global_batch": world * B_PER_GPU, "clip_seconds": CLIP_SECONDS, "frames": T_SAMPLES // 320,
                        "parallelism": f"dp{world}", "hipgraph": graph is not None,
-                       "grad_allreduce": ("two collectives (ReduceOp.AVG), the first overlapped with the CNN backward" if overlap else "one bucket (ReduceOp.AVG)") if world > 1 or overlap else None,
+                       "grad_allreduce": (("two collectives, the first overlapped with the CNN backward" if overlap else "one bucket")
+                                          + (" (SUM, in place on the context's accumulator; 1 / world in the optimizer)" if fused else " (ReduceOp.AVG on a separate bucket)")) if world > 1 or overlap else None,
                        "optimizer": None if args.no_optimizer else ("fused: norm pass + commit pass over the context's gradient accumulator" if fused else "grads_finalize + adamw_compute + adamw_apply over the bucket"),
                        "weights": "random init (Equinox distributions), 11606230 params"},
             "model_tflops": round(world * FLOPS_PER_STEP / (elapsed / args.steps) / 1e12, 2),
+            "host_issue_ms_per_step": round(host_issue_ms, 4),
             "loss": round(loss_val, 3), "grads_valid": bool(grads_valid), "loss_finite": True,
             "roofline": roofline,
             "rooflines": named_rooflines(breakdown, args.profile_steps) if breakdown else None,

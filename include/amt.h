@@ -18,8 +18,12 @@
  *     (the workspace is (re)allocated on the first call with a new (B, T): do that call outside
  *     hipGraph capture).
  *   - One context per device per process; a context is not thread-safe.
- *   - Activation dtype (AMT_F32 or AMT_BF16) is fixed at creation: `audio` uses it; logits,
- *     probs, labels, losses and gradients are always float32.
+ *   - Activation dtype (AMT_F32 or AMT_BF16) is fixed at creation.  `audio` is float32 in AMT_F32 contexts and
+ *     IEEE float16 in AMT_BF16 contexts: the reference feeds its model float16 samples (grain_loader.py:88;
+ *     python.rs:251-261 rounds them through f16 at load time), so the bf16 path adds no input quantisation of its
+ *     own (bf16 samples alone moved the frame logits by up to 2e-2: profiles/r04_notes.md).  The same two-byte IEEE
+ *     half is the storage type of the forward residual stream inside a bf16 context (csrc/common.h: Res<T>);
+ *     GEMM operands and gradients are bf16.  Logits, probs, labels, losses and parameter gradients are always float32.
  *   - Return value 0 = success; otherwise amt_last_error(ctx) (or amt_last_error(NULL) for a
  *     failed amt_create) describes the failure.
  */
@@ -98,7 +102,7 @@ int32_t amt_set_attn_fp8(amt_ctx* ctx, int32_t enable);
 int32_t amt_num_frames(const amt_config* cfg, int32_t T);
 
 /* Inference: model.predict under vmap (model.py:771-773, infer.py:40).
- * audio [B][2][T] (act dtype) -> logits, probs [B][S][n_events] float32 (either may be NULL). */
+ * audio [B][2][T] (float32 | float16, see Conventions) -> logits, probs [B][S][n_events] float32 (either may be NULL). */
 int32_t amt_forward(amt_ctx* ctx, const void* audio, int32_t B, int32_t T, float* logits, float* probs,
                     void* stream);
 
@@ -141,8 +145,9 @@ uint64_t amt_grad_bucket_split(const amt_ctx* ctx);
  *   accum_index  0 .. accum_count - 1, in order, same grads_flat / grads_valid / loss_out pointers in every call
  * Call 0 zeroes the context's fp32 accumulator; every call adds its gradients to it (no second buffer, no extra pass);
  * only the last call writes grads_flat = accumulator / (scale * accum_count), loss_out = mean over the minibatches of
- * their mean loss, and AND-s grads_valid.  Each call may use its own seed (the reference splits the key per
- * minibatch, train.py:277).  accum_count == 1 is exactly amt_forward_backward / _phase. */
+ * their mean loss, and AND-s grads_valid.  The reference hands every minibatch of a step the SAME key (split once per
+ * step, train.py:274, 283-290): pass the same seed in every call to reproduce that (audio_to_midi_amd.train does); a
+ * different seed per call is allowed and draws independent masks.  accum_count == 1 is exactly amt_forward_backward / _phase. */
 int32_t amt_forward_backward_accum(amt_ctx* ctx, const void* audio, const float* labels, int32_t B, int32_t T,
                                    float scale, uint64_t seed, int32_t train, float* loss_out, float* grads_flat,
                                    int32_t* grads_valid, float* logits, int32_t phase, int32_t accum_index,
@@ -219,11 +224,37 @@ int32_t amt_optimizer_count(amt_ctx* ctx);
  * warm-up run, an aborted step) must be followed by amt_grad_accumulator_reset, otherwise the next one adds to it -
  * which is also how train.py:275-310's accumulation over minibatches looks in this protocol.
  * By default the two passes are ONE launch with a grid barrier between them (one workgroup per compute unit; the new moments
- * stay in registers across it): it needs the device to itself for those ~100 us.  If its barrier does not open within ~1 s
- * (another stream holds compute units) the update of that step is skipped (valid = 0, accumulator zeroed), a sticky device
- * word is set, and amt_optimizer_count - which reads it - switches the context to the two launches for good and records
- * the reason in amt_last_error.  AMT_OPT_PERSIST=0 selects the two launches from the start. */
+ * stay in registers across it): it needs the device to itself for those ~100 us - issue it in stream order behind the
+ * step's collectives.  The barrier's verdict is one word per launch that every workgroup reads (all-or-nothing).  If it does
+ * not open within ~1 s (another stream holds compute units) the update of that step is skipped as a whole (valid = 0,
+ * accumulator zeroed), a sticky device word and a mapped host word are set, and the next optimizer call of the context (or
+ * amt_optimizer_status / amt_optimizer_count) switches it to the two launches for good and records the reason in
+ * amt_last_error.  A time-out is NOT a non-finite step: amt_optimizer_status counts them, so that a loss-scale controller
+ * does not halve its scale for one.  Under stream capture the two launches are taken (a replayed launch would have no
+ * host between replays to see a time-out).  AMT_OPT_PERSIST=0 selects the two launches from the start. */
 int32_t amt_grad_accumulator_reset(amt_ctx* ctx, void* stream);
+/* Number of optimizer steps this context has lost to a barrier time-out of the one-launch form (0 in normal operation;
+ * reads a mapped host word: no synchronisation, but only steps whose launch has completed are seen). */
+int32_t amt_optimizer_status(amt_ctx* ctx);
+
+/* ---- the same protocol across ranks: the collectives run ON the context's accumulator ---------------------------------
+ * The accumulator is bucket-shaped: [head control floats | n gradient sums | tail control floats], contiguous, the
+ * gradient range 16-byte aligned.  amt_grad_bucket returns its first float and the three lengths (head = 4, tail = 2:
+ * audio_to_midi_amd/train.py: GradBucket uses [0] of the head and [0], [1] of the tail; amt_pack_tail writes them).  A
+ * data-parallel step that replaces train.py:238-244, 280, 292-325 is then, per rank and in stream order:
+ *     amt_forward_backward*(grads_flat = NULL)          raw fp32 sums stay in the accumulator (no unscale pass, no copy)
+ *     amt_pack_tail(.., tail_loss = tail)               the rank's loss next to the gradients
+ *     SUM all-reduce over [gradients | tail]            (RCCL; in one piece, or the two ranges of amt_forward_backward_phase)
+ *     amt_adamw_step_reduced(grad_mul = 1 / world, loss_sum = tail)
+ * The optimizer reads accumulator * grad_mul / (scale * accum_count), tests isfinite(|update|^2) && isfinite(*loss_sum) -
+ * a non-finite gradient on ANY rank makes the reduced sum, hence |update|^2, non-finite on EVERY rank: the all-finite flag
+ * of train.py:320-322 needs no collective of its own - and leaves the accumulator zeroed.  This is the single-rank fused
+ * step plus the collectives: the N > 1 rank runs the program the N = 1 benchmark times.  valid_out: device int32, 1 iff
+ * the update was applied (the same on every rank). */
+float* amt_grad_bucket(amt_ctx* ctx, uint64_t* head, uint64_t* n, uint64_t* tail);
+int32_t amt_adamw_step_reduced(amt_ctx* ctx, float lr_base, float layer_lr_decay, float b1, float b2, float eps,
+                               float weight_decay, float clip_norm, int32_t step, float grad_mul, const float* loss_sum,
+                               int32_t* valid_out, void* stream);
 
 /* ---- measurement aid (bench.py roofline leg): per-kernel-class timing with HIP events recorded
  * on the launch stream around every kernel launch.  Process-global; off by default. */

@@ -36,7 +36,7 @@ int32_t amt_op_layernorm_fwd(int32_t dtype, const void* X, const float* w, const
 int32_t amt_op_layernorm_bwd(int32_t dtype, const void* dY, const void* X, const float* mean, const float* rstd,
                              const float* w, const void* dRes, void* dX, float* dw, float* db, int32_t N, int32_t C,
                              void* stream);
-/* Y: Res */
+/* audio, Y: Res */
 int32_t amt_op_stem_fwd(int32_t dtype, const void* audio, const float* w, const float* b, const float* lnw,
                         const float* lnb, void* Y, int32_t B, int32_t T, void* stream);
 int32_t amt_op_stem_bwd(int32_t dtype, const void* audio, const void* dY, const float* w, const float* b,

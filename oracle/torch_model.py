@@ -29,6 +29,16 @@ def to_torch(params, dtype=torch.float64, requires_grad=False):
     return out
 
 
+def round_gemm_weights(params, dtype=torch.bfloat16):
+    """The parameters a reduced-precision context computes with: the operands of its GEMMs (every leaf with >= 2 dims except
+    norms, biases, gamma, the depthwise taps and the stem conv, which the kernels read in fp32) rounded to `dtype`.  For the
+    oracle side of a bf16 comparison, so that it measures the arithmetic and not the rounding of the weights (the reference
+    rounds its weights to fp16 the same way: train.py:54, 273)."""
+    return {k: torch.tensor(v).to(dtype).to(torch.float64).numpy() if v.ndim >= 2 and "norm" not in k
+            and "bias" not in k and "gamma" not in k and "depth_conv" not in k and k != "layers.0.0.conv.weight"
+            else v for k, v in params.items()}
+
+
 def _chan_ln(x, w, b):
     """LayerNorm over channels of (B, C, L)  (model.py:100,117,162,759: vmap over positions)."""
     return F.layer_norm(x.transpose(1, 2), (x.shape[1],), w, b, LN_EPS).transpose(1, 2)
@@ -41,16 +51,16 @@ def _rope(x, cos, sin):
     return torch.stack([x1 * c - x2 * s, x1 * s + x2 * c], dim=-1).flatten(-2)
 
 
-def _sdpa(q, k, v, keep=None, keep_prob=1.0):
+def _no_tap(name, t):
+    return t
+
+
+def _sdpa(q, k, v, keep=None, keep_prob=1.0, tap=_no_tap, tag=""):
     """model.py:241-257.  q,k,v (..., S, hd)."""
     w = torch.softmax((q / math.sqrt(q.shape[-1])) @ k.transpose(-1, -2), dim=-1)
     if keep is not None:
         w = w * keep / keep_prob
-    return w @ v
-
-
-def _no_tap(name, t):
-    return t
+    return tap(tag + "p", w) @ v
 
 
 def _self_attention(lp, x, cos, sin, nh, keep=None, keep_prob=1.0, tap=_no_tap, tag=""):
@@ -61,7 +71,7 @@ def _self_attention(lp, x, cos, sin, nh, keep=None, keep_prob=1.0, tap=_no_tap, 
     c = tap(tag + "c", F.linear(x, lp["Wkvd"]))
     k = tap(tag + "k", _rope(tap(tag + "k_raw", F.linear(c, lp["Wku"])).view(B, S, nh, -1), cos[:S], sin[:S]))
     v = tap(tag + "v", F.linear(c, lp["Wvu"])).view(B, S, nh, -1)
-    o = _sdpa(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), keep, keep_prob)
+    o = _sdpa(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), keep, keep_prob, tap, tag)
     o = tap(tag + "ao", o.transpose(1, 2).reshape(B, S, -1))
     return F.linear(o, lp["Wo"])
 
@@ -132,7 +142,7 @@ def cnn_frontend(p, x, conf=MODEL_CONFIG, tap=_no_tap):
 
 def forward(p, audio, conf=MODEL_CONFIG, rope=None, dropout_masks=None, return_intermediates=False, tap=_no_tap):
     """Batched OutputSequenceGenerator (model.py:740-769 under vmap).  audio (B,2,T).  Tap names of layer l: "tl.{l}.{xn,
-    q_raw,q,c,k_raw,k,v,ao,h,hn,u,g,y}" (local layers: q .. ao are per window); "head.hn"."""
+    q_raw,q,c,k_raw,k,v,p,ao,h,hn,u,g,y}" (p: attention weights after dropout; local layers: q .. ao are per window); "head.hn"."""
     dtype = audio.dtype
     h = cnn_frontend(p, audio, conf, tap)
     inter = {"cnn": h}

@@ -24,10 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import np_model, torch_model  # noqa: E402
 
 
-def bf16_round_gemm_weights(params):   # == tests/util.py (which needs the HIP library to import)
-    return {k: torch.tensor(v).to(torch.bfloat16).to(torch.float64).numpy() if v.ndim >= 2 and "norm" not in k
-            and "bias" not in k and "gamma" not in k and "depth_conv" not in k and k != "layers.0.0.conv.weight"
-            else v for k, v in params.items()}
+bf16_round_gemm_weights = torch_model.round_gemm_weights
 
 
 CLASSES = {
@@ -35,6 +32,7 @@ CLASSES = {
     "tr_ln": lambda n: (n.startswith("tl.") and n.split(".")[2] in ("xn", "hn")) or n == "head.hn",
     "tr_qkv": lambda n: n.startswith("tl.") and n.split(".")[2] in ("q_raw", "q", "c", "k_raw", "k", "v"),
     "tr_ao": lambda n: n.startswith("tl.") and n.split(".")[2] == "ao",
+    "tr_p": lambda n: n.startswith("tl.") and n.split(".")[2] == "p",
     "tr_ffn": lambda n: n.startswith("tl.") and n.split(".")[2] in ("u", "g"),
     "cnn_resid": lambda n: n.startswith("cnn.") and n.endswith(".y"),
     "cnn_branch": lambda n: n.startswith("cnn.") and n.split(".")[-1] in ("ln", "u", "h", "z"),

@@ -63,6 +63,15 @@ def build(name):
     k_attn = [k for k in keys if k.endswith("kv_down_proj.weight")][0]
     out["grad_attn_name"] = np.array(k_attn)
     out["grad_attn"] = (grads[k_attn][:1] if name.startswith("full") else grads[k_attn]).astype(np.float32)
+    # round 4: the same step with the GEMM weights rounded to bf16 (what a bf16 context multiplies with): the comparison
+    # target of the bf16 HIP path, so that its tolerance covers the arithmetic and not the weight rounding (which alone
+    # moves the full-depth logits by ~1e-1)
+    loss_w, logits_w, grads_w = torch_model.loss_and_grads(torch_model.round_gemm_weights(params), audio, labels, conf)
+    out["bf16w.logits"] = logits_w.astype(np.float32)
+    out["bf16w.loss"] = np.float64(loss_w)
+    out["bf16w.grad.layers.0.0.conv.weight"] = grads_w["layers.0.0.conv.weight"].astype(np.float32)
+    out["bf16w.grad.decoder.decoder_pooling.weight"] = grads_w["decoder.decoder_pooling.weight"].astype(np.float32)
+    out["bf16w.grad_attn"] = (grads_w[k_attn][:1] if name.startswith("full") else grads_w[k_attn]).astype(np.float32)
     return out
 
 

@@ -193,6 +193,140 @@ def test_data_parallel_step_four_ranks_equal_one_rank(poison):
         assert np.linalg.norm(outs[0][4] - ref) < 1e-5 * np.linalg.norm(ref)
 
 
+# ------------------------------------------------------------------ the in-place protocol (round 4)
+class _OracleInPlaceBackend:
+    """CPU stand-in for HipTrainBackend(fused=True) over GradBucket.of_model: the backward pass leaves RAW gradient sums
+    (scale * accum_steps * the rank's mean gradient) and the rank's loss in the bucket, DataParallelStep SUM-reduces them in
+    place, and apply() is what amt_adamw_step_reduced evaluates on the device: g = sums * (1 / world) / (scale * steps), the gate
+    isfinite(|update|^2) && isfinite(loss sum), oracle/optim.py's chain behind it, the accumulator left zeroed, the flags
+    published.  The ranges, the reduction and the order of the calls are the production code (DataParallelStep)."""
+    fused = True
+    in_place = True
+    SCALE = 4.0
+
+    def __init__(self, conf, params, audio, labels, bucket, split, poison=False, accum_steps=1):
+        from oracle import optim
+        self.conf, self.audio, self.labels = conf, audio, labels
+        self.bucket, self.split, self.poison, self.accum_steps = bucket, split, poison, accum_steps
+        self.world = 1                       # set by DataParallelStep
+        self.flat = P.equinox_to_flat(params, conf).astype(np.float64)
+        self.chain = optim.AdamWChain(self.flat.size)
+        self.params_np = params
+        self.applied = []
+        self._cache = None
+
+    def _compute(self):
+        k = self.accum_steps
+        mb = self.audio.shape[0] // k
+        loss, raw = 0.0, None
+        for i in range(k):
+            li, _, g = torch_model.loss_and_grads(self.params_np, self.audio[i * mb:(i + 1) * mb], self.labels[i * mb:(i + 1) * mb],
+                                                  self.conf, dtype=torch.float64)
+            fi = torch.from_numpy(P.equinox_to_flat(g, self.conf)).to(torch.float32) * self.SCALE      # the scaled loss's gradient
+            raw = fi if raw is None else raw + fi
+            loss += li
+        if self.poison:
+            raw[self.split + 5] = float("inf")      # a non-finite gradient in the first half's range
+        return float(loss / k), raw
+
+    def full(self, seed):
+        loss, raw = self._compute()
+        self.bucket.grads.add_(raw)                  # the backward pass ADDS into the (clean) accumulator
+        self.bucket.tail[0] = loss
+
+    def half(self, phase, seed):
+        b = self.bucket
+        if phase == 1:
+            self._cache = self._compute()
+            loss, raw = self._cache
+            b.grads[self.split:].add_(raw[self.split:])
+            b.tail[0] = loss
+        else:
+            b.grads[:self.split].add_(self._cache[1][:self.split])
+
+    def discard(self):
+        self.bucket.grads.zero_()
+
+    def advance_seed(self):
+        pass
+
+    def apply(self, step, lr_base):
+        b = self.bucket
+        b.loss_div = float(self.world)
+        g = b.grads.numpy().astype(np.float64) * (1.0 / self.world) / (self.SCALE * self.accum_steps)
+        trial = self.chain.__class__(self.flat.size)
+        trial.mu, trial.nu, trial.count = self.chain.mu.copy(), self.chain.nu.copy(), self.chain.count
+        with np.errstate(all="ignore"):
+            new = trial.update(self.flat, g, lr_base)
+            norm2 = float(np.sum((new - self.flat) ** 2))
+        open_ = bool(np.isfinite(norm2) and np.isfinite(float(b.tail[0])))
+        if open_:
+            self.flat, self.chain = new, trial
+        b.grads.zero_()                              # the commit pass leaves the accumulator zeroed in every case
+        b.head[0] = b.tail[1] = 1.0 if open_ else 0.0
+        self.applied.append(open_)
+
+
+def _inplace_worker(rank, world, port, q, poison, overlap, accum):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    conf = _conf()
+    params = np_model.init_params(conf, seed=3, gamma=1.0)
+    audio, labels = synth.make_batch(4, 320 * 20, seed=9)
+    per = 4 // world
+    shard = slice(rank * per, rank * per + per)
+    bucket = train.GradBucket(P.param_count(conf), "cpu")
+    split = _split_of(conf)
+    be = _OracleInPlaceBackend(conf, params, audio[shard], labels[shard], bucket, split, poison=poison and rank == world - 1,
+                               accum_steps=accum)
+    dp = train.DataParallelStep(be, bucket, split, dist=dist, overlap=overlap, graph=True, lr_base=1e-2)
+    assert dp.in_place and be.world == world
+    dp.prepare(seed=0)
+    assert float(bucket.grads.abs().max()) == 0.0          # the rehearsal's gradients were discarded
+    dp.step()
+    loss, valid = dp.result()
+    q.put((rank, loss, valid, be.applied[-1], be.flat.copy(), float(bucket.grads.abs().max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,overlap,accum", [(2, False, 1), (2, True, 1), (2, False, 2), (4, True, 1)])
+@pytest.mark.parametrize("poison", [False, True])
+def test_in_place_step_n_ranks_equal_one_rank(world, poison, overlap, accum):
+    """The in-place protocol (include/amt.h: amt_grad_bucket / amt_adamw_step_reduced): SUM all-reduce of
+    the raw gradient sums and the loss word on the accumulator itself, 1 / world inside the optimizer, no flag collective.
+    N ranks end with the PARAMETERS one rank reaches on the global batch; an infinite gradient on one rank closes the gate
+    on every rank through the reduced sum alone; the accumulator is left zeroed either way."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_inplace_worker, args=(r, world, port, q, poison, overlap, accum)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in range(world)], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle import optim
+    conf = _conf()
+    params = np_model.init_params(conf, seed=3, gamma=1.0)
+    audio, labels = synth.make_batch(4, 320 * 20, seed=9)
+    ref_loss, _, g = torch_model.loss_and_grads(params, audio, labels, conf)
+    flat0 = P.equinox_to_flat(params, conf).astype(np.float64)
+    ref_new = optim.AdamWChain(flat0.size).update(flat0, P.equinox_to_flat(g, conf).astype(np.float64), 1e-2)
+    for rank, loss, valid, applied, flat, gmax in outs:
+        assert valid == (not poison) and applied == (not poison), (rank, valid, applied)
+        assert abs(loss - ref_loss) < 1e-5 * abs(ref_loss)
+        assert gmax == 0.0
+        if poison:
+            assert np.array_equal(flat, flat0)                       # skipped on EVERY rank
+        else:
+            assert np.linalg.norm(flat - ref_new) < 1e-5 * np.linalg.norm(ref_new - flat0), rank
+            assert np.array_equal(flat, outs[0][4])                  # replicas stay bit-identical
+
+
 def test_grad_bucket_layout_and_single_rank_step():
     b = train.GradBucket(10, "cpu")
     assert b.buf.numel() == 16 and b.grads.data_ptr() == b.buf.data_ptr() + 16

@@ -44,14 +44,12 @@ def test_reduced_model_forward_backward(small_conf, dtype, S):
                                return_logits=True)
     assert out.grads_valid
     if dtype == "bfloat16":   # the oracle sees the same bf16-rounded parameters the device computes with
-        params = {k: torch.tensor(v).to(torch.bfloat16).to(torch.float64).numpy() if v.ndim >= 2 and "norm" not in k
-                  and "bias" not in k and "gamma" not in k and "depth_conv" not in k and k != "layers.0.0.conv.weight"
-                  else v for k, v in params.items()}
+        params = torch_model.round_gemm_weights(params)
     loss_ref, logits_ref, grads_ref = torch_model.loss_and_grads(params, audio, labels, conf)
     logits = out.logits.cpu().numpy()
     assert np.array_equal(logits, logits_p.cpu().numpy())
     assert np.allclose(probs_p.cpu().numpy(), 1 / (1 + np.exp(-logits)), atol=1e-6)
-    tol_logit, tol_loss, tol_grad = (2e-4, 1e-5, 2e-3) if dtype == "float32" else (6e-2, 1e-2, 8e-2)
+    tol_logit, tol_loss, tol_grad = (2e-4, 1e-5, 2e-3) if dtype == "float32" else (3e-2, 1e-3, 4e-2)
     err = np.abs(logits - logits_ref).max()
     assert err <= tol_logit, f"logits max abs err {err}"
     assert abs(out.loss - loss_ref) <= tol_loss * abs(loss_ref), (out.loss, loss_ref)
@@ -110,11 +108,12 @@ def test_full_model_forward_5s(dtype):
     model = amt.OutputSequenceGenerator(conf, dtype=dtype)
     model.load_equinox_params(params)
     logits, probs = model.predict(None, torch.from_numpy(audio))
-    pt = torch_model.to_torch(params, torch.float64)
+    # (bf16: the oracle multiplies with the bf16-rounded GEMM weights the context multiplies with)
+    pt = torch_model.to_torch(params if dtype == "float32" else torch_model.round_gemm_weights(params), torch.float64)
     ref, _ = torch_model.forward(pt, torch.from_numpy(audio).double(), conf)
     err = np.abs(logits.cpu().numpy() - ref.numpy()).max()
     assert logits.shape == (1, 250, 90)
-    assert err <= (5e-4 if dtype == "float32" else 1.5e-1), err
+    assert err <= (5e-4 if dtype == "float32" else 3e-2), err      # 1e-4 (5 s: 5e-4 asserted) / 3e-2
 
 
 def test_size_independent_properties_at_bench_size():
@@ -284,6 +283,9 @@ def test_two_phase_step_equals_one_call(small_conf):
     g = torch.full((model.n_params,), 3.0, dtype=torch.float32, device="cuda")
     loss = torch.zeros(2, device="cuda")
     valid = torch.zeros(1, dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):       # the phase entry point converts nothing: bf16 samples are not its input type
+        model.loss_and_grads_phase(1, a, y, g, loss, valid, seed=11, train=True)
+    a = a.to(model.audio_dtype)
     model.loss_and_grads_phase(1, a, y, g, loss, valid, seed=11, train=True)
     torch.cuda.synchronize()
     assert float((g[:split] - 3.0).abs().max()) == 0.0       # phase 2 writes this range

@@ -211,7 +211,7 @@ def test_stem(dtype):
     a = rounded(rng.standard_normal((B, 2, T)), dtype)
     w = (rng.standard_normal((4, 2, 5)) * 0.3).astype(np.float32); b = rng.standard_normal(4).astype(np.float32)
     lw = rng.standard_normal(4).astype(np.float32); lb = rng.standard_normal(4).astype(np.float32)
-    ad = dev(a, dtype)
+    ad = dev_res(a, dtype)                                               # the audio has the residual stream's storage type
     Y = torch.zeros((B, L, 4), device="cuda", dtype=RES_TD[dtype])      # the Stem's output starts the residual stream
     call("amt_op_stem_fwd", DT[dtype], P(ad), P(f32(w)), P(f32(b)), P(f32(lw)), P(f32(lb)), P(Y), B, T, stream())
     tw = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (w, b, lw, lb)]

@@ -35,9 +35,9 @@ from oracle import np_model, post as opost, torch_model  # noqa: E402
 from util import bf16_round_gemm_weights, dropout_masks_for  # noqa: E402
 
 #            |dlogit|  loss rel  whole-gradient rel-L2  per-leaf rel-L2 (leaves with norm > 1e-3 of the largest)
-TOL = {"float32": (2e-5, 1e-6, 2e-6, 2e-5),
-       "bfloat16": (5e-2, 1e-3, 3e-3, 6e-2)}
 SURVEY_BF16_LOGIT_TOL = 3e-2
+TOL = {"float32": (2e-5, 1e-6, 2e-6, 2e-5),
+       "bfloat16": (SURVEY_BF16_LOGIT_TOL, 1e-3, 2e-3, 4e-2)}
 
 
 def _compare(model, out, loss_ref, logits_ref, grads_ref, dtype):
@@ -91,7 +91,7 @@ def test_full_depth_10s_inference_meets_the_survey_tolerance_with_the_reference_
     pt = torch_model.to_torch(bf16_round_gemm_weights(params), torch.float64)
     ref, _ = torch_model.forward(pt, torch.from_numpy(audio).double(), conf)
     err = float(np.abs(logits.cpu().numpy() - ref.numpy()).max())
-    assert err <= SURVEY_BF16_LOGIT_TOL * 1.05, err      # 5 % headroom over the measured 2.9e-2: this IS the survey's bound
+    assert err <= SURVEY_BF16_LOGIT_TOL, err
 
 
 def test_production_qkv_backward_tile_is_pinned_in_fp32(small_conf, monkeypatch):

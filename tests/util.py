@@ -125,10 +125,6 @@ def dropout_masks_for(seed, conf, B, S, n_heads=4):
 
 
 def bf16_round_gemm_weights(params):
-    """The parameters a bf16 context computes with: GEMM weights (2-D and higher, except norms, biases, gamma, the
-    depthwise taps and the stem conv, which the kernels read in fp32) rounded to bf16; for the oracle side of a bf16
-    comparison, so that the comparison measures the arithmetic and not the weight rounding."""
-    import torch
-    return {k: torch.tensor(v).to(torch.bfloat16).to(torch.float64).numpy() if v.ndim >= 2 and "norm" not in k
-            and "bias" not in k and "gamma" not in k and "depth_conv" not in k and k != "layers.0.0.conv.weight"
-            else v for k, v in params.items()}
+    """The parameters a bf16 context computes with (oracle/torch_model.py: round_gemm_weights)."""
+    from oracle import torch_model
+    return torch_model.round_gemm_weights(params)
