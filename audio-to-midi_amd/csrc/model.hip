@@ -337,6 +337,11 @@ struct amt_ctx {
   float* amax = nullptr;        // [layers][prev q,k,v,- | cur q,k,v,-]: delayed per-tensor scaling state
   uint64_t* seed_word = nullptr;   // device word added to every dropout seed (amt_seed_word / amt_advance_seed)
   TeamState* team = nullptr;    // XCD-team protocol words (team.h); null: team launches disabled (AMT_TEAM=0)
+  // run_backward phase 3 ("first half complete" published on the device): the counter, the polling kernel's give-up count,
+  // and the host's bookkeeping of the value the next wait expects
+  unsigned* half_sig = nullptr;
+  unsigned* half_timeouts = nullptr;
+  uint32_t half_base = 0, half_waits = 0;
   int cnn_late_max_c = 0;       // AMT_CNN_WGRAD_LATE=C: weight gradients of the CNN stages with <= C channels as one batch of launches after the pass (1 = all)
   bool fuse_ffn = true;         // AMT_FUSE_FFN=0: second half of a layer as chain + two tiled GEMM launches
   bool lr_idx_ok = false;       // lr_idx / lr_tab describe lr_scale (fewer than 255 depths)
@@ -734,7 +739,35 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
 __global__ void advance_seed_kernel(uint64_t* p, uint64_t delta) { *p += delta; }
 
+// ---- "first half complete" as a DEVICE-SIDE signal (run_backward phase 3; include/amt.h: amt_first_half_wait)
+// The overlapped data-parallel step wants its first collective to start when the gradients of [fn_w, n) are complete, in
+// the MIDDLE of the backward pass.  Cutting the pass into two host calls (phases 1 / 2) costs two graph launches, a flush
+// launch for the riders that would have travelled on the first CNN Block chain and the cross-stream hand-shakes: 0.12 ms
+// per step at cfg2 with no collective at all (profiles/r04_notes.md); external event-record nodes are "disallowed in
+// rocm" (torch 2.10) and a captured RCCL call aborts its watchdog.  So the one-call launch sequence stays ONE graph and
+// one of its nodes publishes a counter; a one-wave kernel on the communication stream polls it (bounded) in front of the
+// collective.  MEASURED (scratch/overlap_cost.py, profiles/r04_notes.md): the signalled graph itself costs +8 us per step,
+// but a kernel RESIDENT on a second queue costs the main queue 0.14 ms per step (every one of its ~200 dependent launches
+// gets a little slower while another queue is active) - as much as the two-call form's split; and the stream operation
+// made for this (hipStreamWaitValue32 on HSA signal memory: the command processor polls, no wave) made the step 4.4 ms
+// instead of 3.0.  The two-call form therefore stays the default and this one an opt-in (DataParallelStep(signal=True)).
+__global__ void half_signal_kernel(unsigned* sig, const float* loss_acc, float* tail_loss, float loss_mul) {
+  if (tail_loss != nullptr) tail_loss[0] = loss_acc[0] * loss_mul;      // the rank's loss travels with the first range
+  __threadfence_system();
+  __hip_atomic_fetch_add(sig, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void half_wait_kernel(const unsigned* sig, unsigned target, unsigned max_polls, unsigned* timeouts) {
+  unsigned polls = 0;
+  while ((int)(__hip_atomic_load(sig, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - target) < 0) {
+    __builtin_amdgcn_s_sleep(32);
+    if (++polls > max_polls) { __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+  }
+}
+
 // ------------------------------------------------------------------------------------ backward
+// phase 3: the whole backward pass (the launches of phase 0) plus, right behind the first CNN Block chain - which carries the
+// last riders of the range [L.fn_w, n_params) - the record sums of that range and a one-thread kernel that publishes "first
+// half complete" on the device (half_signal_kernel); fused protocol only (grads_out == nullptr).
 // phase 0: the whole backward pass.  phase 1 / 2: its two halves for the overlapped data-parallel step —
 // 1 = loss, decoder, transformer and final CNN LayerNorm (their gradients = the flat range
 // [L.fn_w, n_params), complete and unscaled when the call returns), 2 = the CNN stages (range [0, L.fn_w)).
@@ -1084,6 +1117,18 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     return 0;
   }
   if (phase == 2) { live = true; sink.dry = dry || A.overflow; deferred.clear(); }   // phase 1 ran the deferred problems itself (none of them takes sink records)
+  bool signalled = phase != 3;
+  auto signal_first_half = [&]() {     // phase 3: every launch that adds to [L.fn_w, n_params) has been issued
+    // (called right behind the first CNN Block's launch and BEFORE its end_scope: the riders of the last transformer scopes
+    // have travelled on that launch - or were flushed when the scope began - and the Block's own weight gradients, still
+    // pending, belong to the second range)
+    if (signalled) return;
+    signalled = true;
+    RUN(reduce_partials(s, c->part_desc_dev, c->n_part_desc_half, c->partials, grads));
+    if (acc_last)
+      RUN(hipLaunchKernelGGL(half_signal_kernel, dim3(1), dim3(1), 0, s, c->half_sig, c->loss_acc, grads + L.n_params,
+                             1.f / (float)acc_count));
+  };
   // CNN stages, last to first
   auto late_for = [&](int si) { return si >= 0 && !side_on && L.stages[si].C <= c->cnn_late_max_c; };
   int Lcur = S;
@@ -1113,6 +1158,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
         sa.B = B; sa.L = Lcur; sa.C = C;
         block_small_bwd_full(s, dt, sa, &sink);
         dcur = dx;
+        signal_first_half();
         end_scope();
         continue;
       }
@@ -1134,6 +1180,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
                         deferred.data(), (int)deferred.size());
         deferred.clear();
         dcur = dx;
+        signal_first_half();
         end_scope();
         continue;
       }
@@ -1153,6 +1200,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       dwblock_bwd(s, dt, dln, bs.x, dy, bs.z, c->P(bp.dw_w), c->P(bp.dw_b), bs.mean, bs.rstd, c->P(bp.ln_w), dx,
                   G(bp.ln_w), G(bp.ln_b), G(bp.dw_w), G(bp.dw_b), G(bp.gamma), B, Lcur, C, &sink);
       dcur = dx;
+      signal_first_half();
       end_scope();
     }
     if (si > 0) {
@@ -1177,6 +1225,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     }
   }
   flush_deferred();
+  signal_first_half();     // (a model without Blocks)
   late_mode = false;
   {   // the CNN weight gradients, 8 problems per launch, many token splits (the launches are large and independent)
     static const int late_target = getenv("AMT_LATE_WGRAD_WGS") ? atoi(getenv("AMT_LATE_WGRAD_WGS")) : 1024;
@@ -1194,7 +1243,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   }
   if (dry && scratch_used > c->scratch_max) c->scratch_max = scratch_used;
   c->part_total = sink.off;
-  if (phase == 2) {
+  if (phase == 2 || phase == 3) {
     RUN(reduce_partials(s, c->part_desc_dev + c->n_part_desc_half, c->n_part_desc - c->n_part_desc_half, c->partials, grads));
     if (acc_last && grads_out != nullptr) RUN(grads_finalize(s, grads, grads_out, L.fn_w, out_mul, grads_valid));
   } else {
@@ -1470,7 +1519,13 @@ void amt_destroy(amt_ctx* c) {
   (void)hipSetDevice(c->device);
   void* ptrs[] = {c->params, c->wc, c->head_bias, c->conv_dev, c->conv_prefix_dev, c->rope_cos, c->rope_sin,
                   c->arena.base, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, c->norm2, c->loss_acc,
-                  c->partials, c->amax, c->gacc, c->team, c->seed_word, c->lr_idx, c->lr_tab};
+                  c->partials, c->amax, c->gacc, c->team, c->seed_word, c->lr_idx, c->lr_tab, c->half_timeouts};
+  if (c->half_sig) {      // release whatever may still wait on the counter, then free it
+    const unsigned big = 0x7fffffffu;
+    (void)hipMemcpy(c->half_sig, &big, sizeof(big), hipMemcpyHostToDevice);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(c->half_sig);
+  }
   for (const amt_ctx::PlanRec& r : c->plans)
     if (r.desc_dev) (void)hipFree(r.desc_dev);
   for (void* p : ptrs)
@@ -1543,7 +1598,16 @@ int32_t amt_forward_backward_accum(amt_ctx* c, const void* audio, const float* l
                                    uint64_t seed, int32_t train, float* loss_out, float* grads_flat, int32_t* grads_valid,
                                    float* logits, int32_t phase, int32_t accum_index, int32_t accum_count, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (phase < 0 || phase > 2) { c->err = "phase must be 0 (whole step), 1 or 2"; return 1; }
+  if (phase < 0 || phase > 3) { c->err = "phase must be 0 (whole step), 1, 2 or 3 (whole step + first-half signal)"; return 1; }
+  if (phase == 3 && c->use_side) { c->err = "phase 3 (first-half signal) is not available with AMT_SIDE_STREAM"; return 1; }
+  if (phase == 3 && grads_flat != nullptr) { c->err = "phase 3 (first-half signal) belongs to the fused protocol: grads_flat must be NULL"; return 1; }
+  if (phase == 3 && c->half_sig == nullptr) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->half_sig), 8));
+    HIPCHK(c, hipMemset(c->half_sig, 0, 8));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->half_timeouts), sizeof(unsigned)));
+    HIPCHK(c, hipMemset(c->half_timeouts, 0, sizeof(unsigned)));
+    HIPCHK(c, hipDeviceSynchronize());
+  }
   if (accum_count < 1 || accum_index < 0 || accum_index >= accum_count) { c->err = "accum_index must be in [0, accum_count)"; return 1; }
   if (check_shape(c, B, T)) return 1;
   if (!(scale > 0.f)) { c->err = "scale must be positive"; return 1; }
@@ -1758,6 +1822,33 @@ float* amt_grad_bucket(amt_ctx* c, uint64_t* head, uint64_t* n, uint64_t* tail) 
   if (n) *n = c->L.n_params;
   if (tail) *tail = 2;
   return c->gacc + c->gacc_pad - 4;
+}
+
+int32_t amt_first_half_wait(amt_ctx* c, void* stream) {
+  if (c->half_sig == nullptr) { c->err = "amt_first_half_wait: no phase-3 step has been issued on this context"; return 1; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const uint32_t target = c->half_base + ++c->half_waits;      // the k-th wait since the last sync consumes the k-th signal
+  hipLaunchKernelGGL(half_wait_kernel, dim3(1), dim3(1), 0, s, c->half_sig, target, 1u << 22, c->half_timeouts);   // ~2-4 s
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { c->err = std::string("amt_first_half_wait: ") + hipGetErrorString(e); return 1; }
+  return 0;
+}
+
+int32_t amt_first_half_sync(amt_ctx* c, void* stream) {
+  if (c->half_sig == nullptr) return 0;
+  HIPCHK(c, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  uint32_t v = 0;
+  HIPCHK(c, hipMemcpy(&v, c->half_sig, sizeof(v), hipMemcpyDeviceToHost));
+  c->half_base = v;
+  c->half_waits = 0;
+  return 0;
+}
+
+int32_t amt_first_half_status(amt_ctx* c) {
+  if (c->half_timeouts == nullptr) return 0;
+  unsigned w = 0;
+  if (hipMemcpy(&w, c->half_timeouts, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int32_t)w;
 }
 
 int32_t amt_optimizer_status(amt_ctx* c) {

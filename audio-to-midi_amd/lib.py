@@ -107,6 +107,9 @@ SIGNATURES = {
     "amt_optimizer_count": (_i32, [_vp]),
     "amt_grad_accumulator_reset": (_i32, [_vp, _vp]),
     "amt_optimizer_status": (_i32, [_vp]),
+    "amt_first_half_wait": (_i32, [_vp, _vp]),
+    "amt_first_half_sync": (_i32, [_vp, _vp]),
+    "amt_first_half_status": (_i32, [_vp]),
     "amt_grad_bucket": (_vp, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "amt_adamw_step_reduced": (_i32, [_vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp, _vp, _vp]),
     "amt_profile_begin": (None, []),

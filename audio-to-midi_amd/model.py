@@ -258,8 +258,10 @@ class OutputSequenceGenerator:
                              valid_out: torch.Tensor, scale: float = 1.0, seed: int = 0, train: bool = True, accum=(0, 1)):
         """Asynchronous half of ``loss_and_grads`` (include/amt.h: amt_forward_backward_phase).  All tensors are
         caller-owned device tensors (audio in ``model.audio_dtype``, labels fp32); nothing is synchronised."""
-        if int(phase) not in (1, 2):
-            raise RuntimeError("amt_forward_backward_phase failed: phase must be 1 or 2")
+        if int(phase) not in (1, 2, 3):
+            raise RuntimeError("amt_forward_backward_phase failed: phase must be 1, 2 or 3")
+        if int(phase) == 3 and grads_out is not None:
+            raise ValueError("phase 3 (whole step + first-half signal) belongs to the fused protocol: grads_out must be None")
         if audio.dtype != self.audio_dtype or not audio.is_cuda or not audio.is_contiguous():
             raise ValueError(f"audio must be a contiguous device tensor of dtype {self.audio_dtype} (model.audio_dtype): "
                              "this entry point converts nothing")
@@ -318,6 +320,20 @@ class OutputSequenceGenerator:
             raise RuntimeError("amt_grad_bucket returned NULL")
         total = int(h.value + n.value + t.value)
         return _DevView(ptr, total, self.device).tensor(), int(h.value), int(n.value), int(t.value)
+
+    def first_half_wait(self, stream: Optional[torch.cuda.Stream] = None):
+        """Enqueue, on ``stream`` (default: the current one - make it the communication stream), the kernel that waits for
+        the "first half complete" signal of a ``loss_and_grads_phase(3, ...)`` step (include/amt.h: amt_first_half_wait)."""
+        st = C.c_void_p((stream or torch.cuda.current_stream(self.device)).cuda_stream)
+        self._check(self._L.amt_first_half_wait(self._h, st), "amt_first_half_wait")
+
+    def first_half_sync(self):
+        """Declare every first-half signal published so far as consumed (after unpaired rehearsal steps)."""
+        self._check(self._L.amt_first_half_sync(self._h, self._stream()), "amt_first_half_sync")
+
+    def first_half_status(self) -> int:
+        """Number of first-half waits that gave up (0 in normal operation; synchronises)."""
+        return int(self._L.amt_first_half_status(self._h))
 
     def optimizer_status(self) -> int:
         """Optimizer steps lost to a barrier time-out of the one-launch form (include/amt.h: amt_optimizer_status)."""

@@ -184,6 +184,26 @@ class HipTrainBackend:
         else:
             self.model.pack_tail(self.loss_buf, self.valid_buf, head_valid=b.head[0:1])
 
+    def full_signal(self, seed: int):
+        """The whole step as ONE launch sequence that publishes "first half complete" on the device behind the first CNN
+        Block chain (include/amt.h: amt_first_half_wait): the overlapped form without cutting the step in two host calls.
+        In-place protocol only; the library writes the rank's loss into the bucket's tail in front of the signal."""
+        if not self.in_place:
+            raise RuntimeError("full_signal needs the in-place protocol (fused=True over GradBucket.of_model)")
+        k = self.accum_steps
+        for i, (a, y) in enumerate(self._mb[:-1]):
+            self.model.loss_and_grads(a, y, scale=self.scale, seed=seed, train=True, grads_out=None, sync=False,
+                                      accum=(i, k), loss_out=self.loss_buf, valid_out=self.valid_buf, fused_optimizer=True)
+        a, y = self._mb[-1]
+        self.model.loss_and_grads_phase(3, a, y, None, self.loss_buf, self.valid_buf, scale=self.scale, seed=seed, train=True,
+                                        accum=(k - 1, k))
+
+    def wait_first_half(self, stream):
+        self.model.first_half_wait(stream)
+
+    def sync_signals(self):
+        self.model.first_half_sync()
+
     def advance_seed(self):
         self.model.advance_seed(1)      # one key per step (train.py:274), whatever the number of minibatches
 
@@ -216,17 +236,18 @@ class HipTrainBackend:
 class DataParallelStep:
     """One optimizer step of the data-parallel loop (train.py:259-332 with the GSPMD all-reduce made explicit).
 
-    ``overlap=True``: the step runs in two halves (amt_forward_backward_phase); the collective of the range the
-    first half completes (37 of the 46 MB at the reference configuration, with the loss and the first flag behind
-    it) runs on a side stream while the second half (CNN backward) executes, the rest follows on the main stream:
-    two collectives per step.  ``overlap=False``: one collective over the whole bucket after the backward pass.
+    ``overlap=True``: the collective of the range the first half of the backward pass completes (37 of the 46 MB at the
+    reference configuration, with the loss behind it) runs on a side stream while the CNN backward executes, the rest
+    follows on the main stream: two collectives per step.  The step runs in two host calls (amt_forward_backward_phase);
+    ``signal=True`` (in-place protocol, GPU) keeps it ONE launch sequence that signals the first half's completion on the
+    device instead (include/amt.h: amt_first_half_wait; measured no faster).  ``overlap=False``: one collective over the whole bucket after the backward pass.
     The reduction is a MEAN over ranks: ``ReduceOp.AVG`` where the backend has it (RCCL), SUM followed by a scale
     of the same range otherwise (gloo).  On CUDA/HIP devices the per-rank work is captured into hipGraphs unless
     ``graph=False``; the dropout seed of a replay is ``seed + seed_word`` with the device word advanced inside the
     graph, so replays draw fresh masks."""
 
     def __init__(self, backend, bucket: GradBucket, split: int, dist=None, overlap: bool = False, graph: bool = True,
-                 lr_base: float = 1e-4):
+                 lr_base: float = 1e-4, signal: Optional[bool] = None):
         self.backend, self.bucket, self.split, self.dist = backend, bucket, int(split), dist
         self.world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
         # in-place protocol (HipTrainBackend(fused=True) over GradBucket.of_model): the collectives are SUMs over the
@@ -234,6 +255,13 @@ class DataParallelStep:
         self.in_place = bool(getattr(backend, "in_place", False))
         if hasattr(backend, "world"):
             backend.world = self.world
+        # overlap without splitting the step: one launch sequence + a device-side signal (HipTrainBackend.full_signal)
+        # opt-in (signal=True): measured no faster than the two-call form - a kernel resident on the communication queue
+        # slows the main queue's ~200 dependent launches by as much as the split costs (include/amt.h, profiles/r04_notes.md)
+        can_signal = bool(overlap) and self.in_place and hasattr(backend, "full_signal") and bucket.buf.is_cuda
+        if signal and not can_signal:
+            raise ValueError("the signalled overlap form needs overlap=True and the in-place protocol on a GPU")
+        self.signal = bool(signal)
         if getattr(backend, "fused", False) and self.world > 1 and not self.in_place:
             raise ValueError("more than one rank with the fused optimizer needs the model's own bucket: GradBucket.of_model(model)")
         # the optimizer gate tests the MEAN of the ranks' 0/1 flags against 0.999 (csrc/head.hip: adamw_gate_open): one
@@ -290,7 +318,11 @@ class DataParallelStep:
         discard = getattr(be, "discard", lambda: None)      # fused protocol: rehearsal gradients must not reach the optimizer
         be.full(seed)
         discard()
-        if self.overlap:
+        if self.signal:
+            be.full_signal(seed)
+            discard()
+            be.sync_signals()      # the rehearsal's signal has no wait: declared consumed
+        elif self.overlap:
             be.half(1, seed); be.half(2, seed)
             discard()
         if self.cuda:
@@ -302,11 +334,21 @@ class DataParallelStep:
         with torch.cuda.stream(side):          # warm-up on a side stream, as torch's capture rules want
             be.full(seed)
             discard()
-            if self.overlap:
+            if self.signal:
+                be.full_signal(seed)
+                discard()
+                be.sync_signals()
+            elif self.overlap:
                 be.half(1, seed); be.half(2, seed)
                 discard()
         torch.cuda.current_stream().wait_stream(side)
-        if self.overlap:
+        if self.signal:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                be.advance_seed()
+                be.full_signal(seed)
+            self._graphs = (g,)
+        elif self.overlap:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga):
                 be.advance_seed()
@@ -335,7 +377,20 @@ class DataParallelStep:
         be, b = self.backend, self.bucket
         seed = self.step_no if seed is None else seed
         self._check_generation()
-        if self.overlap:
+        if self.signal:
+            # ONE graph (the single-rank step's launch sequence); the communication stream waits ON THE DEVICE for the
+            # signal the graph publishes behind its first CNN Block chain, then reduces [split, n) + loss while the CNN
+            # backward runs; the CNN range follows on the main stream
+            if self._graphs is not None:
+                self._graphs[0].replay()
+            else:
+                be.full_signal(seed)
+            with torch.cuda.stream(self._comm):
+                be.wait_first_half(self._comm)
+                self._mean_allreduce(self._first_range())
+            self._mean_allreduce(self._second_range())
+            torch.cuda.current_stream().wait_stream(self._comm)
+        elif self.overlap:
             if self._graphs is not None:
                 self._graphs[0].replay()
             else:

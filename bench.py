@@ -316,6 +316,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: one all-reduce after the whole backward pass instead of the two-bucket overlap")
     ap.add_argument("--force-overlap", action="store_true", help="use the two-phase step even at N = 1 (testing)")
+    ap.add_argument("--signal", action="store_true",
+                    help="overlap as ONE launch sequence with a device-side first-half signal (amt_first_half_wait) instead of "
+                         "two host calls / two graphs (amt_forward_backward_phase); measured no faster")
     ap.add_argument("--workload", choices=["train", "infer"], default="train",
                     help="train = BASELINE configs[1] (default, the headline metric); infer = configs[3]: streaming "
                          "inference, 32 x 60 s clips -> 448 windows of 5 s, forward + stitch (reported, not the headline)")
@@ -379,7 +382,9 @@ def main():
     # stages are still in their backward pass; the CNN range, preceded by the whole step's finite flag, follows:
     # two collectives per step.  Per-GPU work is identical to the one-call step.
     overlap = (world > 1 and not args.no_overlap) or args.force_overlap
-    if overlap and dist is None:
+    if overlap and dist is None and os.environ.get("AMT_BENCH_NO_PG"):
+        pass      # diagnostic: the two-phase per-rank program with NO collective calls at all (what the split itself costs)
+    elif overlap and dist is None:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -388,7 +393,7 @@ def main():
     # finite check and the clip are all still computed, train.py:319-325)
     backend = amt_train.HipTrainBackend(model, audio, labels, bucket, scale=1.0, use_optimizer=not args.no_optimizer, fused=fused)
     dp = amt_train.DataParallelStep(backend, bucket, backend.split, dist=dist, overlap=overlap, graph=not args.no_graph,
-                                    lr_base=1e-4)
+                                    lr_base=1e-4, signal=args.signal)
     dp.prepare(seed=12345)       # every allocation (optimizer state, workspace plan) happens before graph capture
     graph = dp._graphs
 
@@ -464,7 +469,7 @@ def main():
                                    + ("" if args.no_optimizer else ", AdamW + global-norm clip + bf16 weight refresh"),
                        "global_batch": world * B_PER_GPU, "clip_seconds": CLIP_SECONDS, "frames": T_SAMPLES // 320,
                        "parallelism": f"dp{world}", "hipgraph": graph is not None,
-                       "grad_allreduce": (("two collectives, the first overlapped with the CNN backward" if overlap else "one bucket")
+                       "grad_allreduce": ((("two collectives, the first overlapped with the CNN backward" + (" behind a device-side signal of ONE launch sequence" if dp.signal else " (step cut in two host calls)")) if overlap else "one bucket")
                                           + (" (SUM, in place on the context's accumulator; 1 / world in the optimizer)" if fused else " (ReduceOp.AVG on a separate bucket)")) if world > 1 or overlap else None,
                        "optimizer": None if args.no_optimizer else ("fused: norm pass + commit pass over the context's gradient accumulator" if fused else "grads_finalize + adamw_compute + adamw_apply over the bucket"),
                        "weights": "random init (Equinox distributions), 11606230 params"},

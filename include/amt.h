@@ -141,7 +141,8 @@ uint64_t amt_grad_bucket_split(const amt_ctx* ctx);
 
 /* Gradient accumulation over minibatches on the device (train.py:275-310: lax.scan over batch / minibatch chunks, fp32
  * accumulation, grads / (grad_scale * steps), train.py:319): the general form of the two entry points above.
- *   phase        0 = whole step, 1 / 2 = its halves (as amt_forward_backward_phase)
+ *   phase        0 = whole step, 1 / 2 = its halves (as amt_forward_backward_phase), 3 = whole step + first-half signal
+ *                (fused protocol only, see amt_first_half_wait)
  *   accum_index  0 .. accum_count - 1, in order, same grads_flat / grads_valid / loss_out pointers in every call
  * Call 0 zeroes the context's fp32 accumulator; every call adds its gradients to it (no second buffer, no extra pass);
  * only the last call writes grads_flat = accumulator / (scale * accum_count), loss_out = mean over the minibatches of
@@ -252,6 +253,25 @@ int32_t amt_optimizer_status(amt_ctx* ctx);
  * step plus the collectives: the N > 1 rank runs the program the N = 1 benchmark times.  valid_out: device int32, 1 iff
  * the update was applied (the same on every rank). */
 float* amt_grad_bucket(amt_ctx* ctx, uint64_t* head, uint64_t* n, uint64_t* tail);
+/* Overlapping the first collective with the CNN backward WITHOUT cutting the step in two host calls.
+ * amt_forward_backward_accum(phase = 3, grads_flat = NULL) issues the launches of the one-call step (phase 0) plus - right
+ * behind the first CNN Block chain, which carries the last weight-gradient riders of the range [amt_grad_bucket_split, n) -
+ * the record sums of that range and a one-thread kernel that writes the rank's loss into tail[0] of the bucket and
+ * publishes "first half complete" in a device counter.  amt_first_half_wait enqueues a one-wave kernel on ANOTHER stream
+ * (the communication stream) that polls that counter for the next unconsumed signal (bounded: ~2-4 s, then it gives up
+ * and counts a time-out); the collective of [split, n) + tail[0] goes behind it.  The step stays ONE hipGraph whose node
+ * sequence is the single-rank step's (+8 us).  MEASURED on one MI355X with no collective at all (profiles/r04_notes.md): a
+ * kernel resident on a second queue slows the ~200 dependent launches of the main queue by 0.14 ms per step, as much as
+ * the two-call form (phases 1 / 2: two graph launches, a flush launch) costs, and hipStreamWaitValue32 on signal memory in
+ * its place made the step 4.4 ms instead of 3.0 (torch 2.10 on ROCm refuses external event-record nodes in a capture and a
+ * captured RCCL call aborts its watchdog, so those forms are not available).  Hence an OPT-IN; the two-call form is what
+ * DataParallelStep takes by default.  Every phase-3 step must be paired with exactly one amt_first_half_wait, issued after
+ * it in host order; amt_first_half_sync (host-synchronous on the step's stream) declares every signal published so far as
+ * consumed: call it after warm-up / rehearsal steps that were not paired with a wait.  amt_first_half_status: waits that
+ * gave up (host-synchronous). */
+int32_t amt_first_half_wait(amt_ctx* ctx, void* stream);
+int32_t amt_first_half_sync(amt_ctx* ctx, void* stream);
+int32_t amt_first_half_status(amt_ctx* ctx);
 int32_t amt_adamw_step_reduced(amt_ctx* ctx, float lr_base, float layer_lr_decay, float b1, float b2, float eps,
                                float weight_decay, float clip_norm, int32_t step, float grad_mul, const float* loss_sum,
                                int32_t* valid_out, void* stream);

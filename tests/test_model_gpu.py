@@ -296,6 +296,8 @@ def test_two_phase_step_equals_one_call(small_conf):
     assert float((g - ref.grads_flat).norm() / ref.grads_flat.norm()) < 1e-5
     assert int(valid.item()) == 1
     with pytest.raises(RuntimeError):
+        model.loss_and_grads_phase(4, a, y, g, loss, valid)
+    with pytest.raises(ValueError):       # phase 3 (whole step + first-half signal) is the fused protocol's: no caller buffer
         model.loss_and_grads_phase(3, a, y, g, loss, valid)
 
 

@@ -254,31 +254,34 @@ def test_in_place_protocol_on_the_models_own_bucket(small_conf):
     protocol (separate bucket, unscale pass, three-pass optimizer) on a twin model; accumulation over two minibatches."""
     audio, labels = synth.make_batch(4, 320 * 48, seed=4)
     outs = {}
-    for mode in ("legacy", "inplace", "inplace-overlap", "inplace-accum2"):
+    for mode in ("legacy", "inplace", "inplace-overlap", "inplace-signal-overlap", "inplace-signal-accum2-overlap", "inplace-accum2"):
         model = amt.OutputSequenceGenerator(small_conf, key=8, dtype="float32", gamma=1.0)
         a, y = torch.from_numpy(audio).cuda(), torch.from_numpy(labels).cuda()
         inplace = mode != "legacy"
         bucket = train.GradBucket.of_model(model) if inplace else train.GradBucket(model.n_params, "cuda")
-        be = train.HipTrainBackend(model, a, y, bucket, fused=inplace, accum_steps=2 if mode.endswith("accum2") else 1)
+        be = train.HipTrainBackend(model, a, y, bucket, fused=inplace, accum_steps=2 if "accum2" in mode else 1)
         assert be.in_place == inplace
-        dp = train.DataParallelStep(be, bucket, be.split, dist=None, overlap=mode.endswith("overlap"), graph=True, lr_base=1e-3)
-        assert dp.in_place == inplace
+        # "signal": ONE launch sequence + the device-side first-half signal (amt_first_half_wait); else the two-call form
+        dp = train.DataParallelStep(be, bucket, be.split, dist=None, overlap=mode.endswith("overlap"), graph=True, lr_base=1e-3,
+                                    signal="signal" in mode)
+        assert dp.in_place == inplace and dp.signal == ("signal" in mode)
         dp.prepare(seed=5)
         assert float(bucket.grads.abs().max()) == 0.0 or not inplace      # rehearsal sums were discarded
         model.seed_word().zero_()
         for _ in range(3):
             dp.step()
         loss, valid = dp.result()
-        assert valid and dp.applied == 3 and dp.optimizer_timeouts == 0
+        assert valid and dp.applied == 3 and dp.optimizer_timeouts == 0 and model.first_half_status() == 0
         if inplace:
             assert float(bucket.grads.abs().max()) == 0.0                  # the commit pass leaves the accumulator zeroed
         outs[mode] = (loss, model.weights_tensor().clone())
-    for mode in ("inplace", "inplace-overlap"):
+    for mode in ("inplace", "inplace-overlap", "inplace-signal-overlap"):
         assert abs(outs[mode][0] - outs["legacy"][0]) <= 1e-5 * abs(outs["legacy"][0]), mode
         assert float((outs[mode][1] - outs["legacy"][1]).abs().max()) < 5e-6, mode
     # two minibatches of two clips with the same key: each clip sees the masks of its position in the MINIBATCH, so the
     # step is a different (equally valid) draw - finite, applied, and close to the one-batch step
     assert float((outs["inplace-accum2"][1] - outs["legacy"][1]).abs().max()) < 5e-2
+    assert float((outs["inplace-signal-accum2-overlap"][1] - outs["inplace-accum2"][1]).abs().max()) < 5e-6
     with pytest.raises(ValueError):       # more than one rank on a foreign bucket cannot use the fused optimizer
         class _D:
             ReduceOp = None
