@@ -119,10 +119,11 @@ class HipTrainBackend:
     """Per-rank forward/backward/optimizer on the HIP library for fixed, device-resident inputs."""
 
     def __init__(self, model, audio: torch.Tensor, labels: torch.Tensor, bucket: GradBucket, scale: float = 1.0,
-                 use_optimizer: bool = True, accum_steps: int = 1, fused: bool = False):
+                 use_optimizer: bool = True, accum_steps: int = 1, fused: bool = False, optimizer_args: Optional[dict] = None):
         audio = audio.to(dtype=model.audio_dtype)      # once, here: no conversion launch inside a captured step
         self.model, self.audio, self.labels, self.bucket, self.scale = model, audio, labels, bucket, float(scale)
         self.use_optimizer = use_optimizer
+        self.optimizer_args = dict(optimizer_args or {})      # layer_lr_decay, b1, b2, eps, weight_decay, clip_norm (model.adamw_step)
         # fused = the fused protocol (include/amt.h): the gradients never leave the context's accumulator, AdamW reads the
         # raw sums (norm pass + commit pass, one launch) and leaves the accumulator zeroed.  With more than one rank the
         # bucket must BE that accumulator (GradBucket.of_model): the collectives then run on it in place and the rank runs
@@ -142,7 +143,7 @@ class HipTrainBackend:
         self.valid_buf = torch.ones(1, dtype=torch.int32, device=dev)
         self.split = model.grad_bucket_split()
         if use_optimizer:
-            model.init_optimizer()
+            model.init_optimizer(self.optimizer_args.get("layer_lr_decay", 0.7))
 
     def full(self, seed: int):
         b, k = self.bucket, self.accum_steps
@@ -217,20 +218,86 @@ class HipTrainBackend:
             # every rank, no flag collective (include/amt.h: amt_adamw_step_reduced)
             b = self.bucket
             b.loss_div = float(self.world)
-            self.model.adamw_step_reduced(lr_base, -1, 1.0 / self.world, b.tail[0:1], valid=self.valid_buf)
+            self.model.adamw_step_reduced(lr_base, -1, 1.0 / self.world, b.tail[0:1], valid=self.valid_buf, **self.optimizer_args)
             self.model.pack_tail(b.tail[0:1], self.valid_buf, head_valid=b.head[0:1], tail_valid=b.tail[1:2])
         elif self.fused:
             b = self.bucket
-            self.model.adamw_step(None, lr_base=lr_base, step=-1, valid=self.valid_buf)
+            self.model.adamw_step(None, lr_base=lr_base, step=-1, valid=self.valid_buf, **self.optimizer_args)
             self.model.pack_tail(self.loss_buf, self.valid_buf, head_valid=b.head[0:1], tail_loss=b.tail[0:1], tail_valid=b.tail[1:2])
         elif self.use_optimizer:
-            self.model.adamw_step(self.bucket.grads, lr_base=lr_base, step=-1, valid_mean=self.bucket.valid_all)
+            self.model.adamw_step(self.bucket.grads, lr_base=lr_base, step=-1, valid_mean=self.bucket.valid_all, **self.optimizer_args)
 
     def applied_steps(self) -> int:
         return self.model.optimizer_count() if self.use_optimizer else 0
 
     def generation(self) -> int:
         return self.model.plan_generation()
+
+
+class InputFeeder:
+    """A fresh batch per step from pinned host memory, uploaded on a copy stream while the previous step computes
+    (the reference uploads each minibatch inside its step: ``jax.device_put(batch, batch_sharding)``, train.py:280).
+
+    The step (a captured hipGraph) reads FIXED device tensors, and it reads them until its very end (the Stem's backward
+    re-reads the audio), so the upload of batch k + 1 goes into a staging pair while step k runs; ``take()`` - in front of
+    step k + 1 on the compute stream - waits for it and copies staging -> inputs on the device (6.6 MB at the reference
+    configuration: two small launches).  ``prefetch()`` may be called right after the step has been issued."""
+
+    def __init__(self, audio_dev: torch.Tensor, labels_dev: torch.Tensor):
+        self.audio, self.labels = audio_dev, labels_dev
+        self.stage_a, self.stage_y = torch.empty_like(audio_dev), torch.empty_like(labels_dev)
+        self.copy_stream = torch.cuda.Stream(device=audio_dev.device)
+        self.ready = torch.cuda.Event()
+        self.taken = torch.cuda.Event()
+        self.taken.record(torch.cuda.current_stream(audio_dev.device))
+        self.pending = False
+        self.bytes_per_batch = audio_dev.numel() * audio_dev.element_size() + labels_dev.numel() * labels_dev.element_size()
+        self._ring, self._ring_ev, self._slot = None, None, 0      # two pinned host pairs for prefetch_from_host
+
+    @staticmethod
+    def pin(audio, labels, audio_dtype):
+        """host batch -> pinned tensors in the dtypes the device takes (the reference's loader hands over float16 samples,
+        grain_loader.py:88)"""
+        a = torch.as_tensor(audio).to(audio_dtype).contiguous().pin_memory()
+        y = torch.as_tensor(labels).to(torch.float32).contiguous().pin_memory()
+        return a, y
+
+    def prefetch(self, host_audio: torch.Tensor, host_labels: torch.Tensor):
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(self.taken)          # the staging pair has been consumed
+            self.stage_a.copy_(host_audio, non_blocking=True)
+            self.stage_y.copy_(host_labels, non_blocking=True)
+            self.ready.record(self.copy_stream)
+        self.pending = True
+
+    def prefetch_from_host(self, audio, labels):
+        """The same for an arbitrary host batch (numpy / pageable torch): converted into one of two persistent pinned pairs
+        first (no pinned allocation per step); a pair is rewritten only after the upload that read it has finished."""
+        if self._ring is None:
+            self._ring = [(torch.empty(self.audio.shape, dtype=self.audio.dtype).pin_memory(),
+                           torch.empty(self.labels.shape, dtype=self.labels.dtype).pin_memory()) for _ in range(2)]
+            self._ring_ev = [None, None]
+        k = self._slot
+        self._slot ^= 1
+        if self._ring_ev[k] is not None:
+            self._ring_ev[k].synchronize()
+        ha, hy = self._ring[k]
+        ha.copy_(torch.as_tensor(audio).reshape(ha.shape))
+        hy.copy_(torch.as_tensor(labels).reshape(hy.shape))
+        self.prefetch(ha, hy)
+        ev = torch.cuda.Event()
+        ev.record(self.copy_stream)
+        self._ring_ev[k] = ev
+
+    def take(self):
+        if not self.pending:
+            return
+        cur = torch.cuda.current_stream(self.audio.device)
+        cur.wait_event(self.ready)
+        self.audio.copy_(self.stage_a, non_blocking=True)
+        self.labels.copy_(self.stage_y, non_blocking=True)
+        self.taken.record(cur)
+        self.pending = False
 
 
 class DataParallelStep:
@@ -436,3 +503,123 @@ class DataParallelStep:
             raise RuntimeError("an in-launch XCD-team hand-off timed out (amt_team_status != 0): the outputs of that step are "
                                "undefined; the context has switched its CNN stages back to one launch per Block")
         return float(v[1]), bool(valid)
+
+
+# ======================================================================================================
+# train(): the reference's training loop (train.py:211-452) over the pieces above.
+# ======================================================================================================
+def train(model, data_loader, *, num_steps: int, base_learning_rate: float = 1e-4, warmup_steps: int = 1000,
+          layer_lr_decay: float = 0.7, weight_decay: float = 0.005, dist=None, overlap: Optional[bool] = None,
+          accum_steps: int = 1, loss_scaling: bool = False, grad_scale: float = 1.0, check_every: int = 1,
+          checkpoint_dir=None, checkpoint_every: int = 20, checkpoints_to_keep: int = 3, print_every: int = 1000,
+          seed: int = 1234, log: Callable[[str], None] = print):
+    """``train(...)`` of the reference (train.py:211-452, called from main at :872) on the HIP path.
+
+    ``data_loader`` yields ``(events, audio)`` host batches - the reference's order (train.py:355) -: events
+    ``[B, frames, 90]`` soft labels, audio ``[B, 2, T]``; every batch has the shape of the first one (the loader crops / pads
+    to the batch, grain_loader.py:60-88).  ``B`` is the RANK's batch; ``accum_steps`` minibatches of it are accumulated on
+    the device (train.py:275-310).  What the reference's loop does, and where it lives here:
+
+    * learning rate (train.py:455-466): ``create_learning_rate_schedule(base, warmup_steps, num_steps)`` evaluated at the
+      count of APPLIED updates (optax's count; a skipped step does not advance it) -> ``DataParallelStep.lr_base``;
+    * the step (train.py:259-332): ``DataParallelStep`` over ``HipTrainBackend(fused=True)`` on the model's own bucket:
+      forward, loss, backward, (collectives,) AdamW + clip, gated on the device - one hipGraph replay + one optimizer launch;
+    * a fresh batch per step (train.py:280): ``InputFeeder`` (pinned host memory, copy stream, double-buffered);
+    * non-finite step (train.py:369-377): the device gate leaves parameters, m, v and the update count untouched, so there is
+      nothing to roll back; with ``loss_scaling`` the scale is halved (and doubled while scaled_loss < 1e4, train.py:379-382:
+      ``LossScaleController``), which re-captures the step - bf16 needs no scaling, so it is off by default and the scale
+      stays ``grad_scale``.  A barrier time-out of the one-launch optimizer (``DataParallelStep.optimizer_timeouts``) also
+      skips a step but is not a numerical event: the scale is left alone;
+    * checkpoints (train.py:384-394, 799-812): every ``checkpoint_every`` steps the flat weight file + metadata
+      (``infer.save_checkpoint``), the newest ``checkpoints_to_keep`` are kept; rank 0 only;
+    * ``check_every``: how often the host synchronises to read (loss, valid) - the reference does every step (it decides on
+      the host); with the device gate 1 is only needed when ``loss_scaling`` is on.
+
+    Out of scope, as in SURVEY.md section 2: test-set evaluation, TensorBoard, the (no-op) genetic recombination.
+    Returns a dict: steps issued, updates applied, skipped steps, final scale, per-check (step, loss) history."""
+    import itertools
+    import os as _os
+    from . import infer as _infer
+    rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
+    world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
+    if overlap is None:
+        overlap = world > 1
+    it = iter(data_loader)
+    try:
+        events0, audio0 = next(it)
+    except StopIteration:
+        raise ValueError("the data loader is empty") from None
+    dev = model.device
+    audio_dev = torch.as_tensor(audio0).to(device=dev, dtype=model.audio_dtype).contiguous()
+    labels_dev = torch.as_tensor(events0).to(device=dev, dtype=torch.float32).contiguous()
+    model.init_optimizer(layer_lr_decay)
+    bucket = GradBucket.of_model(model)
+    controller = LossScaleController(scale=float(grad_scale), enabled=bool(loss_scaling))
+    schedule = create_learning_rate_schedule(base_learning_rate, warmup_steps, num_steps)
+    hyper = dict(layer_lr_decay=layer_lr_decay, weight_decay=weight_decay)
+
+    def build(scale):
+        be = HipTrainBackend(model, audio_dev, labels_dev, bucket, scale=scale, fused=True, accum_steps=accum_steps,
+                             optimizer_args=hyper)
+        step = DataParallelStep(be, bucket, be.split, dist=dist, overlap=overlap, graph=True, lr_base=schedule(0))
+        step.prepare(seed=seed)
+        return be, step
+
+    be, dp = build(controller.scale)
+    feeder = InputFeeder(audio_dev, labels_dev)      # (the backend reads these very tensors: same dtype, no copy was made)
+    assert be.audio.data_ptr() == audio_dev.data_ptr()
+    history, skipped, issued, timeouts_seen = [], 0, 0, 0
+    loss_sum, loss_n = 0.0, 0
+    saved = []
+    applied = model.optimizer_count()
+    have_batch = True                      # batch 1 is already in the input tensors
+    for step_no in range(1, num_steps + 1):
+        if not have_batch:
+            break
+        feeder.take()                      # (batch k + 1 was sent on its way while step k was being issued)
+        dp.lr_base = schedule(applied)     # optax evaluates the schedule at its count BEFORE the increment (oracle/optim.py)
+        dp.step(seed=seed + step_no)
+        issued += 1
+        try:
+            ev_h, au_h = next(it)
+            feeder.prefetch_from_host(au_h, ev_h)
+        except StopIteration:
+            have_batch = False
+        applied += 1                       # optimistic; re-aligned with the device count at every check
+        if step_no % check_every == 0 or step_no == num_steps:
+            loss, valid = dp.result()      # synchronises; dp.applied = the device's count of applied updates
+            applied = dp.applied
+            new_timeouts = dp.optimizer_timeouts - timeouts_seen
+            timeouts_seen = dp.optimizer_timeouts
+            if new_timeouts:
+                skipped += new_timeouts
+                log(f"step {step_no}: the one-launch optimizer timed out at its grid barrier - step skipped, scale unchanged")
+            elif controller.update(valid, loss, loss * controller.scale):
+                skipped += 1
+                log(f"Encountered NAN/inf loss at step {step_no}, loss = {loss}. Skipped on the device; grad scale -> {controller.scale}")
+                if controller.enabled:
+                    be, dp = build(controller.scale)       # the scale is an argument of the captured launches
+                continue
+            elif controller.enabled and be.scale != controller.scale:
+                log(f"Grad scale: {be.scale} -> {controller.scale}")
+                be, dp = build(controller.scale)
+            if valid:
+                loss_sum += loss; loss_n += 1
+                history.append((step_no, loss))
+        if print_every and step_no % print_every == 0 and loss_n:
+            log(f"Step {step_no}/{num_steps}, Loss: {loss_sum / loss_n}, LR = {schedule(applied)}")
+            loss_sum, loss_n = 0.0, 0
+        if checkpoint_dir is not None and rank == 0 and checkpoint_every and step_no % checkpoint_every == 0:
+            torch.cuda.synchronize()
+            _infer.save_checkpoint(checkpoint_dir, model.weights_tensor().cpu().numpy(), model.conf, step=step_no)
+            saved.append(step_no)
+            while len(saved) > checkpoints_to_keep:
+                old = saved.pop(0)
+                for name in (f"params_{old}.f32", f"metadata_{old}.json"):
+                    try:
+                        _os.remove(_os.path.join(str(checkpoint_dir), name))
+                    except OSError:
+                        pass
+    torch.cuda.synchronize()
+    return {"steps": issued, "applied": model.optimizer_count(), "skipped": skipped, "grad_scale": controller.scale,
+            "history": history, "checkpoints": saved}

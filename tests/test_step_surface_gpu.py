@@ -318,3 +318,38 @@ def test_data_parallel_step_uses_the_fused_protocol_under_graph_replay(small_con
         outs[fused] = (loss, model.weights_tensor().clone())
     assert abs(outs[True][0] - outs[False][0]) <= 1e-5 * abs(outs[False][0])
     assert float((outs[True][1] - outs[False][1]).abs().max()) < 5e-6
+
+
+def test_train_entry_loss_falls_and_a_skipped_step_rolls_nothing_forward(small_conf, tmp_path):
+    """audio_to_midi_amd.train.train(): the reference's loop (train.py:211-452) wired from the schedule, the loss-scale
+    controller, DataParallelStep on the model's own bucket, the double-buffered input feeder and the checkpoint cadence.
+    50 steps on a small model over a fixed set of four batches: the loss falls; one batch carries a NaN sample - that step is
+    skipped ON THE DEVICE (nothing to roll back: parameters stay finite, the update count is steps - skipped) and the loop
+    goes on; checkpoints appear every 20 steps and only the newest `checkpoints_to_keep` stay."""
+    model = amt.OutputSequenceGenerator(small_conf, key=11, dtype="bfloat16", gamma=1.0)
+    batches = []
+    for j in range(4):
+        audio, labels = synth.make_batch(4, 320 * 48, seed=30 + j)
+        batches.append((labels, audio))                     # the reference's order: (events, audio)
+
+    def loader():
+        for k in range(50):
+            ev, au = batches[k % 4]
+            if k == 17:
+                au = au.copy(); au[1, 0, 1000] = np.nan     # one poisoned sample
+            yield ev, au
+
+    logs = []
+    out = train.train(model, loader(), num_steps=50, base_learning_rate=2e-3, warmup_steps=5, checkpoint_dir=tmp_path,
+                      checkpoint_every=20, checkpoints_to_keep=1, print_every=10, log=logs.append)
+    assert out["steps"] == 50 and out["skipped"] == 1 and out["applied"] == 49 == model.optimizer_count()
+    assert bool(torch.isfinite(model.weights_tensor()).all())
+    hist = dict(out["history"])
+    assert 18 not in hist and len(hist) == 49                                  # step 18 consumed the poisoned batch
+    first, last = np.mean([hist[k] for k in range(1, 9)]), np.mean([hist[k] for k in range(43, 51)])
+    assert last < 0.8 * first, (first, last)
+    assert out["checkpoints"] == [40] and sorted(p.name for p in tmp_path.iterdir()) == ["metadata_40.json", "params_40.f32"]
+    assert any("NAN/inf" in ln for ln in logs) and any(ln.startswith("Step 50/50") for ln in logs)
+    from audio_to_midi_amd import infer
+    flat, conf, step = infer.load_checkpoint(tmp_path)
+    assert step == 40 and flat.size == model.n_params
