@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -337,10 +339,12 @@ struct amt_ctx {
   float* amax = nullptr;        // [layers][prev q,k,v,- | cur q,k,v,-]: delayed per-tensor scaling state
   uint64_t* seed_word = nullptr;   // device word added to every dropout seed (amt_seed_word / amt_advance_seed)
   TeamState* team = nullptr;    // XCD-team protocol words (team.h); null: team launches disabled (AMT_TEAM=0)
-  // run_backward phase 3 ("first half complete" published on the device): the counter, the polling kernel's give-up count,
-  // and the host's bookkeeping of the value the next wait expects
-  unsigned* half_sig = nullptr;
-  unsigned* half_timeouts = nullptr;
+  // run_backward phase 3 ("first half complete" published from inside the launch sequence): the counter, its mapped host
+  // copy, and the host's bookkeeping of the value the next wait expects
+  unsigned* half_sig = nullptr;            // device counter of published signals
+  volatile unsigned* half_host = nullptr;  // the same count in mapped host memory (what amt_first_half_wait polls)
+  unsigned* half_host_dev = nullptr;       // ... its device address
+  int half_timeouts = 0;
   uint32_t half_base = 0, half_waits = 0;
   int cnn_late_max_c = 0;       // AMT_CNN_WGRAD_LATE=C: weight gradients of the CNN stages with <= C channels as one batch of launches after the pass (1 = all)
   bool fuse_ffn = true;         // AMT_FUSE_FFN=0: second half of a layer as chain + two tiled GEMM launches
@@ -739,29 +743,27 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
 __global__ void advance_seed_kernel(uint64_t* p, uint64_t delta) { *p += delta; }
 
-// ---- "first half complete" as a DEVICE-SIDE signal (run_backward phase 3; include/amt.h: amt_first_half_wait)
+// ---- "first half complete" published from INSIDE the launch sequence (run_backward phase 3; include/amt.h: amt_first_half_wait)
 // The overlapped data-parallel step wants its first collective to start when the gradients of [fn_w, n) are complete, in
-// the MIDDLE of the backward pass.  Cutting the pass into two host calls (phases 1 / 2) costs two graph launches, a flush
-// launch for the riders that would have travelled on the first CNN Block chain and the cross-stream hand-shakes: 0.12 ms
-// per step at cfg2 with no collective at all (profiles/r04_notes.md); external event-record nodes are "disallowed in
-// rocm" (torch 2.10) and a captured RCCL call aborts its watchdog.  So the one-call launch sequence stays ONE graph and
-// one of its nodes publishes a counter; a one-wave kernel on the communication stream polls it (bounded) in front of the
-// collective.  MEASURED (scratch/overlap_cost.py, profiles/r04_notes.md): the signalled graph itself costs +8 us per step,
-// but a kernel RESIDENT on a second queue costs the main queue 0.14 ms per step (every one of its ~200 dependent launches
-// gets a little slower while another queue is active) - as much as the two-call form's split; and the stream operation
-// made for this (hipStreamWaitValue32 on HSA signal memory: the command processor polls, no wave) made the step 4.4 ms
-// instead of 3.0.  The two-call form therefore stays the default and this one an opt-in (DataParallelStep(signal=True)).
-__global__ void half_signal_kernel(unsigned* sig, const float* loss_acc, float* tail_loss, float loss_mul) {
+// the MIDDLE of the backward pass.  What the obvious forms cost on this platform, all measured at cfg2 with NO collective
+// running (scratch/overlap_cost.py, scratch/feeder_cost.py, profiles/r04_notes.md; the one-call step: 3.01 ms):
+//   * the pass cut into two host calls / two graphs with the communication stream waiting for an event of the compute
+//     stream in between (phases 1 / 2):                                                          3.14-3.16 ms.  Of the
+//     +0.13 ms, ~0.12 are that ONE cross-stream wait: any stream waiting for an event recorded on the busy compute stream
+//     costs that much (an event record alone: +5 us; the compute stream waiting for ANOTHER stream's event: +20 us);
+//   * one graph + a one-wave kernel on the communication stream that polls a device counter:    3.16 ms (a kernel resident
+//     on a second queue slows the ~200 dependent launches of the first);
+//   * one graph + hipStreamWaitValue32 on HSA signal memory (the command processor polls):      4.4 ms;
+//   * external event-record nodes inside a capture: "disallowed in rocm" (torch 2.10); a captured RCCL call aborts its watchdog.
+// So: the one-call launch sequence stays ONE graph (+8 us: the first range's record sums and this kernel), one of its nodes
+// publishes a counter into MAPPED HOST memory, and the HOST polls that word before it issues the collective on the
+// communication stream.  No stream ever waits for the compute stream.
+__global__ void half_signal_kernel(unsigned* counter, unsigned* host_word, const float* loss_acc, float* tail_loss, float loss_mul) {
   if (tail_loss != nullptr) tail_loss[0] = loss_acc[0] * loss_mul;      // the rank's loss travels with the first range
-  __threadfence_system();
-  __hip_atomic_fetch_add(sig, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__global__ void half_wait_kernel(const unsigned* sig, unsigned target, unsigned max_polls, unsigned* timeouts) {
-  unsigned polls = 0;
-  while ((int)(__hip_atomic_load(sig, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - target) < 0) {
-    __builtin_amdgcn_s_sleep(32);
-    if (++polls > max_polls) { __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-  }
+  const unsigned v = counter[0] + 1u;                                    // (one thread, launches of a context are serialised)
+  counter[0] = v;
+  __threadfence_system();                                                // the gradients of earlier launches and the loss word: visible first
+  __hip_atomic_store(host_word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------------------------ backward
@@ -1126,7 +1128,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     signalled = true;
     RUN(reduce_partials(s, c->part_desc_dev, c->n_part_desc_half, c->partials, grads));
     if (acc_last)
-      RUN(hipLaunchKernelGGL(half_signal_kernel, dim3(1), dim3(1), 0, s, c->half_sig, c->loss_acc, grads + L.n_params,
+      RUN(hipLaunchKernelGGL(half_signal_kernel, dim3(1), dim3(1), 0, s, c->half_sig, c->half_host_dev, c->loss_acc, grads + L.n_params,
                              1.f / (float)acc_count));
   };
   // CNN stages, last to first
@@ -1519,13 +1521,8 @@ void amt_destroy(amt_ctx* c) {
   (void)hipSetDevice(c->device);
   void* ptrs[] = {c->params, c->wc, c->head_bias, c->conv_dev, c->conv_prefix_dev, c->rope_cos, c->rope_sin,
                   c->arena.base, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, c->norm2, c->loss_acc,
-                  c->partials, c->amax, c->gacc, c->team, c->seed_word, c->lr_idx, c->lr_tab, c->half_timeouts};
-  if (c->half_sig) {      // release whatever may still wait on the counter, then free it
-    const unsigned big = 0x7fffffffu;
-    (void)hipMemcpy(c->half_sig, &big, sizeof(big), hipMemcpyHostToDevice);
-    (void)hipDeviceSynchronize();
-    (void)hipFree(c->half_sig);
-  }
+                  c->partials, c->amax, c->gacc, c->team, c->seed_word, c->lr_idx, c->lr_tab, c->half_sig};
+  if (c->half_host) { (void)hipDeviceSynchronize(); (void)hipHostFree(const_cast<unsigned*>(c->half_host)); }
   for (const amt_ctx::PlanRec& r : c->plans)
     if (r.desc_dev) (void)hipFree(r.desc_dev);
   for (void* p : ptrs)
@@ -1604,8 +1601,11 @@ int32_t amt_forward_backward_accum(amt_ctx* c, const void* audio, const float* l
   if (phase == 3 && c->half_sig == nullptr) {
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->half_sig), 8));
     HIPCHK(c, hipMemset(c->half_sig, 0, 8));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->half_timeouts), sizeof(unsigned)));
-    HIPCHK(c, hipMemset(c->half_timeouts, 0, sizeof(unsigned)));
+    unsigned* hw = nullptr;
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&hw), sizeof(unsigned), hipHostMallocMapped));
+    *hw = 0u;
+    c->half_host = hw;
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->half_host_dev), hw, 0));
     HIPCHK(c, hipDeviceSynchronize());
   }
   if (accum_count < 1 || accum_index < 0 || accum_index >= accum_count) { c->err = "accum_index must be in [0, accum_count)"; return 1; }
@@ -1824,32 +1824,32 @@ float* amt_grad_bucket(amt_ctx* c, uint64_t* head, uint64_t* n, uint64_t* tail) 
   return c->gacc + c->gacc_pad - 4;
 }
 
-int32_t amt_first_half_wait(amt_ctx* c, void* stream) {
-  if (c->half_sig == nullptr) { c->err = "amt_first_half_wait: no phase-3 step has been issued on this context"; return 1; }
-  hipStream_t s = static_cast<hipStream_t>(stream);
+int32_t amt_first_half_wait(amt_ctx* c, int32_t timeout_ms) {
+  if (c->half_host == nullptr) { c->err = "amt_first_half_wait: no phase-3 step has been issued on this context"; return 1; }
   const uint32_t target = c->half_base + ++c->half_waits;      // the k-th wait since the last sync consumes the k-th signal
-  hipLaunchKernelGGL(half_wait_kernel, dim3(1), dim3(1), 0, s, c->half_sig, target, 1u << 22, c->half_timeouts);   // ~2-4 s
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { c->err = std::string("amt_first_half_wait: ") + hipGetErrorString(e); return 1; }
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned polls = 0;
+  while ((int32_t)(*c->half_host - target) < 0) {
+    if ((++polls & 1023u) == 0 &&
+        std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > (timeout_ms > 0 ? timeout_ms : 10000)) {
+      c->half_timeouts++;
+      c->err = "amt_first_half_wait: the step did not publish its first-half signal in time";
+      return 1;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
   return 0;
 }
 
 int32_t amt_first_half_sync(amt_ctx* c, void* stream) {
-  if (c->half_sig == nullptr) return 0;
+  if (c->half_host == nullptr) return 0;
   HIPCHK(c, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-  uint32_t v = 0;
-  HIPCHK(c, hipMemcpy(&v, c->half_sig, sizeof(v), hipMemcpyDeviceToHost));
-  c->half_base = v;
+  c->half_base = *c->half_host;
   c->half_waits = 0;
   return 0;
 }
 
-int32_t amt_first_half_status(amt_ctx* c) {
-  if (c->half_timeouts == nullptr) return 0;
-  unsigned w = 0;
-  if (hipMemcpy(&w, c->half_timeouts, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return (int32_t)w;
-}
+int32_t amt_first_half_status(amt_ctx* c) { return c->half_timeouts; }
 
 int32_t amt_optimizer_status(amt_ctx* c) {
   if (c->persist_fail != nullptr && *reinterpret_cast<volatile int*>(c->persist_fail) != 0) {

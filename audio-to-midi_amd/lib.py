@@ -107,7 +107,7 @@ SIGNATURES = {
     "amt_optimizer_count": (_i32, [_vp]),
     "amt_grad_accumulator_reset": (_i32, [_vp, _vp]),
     "amt_optimizer_status": (_i32, [_vp]),
-    "amt_first_half_wait": (_i32, [_vp, _vp]),
+    "amt_first_half_wait": (_i32, [_vp, _i32]),
     "amt_first_half_sync": (_i32, [_vp, _vp]),
     "amt_first_half_status": (_i32, [_vp]),
     "amt_grad_bucket": (_vp, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),

@@ -321,11 +321,10 @@ class OutputSequenceGenerator:
         total = int(h.value + n.value + t.value)
         return _DevView(ptr, total, self.device).tensor(), int(h.value), int(n.value), int(t.value)
 
-    def first_half_wait(self, stream: Optional[torch.cuda.Stream] = None):
-        """Enqueue, on ``stream`` (default: the current one - make it the communication stream), the kernel that waits for
-        the "first half complete" signal of a ``loss_and_grads_phase(3, ...)`` step (include/amt.h: amt_first_half_wait)."""
-        st = C.c_void_p((stream or torch.cuda.current_stream(self.device)).cuda_stream)
-        self._check(self._L.amt_first_half_wait(self._h, st), "amt_first_half_wait")
+    def first_half_wait(self, timeout_ms: int = 0):
+        """Block the calling host thread until the next "first half complete" signal of a ``loss_and_grads_phase(3, ...)``
+        step has been published (include/amt.h: amt_first_half_wait): the collective of the first range may be issued."""
+        self._check(self._L.amt_first_half_wait(self._h, int(timeout_ms)), "amt_first_half_wait")
 
     def first_half_sync(self):
         """Declare every first-half signal published so far as consumed (after unpaired rehearsal steps)."""

@@ -199,8 +199,8 @@ class HipTrainBackend:
         self.model.loss_and_grads_phase(3, a, y, None, self.loss_buf, self.valid_buf, scale=self.scale, seed=seed, train=True,
                                         accum=(k - 1, k))
 
-    def wait_first_half(self, stream):
-        self.model.first_half_wait(stream)
+    def wait_first_half(self):
+        self.model.first_half_wait()
 
     def sync_signals(self):
         self.model.first_half_sync()
@@ -239,18 +239,24 @@ class InputFeeder:
     (the reference uploads each minibatch inside its step: ``jax.device_put(batch, batch_sharding)``, train.py:280).
 
     The step (a captured hipGraph) reads FIXED device tensors, and it reads them until its very end (the Stem's backward
-    re-reads the audio), so the upload of batch k + 1 goes into a staging pair while step k runs; ``take()`` - in front of
-    step k + 1 on the compute stream - waits for it and copies staging -> inputs on the device (6.6 MB at the reference
-    configuration: two small launches).  ``prefetch()`` may be called right after the step has been issued."""
+    re-reads the audio), so the upload of batch k + 1 goes into one of two staging pairs while step k runs; ``take()`` - in
+    front of step k + 1 on the compute stream - waits for it and copies staging -> inputs on the device (6.6 MB at the
+    reference configuration: two small launches).  ``prefetch()`` may be called right after the step has been issued.
+
+    Which way the streams wait for each other matters on this platform (scratch/feeder_cost.py, profiles/r04_notes.md): the
+    compute stream waiting for an event of the copy stream costs ~20 us per step, but ANOTHER stream waiting for an event
+    recorded on the busy compute stream costs 0.12 ms per step (round 4's first form: 3.15 against 3.02 ms).  So the
+    "staging consumed" hand-back is a HOST wait on an event the compute stream recorded a step earlier (long complete by
+    then), and no stream ever waits for the compute stream: 3.045 ms."""
 
     def __init__(self, audio_dev: torch.Tensor, labels_dev: torch.Tensor):
         self.audio, self.labels = audio_dev, labels_dev
-        self.stage_a, self.stage_y = torch.empty_like(audio_dev), torch.empty_like(labels_dev)
+        self.stage = [(torch.empty_like(audio_dev), torch.empty_like(labels_dev)) for _ in range(2)]
         self.copy_stream = torch.cuda.Stream(device=audio_dev.device)
-        self.ready = torch.cuda.Event()
-        self.taken = torch.cuda.Event()
-        self.taken.record(torch.cuda.current_stream(audio_dev.device))
-        self.pending = False
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]         # upload into pair i finished (copy stream)
+        self.consumed = [None, None]                                   # pair i copied into the inputs (compute stream)
+        self.up, self.down = 0, 0                                      # next pair to upload into / to take from
+        self.pending = 0
         self.bytes_per_batch = audio_dev.numel() * audio_dev.element_size() + labels_dev.numel() * labels_dev.element_size()
         self._ring, self._ring_ev, self._slot = None, None, 0      # two pinned host pairs for prefetch_from_host
 
@@ -263,12 +269,17 @@ class InputFeeder:
         return a, y
 
     def prefetch(self, host_audio: torch.Tensor, host_labels: torch.Tensor):
+        if self.pending >= 2:
+            raise RuntimeError("both staging pairs hold batches that have not been taken")
+        i = self.up
+        self.up ^= 1
+        if self.consumed[i] is not None:
+            self.consumed[i].synchronize()               # HOST wait (see the class comment); recorded a step ago
         with torch.cuda.stream(self.copy_stream):
-            self.copy_stream.wait_event(self.taken)          # the staging pair has been consumed
-            self.stage_a.copy_(host_audio, non_blocking=True)
-            self.stage_y.copy_(host_labels, non_blocking=True)
-            self.ready.record(self.copy_stream)
-        self.pending = True
+            self.stage[i][0].copy_(host_audio, non_blocking=True)
+            self.stage[i][1].copy_(host_labels, non_blocking=True)
+            self.ready[i].record(self.copy_stream)
+        self.pending += 1
 
     def prefetch_from_host(self, audio, labels):
         """The same for an arbitrary host batch (numpy / pageable torch): converted into one of two persistent pinned pairs
@@ -292,12 +303,16 @@ class InputFeeder:
     def take(self):
         if not self.pending:
             return
+        i = self.down
+        self.down ^= 1
         cur = torch.cuda.current_stream(self.audio.device)
-        cur.wait_event(self.ready)
-        self.audio.copy_(self.stage_a, non_blocking=True)
-        self.labels.copy_(self.stage_y, non_blocking=True)
-        self.taken.record(cur)
-        self.pending = False
+        cur.wait_event(self.ready[i])
+        self.audio.copy_(self.stage[i][0], non_blocking=True)
+        self.labels.copy_(self.stage[i][1], non_blocking=True)
+        if self.consumed[i] is None:
+            self.consumed[i] = torch.cuda.Event()
+        self.consumed[i].record(cur)
+        self.pending -= 1
 
 
 class DataParallelStep:
@@ -305,9 +320,9 @@ class DataParallelStep:
 
     ``overlap=True``: the collective of the range the first half of the backward pass completes (37 of the 46 MB at the
     reference configuration, with the loss behind it) runs on a side stream while the CNN backward executes, the rest
-    follows on the main stream: two collectives per step.  The step runs in two host calls (amt_forward_backward_phase);
-    ``signal=True`` (in-place protocol, GPU) keeps it ONE launch sequence that signals the first half's completion on the
-    device instead (include/amt.h: amt_first_half_wait; measured no faster).  ``overlap=False``: one collective over the whole bucket after the backward pass.
+    follows on the main stream: two collectives per step.  With the in-place protocol on a GPU the step stays ONE launch
+    sequence that publishes the first half's completion to the host (``signal``, include/amt.h: amt_first_half_wait), which
+    then issues the first collective; otherwise it runs in two host calls (amt_forward_backward_phase).  ``overlap=False``: one collective over the whole bucket after the backward pass.
     The reduction is a MEAN over ranks: ``ReduceOp.AVG`` where the backend has it (RCCL), SUM followed by a scale
     of the same range otherwise (gloo).  On CUDA/HIP devices the per-rank work is captured into hipGraphs unless
     ``graph=False``; the dropout seed of a replay is ``seed + seed_word`` with the device word advanced inside the
@@ -323,12 +338,13 @@ class DataParallelStep:
         if hasattr(backend, "world"):
             backend.world = self.world
         # overlap without splitting the step: one launch sequence + a device-side signal (HipTrainBackend.full_signal)
-        # opt-in (signal=True): measured no faster than the two-call form - a kernel resident on the communication queue
-        # slows the main queue's ~200 dependent launches by as much as the split costs (include/amt.h, profiles/r04_notes.md)
+        # (the default where it is available; signal=False forces the two-call form: 3.05 against 3.15 ms per step at the
+        # reference configuration with no collective running - a stream waiting for an event of the busy compute stream
+        # costs 0.12 ms on this platform, include/amt.h, profiles/r04_notes.md)
         can_signal = bool(overlap) and self.in_place and hasattr(backend, "full_signal") and bucket.buf.is_cuda
         if signal and not can_signal:
             raise ValueError("the signalled overlap form needs overlap=True and the in-place protocol on a GPU")
-        self.signal = bool(signal)
+        self.signal = can_signal if signal is None else bool(signal)
         if getattr(backend, "fused", False) and self.world > 1 and not self.in_place:
             raise ValueError("more than one rank with the fused optimizer needs the model's own bucket: GradBucket.of_model(model)")
         # the optimizer gate tests the MEAN of the ranks' 0/1 flags against 0.999 (csrc/head.hip: adamw_gate_open): one
@@ -343,6 +359,7 @@ class DataParallelStep:
         self.applied = 0          # optimizer updates actually applied (device count, refreshed by result())
         self.optimizer_timeouts = 0   # steps lost to a barrier time-out of the one-launch optimizer (refreshed by result())
         self._graphs = None
+        self._half_done = None
         self._gen = None
         self._comm = torch.cuda.Stream(device=bucket.buf.device) if self.cuda else None
         if self.overlap and self.world > 1 and not (0 < self.split < bucket.n):
@@ -445,15 +462,16 @@ class DataParallelStep:
         seed = self.step_no if seed is None else seed
         self._check_generation()
         if self.signal:
-            # ONE graph (the single-rank step's launch sequence); the communication stream waits ON THE DEVICE for the
-            # signal the graph publishes behind its first CNN Block chain, then reduces [split, n) + loss while the CNN
-            # backward runs; the CNN range follows on the main stream
+            # ONE graph (the single-rank step's launch sequence).  The host waits for the signal the graph publishes behind
+            # its first CNN Block chain (mapped host memory), then issues the collective of [split, n) + loss on the
+            # communication stream - which therefore needs no dependency on the compute stream - while the CNN backward
+            # runs; the CNN range follows on the compute stream, which finally waits for the communication stream
             if self._graphs is not None:
                 self._graphs[0].replay()
             else:
                 be.full_signal(seed)
+            be.wait_first_half()
             with torch.cuda.stream(self._comm):
-                be.wait_first_half(self._comm)
                 self._mean_allreduce(self._first_range())
             self._mean_allreduce(self._second_range())
             torch.cuda.current_stream().wait_stream(self._comm)
@@ -463,19 +481,29 @@ class DataParallelStep:
             else:
                 be.half(1, seed)
             if self.cuda:
-                main = torch.cuda.current_stream()
-                self._comm.wait_stream(main)
+                # The second half is issued FIRST; the host then waits for an event recorded between the halves and issues
+                # the first collective on the communication stream.  (The stream-side form - the communication stream waiting
+                # for that event - costs 0.12 ms per step on this platform: any stream waiting for an event of the busy
+                # compute stream does; profiles/r04_notes.md.)
+                if self._half_done is None:
+                    self._half_done = torch.cuda.Event()
+                self._half_done.record(torch.cuda.current_stream())
+                if self._graphs is not None:
+                    self._graphs[1].replay()
+                else:
+                    be.half(2, seed)
+                self._half_done.synchronize()
                 with torch.cuda.stream(self._comm):
                     self._mean_allreduce(self._first_range())           # transformer + decoder range, loss, first flag
+                self._mean_allreduce(self._second_range())               # whole-step flag + CNN range
+                torch.cuda.current_stream().wait_stream(self._comm)
             else:
                 self._mean_allreduce(self._first_range())
-            if self._graphs is not None:
-                self._graphs[1].replay()
-            else:
-                be.half(2, seed)
-            self._mean_allreduce(self._second_range())                   # whole-step flag + CNN range
-            if self.cuda:
-                torch.cuda.current_stream().wait_stream(self._comm)
+                if self._graphs is not None:
+                    self._graphs[1].replay()
+                else:
+                    be.half(2, seed)
+                self._mean_allreduce(self._second_range())
         else:
             if self._graphs is not None:
                 self._graphs[0].replay()

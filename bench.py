@@ -42,11 +42,31 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def cgroup_cpu_quota():
+    """CPU quota of this process's cgroup in cores (cpu.max / cfs_quota_us), or None when unlimited / unreadable."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2
+            q, per = f.read().split()[:2]
+            return None if q == "max" else max(1, int(round(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:         # cgroup v1
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = int(f.read())
+        return None if q <= 0 else max(1, int(round(q / per)))
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(seconds_budget: float = 30.0):
     """Oracle (torch-CPU fp32 restatement of the reference; JAX is unavailable offline) on the host cores: fwd + bwd of
     B=8 x 10 s clips (the same per-step batch as one GPU).  BASELINE.md section 2: N = ALL host cores the process may run
     on (N stated), two warm-ups, median of five.  The figure at 16 threads - the box's CPU share per GPU, what rounds 1-3
-    reported - is measured beside it (`at_16_threads`)."""
+    reported - is measured beside it (`at_16_threads`).  "May run on" = min(sched_getaffinity, the cgroup's CPU quota): the
+    GPU box shows 256 logical CPUs to a process whose cgroup grants 16 cores' worth of time, and 256 torch threads on that
+    share did not finish ONE step in four minutes (gpurun_out/r4h, round 4)."""
     from oracle import np_model, torch_model
     import audio_to_midi_amd as amt
     conf = np_model.MODEL_CONFIG
@@ -84,13 +104,17 @@ def cpu_baseline(seconds_budget: float = 30.0):
         med = float(np.median(times)) if times else warm[-1]
         return med, len(times), int(torch.get_num_threads())
 
-    cap = int(os.environ.get("AMT_CPU_BASELINE_THREADS", "0"))      # (0: all available cores)
-    n_all = max(1, min(avail, cap) if cap > 0 else avail)
+    quota = cgroup_cpu_quota()
+    usable = min(avail, quota) if quota else avail
+    if quota is None and avail > 64:
+        usable = 16      # no readable quota on a many-core box: the documented CPU share per GPU (an oversubscribed run would not end)
+    cap = int(os.environ.get("AMT_CPU_BASELINE_THREADS", "0"))      # (0: every usable core)
+    n_all = max(1, min(usable, cap) if cap > 0 else usable)
     med, n, thr = measure(n_all, 2, 5, seconds_budget * 0.6)
     out = {"value": round(Bc * CLIP_SECONDS / med, 2), "unit": "audio-sec/s", "cores": thr, "kind": "port",
            "sample": f"fwd+bwd of B={Bc} x 10 s clips, fp32, full model, median of {n} after 2 warm-ups ({med:.2f} s/step); "
                      f"torch-CPU restatement of the reference (JAX unavailable offline); torch threads = {thr} = every core the "
-                     f"process may run on (sched_getaffinity: {avail}, os.cpu_count(): {os.cpu_count()})"}
+                     f"process may run on (sched_getaffinity: {avail}, cgroup CPU quota: {quota}, os.cpu_count(): {os.cpu_count()})"}
     if thr != 16 and avail >= 16:
         med16, n16, thr16 = measure(16, 1, 3, seconds_budget * 0.4)
         out["at_16_threads"] = {"value": round(Bc * CLIP_SECONDS / med16, 2), "cores": thr16,
@@ -330,9 +354,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: one all-reduce after the whole backward pass instead of the two-bucket overlap")
     ap.add_argument("--force-overlap", action="store_true", help="use the two-phase step even at N = 1 (testing)")
-    ap.add_argument("--signal", action="store_true",
-                    help="overlap as ONE launch sequence with a device-side first-half signal (amt_first_half_wait) instead of "
-                         "two host calls / two graphs (amt_forward_backward_phase); measured no faster")
+    ap.add_argument("--no-signal", action="store_true",
+                    help="overlap as two host calls / two graphs (amt_forward_backward_phase) instead of ONE launch sequence that "
+                         "publishes the first half's completion to the host (amt_first_half_wait)")
     ap.add_argument("--workload", choices=["train", "infer"], default="train",
                     help="train = BASELINE configs[1] (default, the headline metric); infer = configs[3]: streaming "
                          "inference, 32 x 60 s clips -> 448 windows of 5 s, forward + stitch (reported, not the headline)")
@@ -407,7 +431,7 @@ def main():
     # finite check and the clip are all still computed, train.py:319-325)
     backend = amt_train.HipTrainBackend(model, audio, labels, bucket, scale=1.0, use_optimizer=not args.no_optimizer, fused=fused)
     dp = amt_train.DataParallelStep(backend, bucket, backend.split, dist=dist, overlap=overlap, graph=not args.no_graph,
-                                    lr_base=1e-4, signal=args.signal)
+                                    lr_base=1e-4, signal=False if args.no_signal else None)
     dp.prepare(seed=12345)       # every allocation (optimizer state, workspace plan) happens before graph capture
     graph = dp._graphs
     # A fresh batch per step (train.py:280: the reference uploads every minibatch): four distinct pinned host batches in

@@ -257,19 +257,18 @@ float* amt_grad_bucket(amt_ctx* ctx, uint64_t* head, uint64_t* n, uint64_t* tail
  * amt_forward_backward_accum(phase = 3, grads_flat = NULL) issues the launches of the one-call step (phase 0) plus - right
  * behind the first CNN Block chain, which carries the last weight-gradient riders of the range [amt_grad_bucket_split, n) -
  * the record sums of that range and a one-thread kernel that writes the rank's loss into tail[0] of the bucket and
- * publishes "first half complete" in a device counter.  amt_first_half_wait enqueues a one-wave kernel on ANOTHER stream
- * (the communication stream) that polls that counter for the next unconsumed signal (bounded: ~2-4 s, then it gives up
- * and counts a time-out); the collective of [split, n) + tail[0] goes behind it.  The step stays ONE hipGraph whose node
- * sequence is the single-rank step's (+8 us).  MEASURED on one MI355X with no collective at all (profiles/r04_notes.md): a
- * kernel resident on a second queue slows the ~200 dependent launches of the main queue by 0.14 ms per step, as much as
- * the two-call form (phases 1 / 2: two graph launches, a flush launch) costs, and hipStreamWaitValue32 on signal memory in
- * its place made the step 4.4 ms instead of 3.0 (torch 2.10 on ROCm refuses external event-record nodes in a capture and a
- * captured RCCL call aborts its watchdog, so those forms are not available).  Hence an OPT-IN; the two-call form is what
- * DataParallelStep takes by default.  Every phase-3 step must be paired with exactly one amt_first_half_wait, issued after
- * it in host order; amt_first_half_sync (host-synchronous on the step's stream) declares every signal published so far as
- * consumed: call it after warm-up / rehearsal steps that were not paired with a wait.  amt_first_half_status: waits that
- * gave up (host-synchronous). */
-int32_t amt_first_half_wait(amt_ctx* ctx, void* stream);
+ * publishes "first half complete" as a counter in MAPPED HOST memory.  amt_first_half_wait blocks the calling HOST thread
+ * (busy poll, `timeout_ms`, 0 = 10 s; error on time-out) until the next unconsumed signal has been published: the host
+ * then issues the collective of [split, n) + tail[0] on its communication stream, which needs no device-side dependency
+ * on the compute stream.  The step stays ONE hipGraph whose node sequence is the single-rank step's (+8 us).
+ * Why the host: measured on one MI355X with no collective running (profiles/r04_notes.md; the one-call step: 3.01 ms): a
+ * stream waiting for an event recorded on the busy compute stream costs 0.12 ms per step (the two-call form, phases 1 / 2:
+ * 3.15 ms), a polling kernel resident on a second queue 0.14 ms, hipStreamWaitValue32 on signal memory 1.4 ms; external
+ * event-record nodes are refused in a capture by torch 2.10 on ROCm and a captured RCCL call aborts its watchdog.
+ * Every phase-3 step must be paired with exactly one amt_first_half_wait, issued after it in host order;
+ * amt_first_half_sync (host-synchronous on the step's stream) declares every signal published so far as consumed: call it
+ * after warm-up / rehearsal steps that were not paired with a wait.  amt_first_half_status: waits that timed out. */
+int32_t amt_first_half_wait(amt_ctx* ctx, int32_t timeout_ms);
 int32_t amt_first_half_sync(amt_ctx* ctx, void* stream);
 int32_t amt_first_half_status(amt_ctx* ctx);
 int32_t amt_adamw_step_reduced(amt_ctx* ctx, float lr_base, float layer_lr_decay, float b1, float b2, float eps,

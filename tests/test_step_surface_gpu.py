@@ -263,7 +263,7 @@ def test_in_place_protocol_on_the_models_own_bucket(small_conf):
         assert be.in_place == inplace
         # "signal": ONE launch sequence + the device-side first-half signal (amt_first_half_wait); else the two-call form
         dp = train.DataParallelStep(be, bucket, be.split, dist=None, overlap=mode.endswith("overlap"), graph=True, lr_base=1e-3,
-                                    signal="signal" in mode)
+                                    signal=("signal" in mode) if mode.endswith("overlap") else None)
         assert dp.in_place == inplace and dp.signal == ("signal" in mode)
         dp.prepare(seed=5)
         assert float(bucket.grads.abs().max()) == 0.0 or not inplace      # rehearsal sums were discarded
