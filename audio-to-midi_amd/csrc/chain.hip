@@ -285,7 +285,9 @@ AMT_DEV void block_fwd_tile(const BlockFwdArgs& a_in, const long n0, const long 
 #ifdef AMT_CHAIN_TIMING
   if (!(a.dbg_slot & 512))
 #endif
-  if constexpr (SAVE) chain_copy_out<T, TT, C, LDX>(Xs, reinterpret_cast<T*>(a.Z), n0, N, tid);
+  if constexpr (SAVE) {     // (the training path passes no Z: dgamma comes from the pw2 weight gradient, head.hip: cnn_gamma_finish)
+    if (a.Z != nullptr) chain_copy_out<T, TT, C, LDX>(Xs, reinterpret_cast<T*>(a.Z), n0, N, tid);
+  }
   chain_copy_out<RT, TT, C, LDX>(Rs, reinterpret_cast<RT*>(a.Y), n0, N, tid);
   if constexpr (!TEAM) {   // the LayerNorm the next operator opens with, on the y rows while they are here (kernels.h: TailLn)
     if (a.tail.w != nullptr) {
@@ -531,7 +533,7 @@ bool block_run_fwd(hipStream_t s, DType dt, const BlockRunFwdArgs& r) {
 void block_fwd_fused(hipStream_t s, DType dt, const BlockFwdArgs& a) {
   const double N = (double)a.B * a.L, es = dt == DT_F32 ? 4 : 2;
   const bool save = a.U != nullptr;   // inference passes no save tensors
-  ProfScope ps(s, "block_fwd_fused", 2.0 * N * (7.0 * a.C + 4.0 * a.C * a.C), ((save ? 8.0 : 2.0) * N * a.C + 4.0 * a.C * a.C) * es);
+  ProfScope ps(s, "block_fwd_fused", 2.0 * N * (7.0 * a.C + 4.0 * a.C * a.C), ((save ? (a.Z ? 8.0 : 7.0) : 2.0) * N * a.C + 4.0 * a.C * a.C) * es);
 #define AMT_BF_CASE(CC_)                                                  \
   case CC_:                                                               \
     if (dt == DT_F32) { if (save) block_fwd_fused_launch<float, CC_, true>(s, a); else block_fwd_fused_launch<float, CC_, false>(s, a); }  \
@@ -908,7 +910,7 @@ void block_bwd_fused(hipStream_t s, DType dt, const BlockBwdArgs& a_in, float* d
   a.n_chain = nb;
   const double N = (double)a.B * a.L, es = dt == DT_F32 ? 4 : 2;
   ProfScope ps(s, n_rider_wgs > 0 ? "block_bwd_fused+wgrad" : "block_bwd_fused",
-               2.0 * N * (21.0 * C + 4.0 * C * C) + rfl, (8.0 * N * C + 4.0 * C * C) * es + rby);
+               2.0 * N * (21.0 * C + 4.0 * C * C) + rfl, ((a.Z ? 8.0 : 7.0) * N * C + 4.0 * C * C) * es + rby);
 #define AMT_BB_CASE(CC_)                                                  \
   case CC_:                                                               \
     if (dt == DT_F32) block_bwd_fused_launch<float, CC_>(s, a, rg, n_rider_wgs);   \

@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256, 2) void block_small_fwd_kernel(
     storevf<C>(Y + row * C, y);
     if (save) {
       storevf<C>(LN + row * C, ln);
-      storevf<C>(Z + row * C, z);
+      if (Z != nullptr) storevf<C>(Z + row * C, z);     // (the training path passes none: dgamma comes from the pw2 weight gradient, head.hip: cnn_gamma_finish)
       mean[row] = mu;
       rstd[row] = rs;
     }
@@ -656,18 +656,21 @@ __global__ __launch_bounds__(256, 2) void block_small_fwd_kernel(
       tail.mean[row] = tm;
       tail.rstd[row] = tr;
     }
+    // (Hh: the training path passes none - block_small_bwd_full re-forms h = gelu(u) from u)
     if (!save) {
     } else if constexpr (H2 == 8) {
       storevf<8>(U + row * H2, u);
-      storevf<8>(Hh + row * H2, h);
+      if (Hh != nullptr) storevf<8>(Hh + row * H2, h);
     } else {
       float t0[8], t1[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) { t0[i] = u[i]; t1[i] = u[8 + i]; }
       storevf<8>(U + row * H2, t0); storevf<8>(U + row * H2 + 8, t1);
+      if (Hh != nullptr) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { t0[i] = h[i]; t1[i] = h[8 + i]; }
-      storevf<8>(Hh + row * H2, t0); storevf<8>(Hh + row * H2 + 8, t1);
+        for (int i = 0; i < 8; ++i) { t0[i] = h[i]; t1[i] = h[8 + i]; }
+        storevf<8>(Hh + row * H2, t0); storevf<8>(Hh + row * H2 + 8, t1);
+      }
     }
   }
 }
@@ -728,12 +731,15 @@ __global__ __launch_bounds__(256) void block_small_bwd_kernel(const T* __restric
 //            the interior rows are staged in LDS as [position][16] tiles
 //   phase 2  dX = dY + dwconv^T(dD), depthwise tap / bias sums; the two 1x1-conv weight gradients are
 //            [16 x 16] x 256-position MFMA products of the staged tiles read column-wise (a ones column in the
-//            LN tile yields the pw1 bias gradient)
+//            LN tile yields the pw1 bias gradient).  h = gelu(u) is re-formed from u (the forward stores neither h nor z:
+//            round 4); the pw2 weight / bias gradients leave RAW (not yet scaled by the layer scale) and dgamma is formed
+//            from them afterwards (head.hip: cnn_gamma_finish)
 // Every parameter gradient leaves the kernel as one record per workgroup (reduce_partials sums them).
 template <int C> struct SmallBwd {
   static constexpr int H2 = 2 * C, ROWS = 256, TL = ROWS - 6, FW = 16;
+  // (no layer-scale record: dgamma is formed from the RAW pw2 weight / bias gradients by cnn_gamma_finish, head.hip)
   static constexpr int O_W1 = 0, O_B1 = H2 * C, O_W2 = O_B1 + H2, O_B2 = O_W2 + C * H2, O_LNW = O_B2 + C,
-                       O_LNB = O_LNW + C, O_TAPS = O_LNB + C, O_DWB = O_TAPS + 7 * C, O_G = O_DWB + C, REC = O_G + C;
+                       O_LNB = O_LNW + C, O_TAPS = O_LNB + C, O_DWB = O_TAPS + 7 * C, REC = O_DWB + C;
 };
 
 // ONE: the grid has one workgroup per tile (no tile loop): the per-thread gradient accumulators are then plain
@@ -741,8 +747,8 @@ template <int C> struct SmallBwd {
 // two waves per SIMD (512 workgroups resident at once instead of two rounds of 256).
 template <typename T, int C, bool ONE>
 __global__ __launch_bounds__(256, ONE ? 2 : 1) void block_small_bwd_full_kernel(
-    const T* __restrict__ dY, const Res<T>* __restrict__ X, const T* __restrict__ U, const T* __restrict__ Hh,
-    const T* __restrict__ Z, const T* __restrict__ LNs, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const T* __restrict__ dY, const Res<T>* __restrict__ X, const T* __restrict__ U,
+    const T* __restrict__ LNs, const float* __restrict__ mean, const float* __restrict__ rstd,
     const T* __restrict__ w2tg, const T* __restrict__ w1t, const float* __restrict__ wdw, const float* __restrict__ bdw,
     const float* __restrict__ lnw, const float* __restrict__ gamma, T* __restrict__ dX, float* __restrict__ rec, int B,
     int L, int tiles_per_clip, int total_tiles) {
@@ -765,10 +771,10 @@ __global__ __launch_bounds__(256, ONE ? 2 : 1) void block_small_bwd_full_kernel(
     if (t < C) { sbd[t] = r_bd; slw[t] = r_lw; sg[t] = r_g; }
   }
   const int p = threadIdx.x, lane = p & 63, wave = p >> 6, r = lane & 15, g = lane >> 4;
-  float alw[C], alb[C], ab[C], aw[7][C], ag[C], adb2[C];
+  float alw[C], alb[C], ab[C], aw[7][C], adb2[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    alw[c] = 0.f; alb[c] = 0.f; ab[c] = 0.f; ag[c] = 0.f; adb2[c] = 0.f;
+    alw[c] = 0.f; alb[c] = 0.f; ab[c] = 0.f; adb2[c] = 0.f;
 #pragma unroll
     for (int k = 0; k < 7; ++k) aw[k][c] = 0.f;
   }
@@ -792,15 +798,18 @@ __global__ __launch_bounds__(256, ONE ? 2 : 1) void block_small_bwd_full_kernel(
       const float fin = inner ? 1.f : 0.f, fv = valid ? 1.f : 0.f;
       float t0[8], t1[8];
       loadvf<C>(dY + row * C, dy);
-      {   // h = gelu(u): only an operand tile of the pw2 weight gradient
-        float hh[H2];
-        if constexpr (H2 == 8) {
-          loadvf<8>(Hh + row * H2, hh);
-        } else {
-          loadvf<8>(Hh + row * H2, t0); loadvf<8>(Hh + row * H2 + 8, t1);
+      float u[H2];       // u: GELU' below, and h = gelu(u) - an operand tile of the pw2 weight gradient - re-formed here
+      if constexpr (H2 == 8) {
+        loadvf<8>(U + row * H2, u);
+      } else {
+        loadvf<8>(U + row * H2, t0); loadvf<8>(U + row * H2 + 8, t1);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) { hh[i] = t0[i]; hh[8 + i] = t1[i]; }
-        }
+        for (int i = 0; i < 8; ++i) { u[i] = t0[i]; u[8 + i] = t1[i]; }
+      }
+      {   // (rounded to T exactly as block_small_fwd_kernel forms the h it multiplies with)
+        float hh[H2];
+#pragma unroll
+        for (int j = 0; j < H2; ++j) hh[j] = to_f(from_f<T>(gelu_tanh(u[j])));
 #pragma unroll
         for (int i = 0; i < 8; ++i) { t0[i] = i < H2 ? hh[i] : 0.f; t1[i] = (8 + i) < H2 ? hh[(8 + i) < H2 ? 8 + i : 0] : 0.f; }
         storevf<8>(&h_t[p][0], t0); storevf<8>(&h_t[p][8], t1);
@@ -812,25 +821,16 @@ __global__ __launch_bounds__(256, ONE ? 2 : 1) void block_small_bwd_full_kernel(
         for (int i = 0; i < 8; ++i) { t0[i] = i < C ? ln[i < C ? i : 0] : (i == C ? 1.f : 0.f); t1[i] = (8 + i) == C ? 1.f : 0.f; }
         storevf<8>(&ln_t[p][0], t0); storevf<8>(&ln_t[p][8], t1);
       }
-      {   // z: layer-scale gradient; dy: pw2 bias gradient and operand tile
-        float z[C];
-        loadvf<C>(Z + row * C, z);
+      {   // dy: pw2 bias gradient and operand tile
 #pragma unroll
-        for (int c = 0; c < C; ++c) { adb2[c] += fin * dy[c]; ag[c] += fin * dy[c] * z[c]; }
+        for (int c = 0; c < C; ++c) adb2[c] += fin * dy[c];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { t0[i] = i < C ? fin * dy[i < C ? i : 0] : 0.f; t1[i] = 0.f; }
         storevf<8>(&dy_t[p][0], t0); storevf<8>(&dy_t[p][8], t1);
       }
       float dl[C];
       {
-        float u[H2], du[H2];
-        if constexpr (H2 == 8) {
-          loadvf<8>(U + row * H2, u);
-        } else {
-          loadvf<8>(U + row * H2, t0); loadvf<8>(U + row * H2 + 8, t1);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) { u[i] = t0[i]; u[8 + i] = t1[i]; }
-        }
+        float du[H2];
 #pragma unroll
         for (int j = 0; j < H2; ++j) {
           float a = 0.f;
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(256, ONE ? 2 : 1) void block_small_bwd_full_kernel(
   }
   // ---- one record per workgroup
   __syncthreads();
-  float* red = reinterpret_cast<float*>(smem_raw);     // [4 waves][2][16][16] MFMA sums, then [4][12 C] row sums
+  float* red = reinterpret_cast<float*>(smem_raw);     // [4 waves][2][16][16] MFMA sums, then [4][11 C] row sums
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     red[wave * 512 + (4 * g + e) * 16 + r] = aw1[e];         // [j][n]: n < C pw1 weight, n == C pw1 bias
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256, ONE ? 2 : 1) void block_small_bwd_full_kernel(
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const float v = group_sum<64>(acc[c]);
-      if (lane == 0) red[2048 + wave * 12 * C + slot * C + c] = v;
+      if (lane == 0) red[2048 + wave * 11 * C + slot * C + c] = v;
     }
   };
   fold(alw, 0);
@@ -927,8 +927,7 @@ __global__ __launch_bounds__(256, ONE ? 2 : 1) void block_small_bwd_full_kernel(
 #pragma unroll
   for (int k = 0; k < 7; ++k) fold(aw[k], 2 + k);
   fold(ab, 9);
-  fold(ag, 10);
-  fold(adb2, 11);
+  fold(adb2, 10);
   __syncthreads();
   float* R = rec + (size_t)blockIdx.x * P::REC;
   {
@@ -936,14 +935,14 @@ __global__ __launch_bounds__(256, ONE ? 2 : 1) void block_small_bwd_full_kernel(
     const float v1 = red[p] + red[512 + p] + red[1024 + p] + red[1536 + p];
     const float v2 = red[256 + p] + red[768 + p] + red[1280 + p] + red[1792 + p];
     if (j < H2) {
-      if (n < C) { R[P::O_W1 + j * C + n] = v1; R[P::O_W2 + n * H2 + j] = v2 * sg[n]; }
+      if (n < C) { R[P::O_W1 + j * C + n] = v1; R[P::O_W2 + n * H2 + j] = v2; }      // pw2: RAW (cnn_gamma_finish scales it)
       else if (n == C) R[P::O_B1 + j] = v1;
     }
   }
-  if (p < 12 * C) {
-    const float v = red[2048 + p] + red[2048 + 12 * C + p] + red[2048 + 24 * C + p] + red[2048 + 36 * C + p];
-    if (p < 11 * C) R[P::O_LNW + p] = v;                       // lnw | lnb | taps 7C | dw bias | gamma
-    else R[P::O_B2 + (p - 11 * C)] = v * sg[p - 11 * C];        // pw2 bias (layer scale folded in, like the weight)
+  if (p < 11 * C) {
+    const float v = red[2048 + p] + red[2048 + 11 * C + p] + red[2048 + 22 * C + p] + red[2048 + 33 * C + p];
+    if (p < 10 * C) R[P::O_LNW + p] = v;                       // lnw | lnb | taps 7C | dw bias
+    else R[P::O_B2 + (p - 10 * C)] = v;                         // pw2 bias, RAW
   }
 }
 
@@ -956,7 +955,7 @@ static void block_small_bwd_full_launch(hipStream_t s, const SmallBwdArgs& a, fl
     (void)once;
   }
   hipLaunchKernelGGL((block_small_bwd_full_kernel<T, C, ONE>), dim3(nb), dim3(256), lds, s, (const T*)a.dY, (const Res<T>*)a.X,
-                     (const T*)a.U, (const T*)a.Hh, (const T*)a.Z, (const T*)a.LN, a.mean, a.rstd, (const T*)a.w2tg,
+                     (const T*)a.U, (const T*)a.LN, a.mean, a.rstd, (const T*)a.w2tg,
                      (const T*)a.w1t, a.wdw, a.bdw, a.lnw, a.gamma, (T*)a.dX, rec, a.B, a.L, tiles_per_clip, total);
 }
 template <typename T, int C>
@@ -969,7 +968,7 @@ void block_small_bwd_full(hipStream_t s, DType dt, const SmallBwdArgs& a, Partia
   const int C = a.C, H2 = 2 * C, TL = 250;
   const int tiles_per_clip = (a.L + TL - 1) / TL, total = a.B * tiles_per_clip;
   const int nb = total < 512 ? total : 512;
-  const int REC = 4 * C * C + 14 * C;
+  const int REC = 4 * C * C + 13 * C;
   const size_t o = sink->take((size_t)nb * REC);
   size_t q = o;
   sink->add(q, nb, REC, H2 * C, a.dW1); q += H2 * C;
@@ -979,12 +978,11 @@ void block_small_bwd_full(hipStream_t s, DType dt, const SmallBwdArgs& a, Partia
   sink->add(q, nb, REC, C, a.dlnw); q += C;
   sink->add(q, nb, REC, C, a.dlnb); q += C;
   sink->add(q, nb, REC, 7 * C, a.dwdw); q += 7 * C;
-  sink->add(q, nb, REC, C, a.dbdw); q += C;
-  sink->add(q, nb, REC, C, a.dgamma);
+  sink->add(q, nb, REC, C, a.dbdw);
   if (sink->dry) return;
   float* rec = sink->ws + o;
   const long N = (long)a.B * a.L;
-  ProfScope ps(s, "block_small_bwd_full", 2.0 * N * (7 * C * 2 + 12 * C * C), 9.0 * N * C * (dt == DT_F32 ? 4 : 2));
+  ProfScope ps(s, "block_small_bwd_full", 2.0 * N * (7 * C * 2 + 12 * C * C), 6.0 * N * C * (dt == DT_F32 ? 4 : 2));
   if (dt == DT_F32) {
     if (C == 4) block_small_bwd_full_t<float, 4>(s, a, rec, nb, tiles_per_clip, total);
     else block_small_bwd_full_t<float, 8>(s, a, rec, nb, tiles_per_clip, total);
@@ -1003,7 +1001,7 @@ void block_small_fwd(hipStream_t s, DType dt, const void* X, const float* wdw, c
   TailLn tl{};
   if (tail != nullptr) tl = *tail;
   const bool save = U != nullptr;      // inference passes no save tensors
-  ProfScope ps(s, "block_small_fwd", 2.0 * N * (7 * C + 4 * C * C), (save ? 8.0 : 2.0) * N * C * (dt == DT_F32 ? 4 : 2));
+  ProfScope ps(s, "block_small_fwd", 2.0 * N * (7 * C + 4 * C * C), (save ? 5.0 + (Hh ? 2.0 : 0.0) + (Z ? 1.0 : 0.0) : 2.0) * N * C * (dt == DT_F32 ? 4 : 2));
 #define AMT_LAUNCH_SF(TT, CC_)                                                                                         \
   hipLaunchKernelGGL((block_small_fwd_kernel<TT, CC_>), dim3(grid), dim3(256), 0, s, (const Res<TT>*)X, wdw, bdw, lnw, lnb,  \
                      (const TT*)w1, b1, (const TT*)w2, b2, gamma, (TT*)LN, mean, rstd, (TT*)U, (TT*)Hh, (TT*)Z, (Res<TT>*)Y, \

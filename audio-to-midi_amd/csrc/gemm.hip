@@ -63,7 +63,7 @@ AMT_DEV void epi_apply(const GemmArgs& a, int n, int m, float (&v)[4]) {
     load4f(reinterpret_cast<const Res<T>*>(a.R) + (size_t)n * a.ldr + m, r);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { v[i] = to_f(from_f<T>(v[i])); y[i] = r[i] + a.gamma[m + i] * v[i]; }
-    store4f(reinterpret_cast<T*>(a.Y2) + (size_t)n * a.ldy2 + m, v);
+    if (a.Y2 != nullptr) store4f(reinterpret_cast<T*>(a.Y2) + (size_t)n * a.ldy2 + m, v);
     store4f(reinterpret_cast<Res<T>*>(a.Y) + (size_t)n * a.ldy + m, y);
   } else if constexpr (EPI == EPI_GLU_BWD) {
     // m indexes dg columns j (0..M-1); u lives in the permuted [.. 16 x u1 | 16 x u2 ..] layout

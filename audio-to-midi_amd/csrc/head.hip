@@ -346,6 +346,40 @@ void reduce_partials(hipStream_t s, const PartDesc* descs_dev, int n_desc, const
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_desc, ry), dim3(256), 0, s, descs_dev, ws, grads);
 }
 
+// ------------------------------------------------------------------ layer-scale gradients from the raw pw2 gradients (kernels.h)
+template <typename T>
+__global__ __launch_bounds__(256) void cnn_gamma_finish_kernel(const float* __restrict__ params, float* __restrict__ grads,
+                                                               const GammaDesc* __restrict__ descs, int n_desc, int total_rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= total_rows) return;
+  int i = 0;
+  while (i + 1 < n_desc && row >= descs[i + 1].row0) ++i;      // (39 Blocks: a short scan)
+  const GammaDesc d = descs[i];
+  const int c = row - d.row0, H2 = 2 * d.C;
+  const float g = params[d.gamma + c];
+  const float* w = params + d.w2 + (size_t)c * H2;
+  float* dw = grads + d.w2 + (size_t)c * H2;
+  float acc = 0.f;
+  for (int j = lane; j < H2; j += 64) {
+    const float raw = dw[j];
+    acc += to_f(from_f<T>(w[j])) * raw;       // the weight the forward multiplied with
+    dw[j] = raw * g;
+  }
+  acc = group_sum<64>(acc);
+  if (lane == 0) {
+    const float braw = grads[d.b2 + c];
+    grads[d.gamma + c] = acc + params[d.b2 + c] * braw;
+    grads[d.b2 + c] = braw * g;
+  }
+}
+void cnn_gamma_finish(hipStream_t s, DType dt, const float* params, float* grads, const GammaDesc* descs_dev, int n_desc, int total_rows) {
+  if (n_desc <= 0 || total_rows <= 0) return;
+  ProfScope ps(s, "cnn_gamma_finish", 0, 0);
+  const int grid = (total_rows + 3) / 4;
+  if (dt == DT_F32) hipLaunchKernelGGL(cnn_gamma_finish_kernel<float>, dim3(grid), dim3(256), 0, s, params, grads, descs_dev, n_desc, total_rows);
+  else hipLaunchKernelGGL(cnn_gamma_finish_kernel<bf16>, dim3(grid), dim3(256), 0, s, params, grads, descs_dev, n_desc, total_rows);
+}
+
 // ------------------------------------------------------------------ AdamW
 // The step is gated on DEVICE flags so that it stays graph-capturable and free of host syncs: gate_i = the int32
 // all-finite flag of amt_forward_backward, gate_f = the same flag after a mean / sum-and-scale all-reduce (1.0 iff every

@@ -111,12 +111,13 @@ void stem_bwd(hipStream_t s, DType dt, const void* audio, const void* dY, const 
 // `sink`, every parameter gradient of the Block (pw1 / pw2 weights + biases with the layer scale folded into pw2's,
 // LayerNorm, depthwise taps + bias, gamma).  Pointers d* are the destinations inside the gradient buffer.
 struct SmallBwdArgs {
-  const void *dY, *X /* Res */, *U, *Hh, *Z, *LN;
+  const void *dY, *X /* Res */, *U, *LN;      // (h = gelu(u) is re-formed from u; no z: see dgamma below)
   const float *mean, *rstd;
   const void *w2tg, *w1t;
   const float *wdw, *bdw, *lnw, *gamma;
   void* dX;
-  float *dW1, *db1, *dW2, *db2, *dlnw, *dlnb, *dwdw, *dbdw, *dgamma;
+  // dW2 / db2 leave RAW (without the layer scale): cnn_gamma_finish forms dgamma from them and scales them afterwards
+  float *dW1, *db1, *dW2, *db2, *dlnw, *dlnb, *dwdw, *dbdw;
   int B, L, C;
 };
 void block_small_bwd_full(hipStream_t s, DType dt, const SmallBwdArgs& a, PartialSink* sink);
@@ -359,6 +360,17 @@ void copy_f32(hipStream_t s, const float* src, float* dst, size_t n);
 void scale_copy_f32(hipStream_t s, const float* src, float* dst, size_t n, float mul);   // dst = src * mul (small vectors)
 // dst[0..n) = src, dst[n..n_pad) = 0 in one launch
 void copy_pad_f32(hipStream_t s, const float* src, float* dst, size_t n, size_t n_pad);
+
+// Layer scale of the CNN Blocks (model.py:157-158, 166: y = x + gamma * z, z = W2 h + b2) without saving z:
+//   dgamma[c] = sum_n dy[n][c] z[n][c] = sum_j W2[c][j] (sum_n dy[n][c] h[n][j]) + b2[c] sum_n dy[n][c]
+//             = < W2[c][:], dW2raw[c][:] > + b2[c] db2raw[c]
+// i.e. a dot product with the pw2 weight gradient BEFORE its own scaling by gamma.  The weight-gradient launches leave
+// dW2raw / db2raw in the gradient buffer; this pass (one launch for all Blocks, at the end of the backward pass) writes
+// dgamma and scales the rows in place (dW2 = gamma dW2raw, db2 = gamma db2raw).  W2 is taken as the activation type's
+// rounding of the fp32 master - the value the forward multiplied with.  Round 4: the forward stores one tensor less per
+// Block (z: 2 of 14.3 MB per C = 128 launch) and the backward reads one less.
+struct GammaDesc { uint64_t w2, b2, gamma; int C; int row0; };      // flat offsets (params and gradients share the layout); first row index
+void cnn_gamma_finish(hipStream_t s, DType dt, const float* params, float* grads, const GammaDesc* descs_dev, int n_desc, int total_rows);
 
 // AdamW (optax.adamw) on the flat parameter vector with per-segment learning rates
 // pass 1: update m, v, write the (unclipped) update into upd, accumulate sum(upd^2) into norm2[0]

@@ -341,6 +341,8 @@ struct amt_ctx {
   TeamState* team = nullptr;    // XCD-team protocol words (team.h); null: team launches disabled (AMT_TEAM=0)
   // run_backward phase 3 ("first half complete" published from inside the launch sequence): the counter, its mapped host
   // copy, and the host's bookkeeping of the value the next wait expects
+  GammaDesc* gamma_desc_dev = nullptr;     // one entry per CNN Block (kernels.h: cnn_gamma_finish)
+  int n_gamma_desc = 0, gamma_rows = 0;
   unsigned* half_sig = nullptr;            // device counter of published signals
   volatile unsigned* half_host = nullptr;  // the same count in mapped host memory (what amt_first_half_wait polls)
   unsigned* half_host_dev = nullptr;       // ... its device address
@@ -512,7 +514,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
         bs.rstd = (float*)A.alloc((size_t)N * sizeof(float));
         bs.u = A.alloc((size_t)N * 2 * C * es);
         bs.h = A.alloc((size_t)N * 2 * C * es);
-        bs.z = A.alloc((size_t)N * C * es);
+        bs.z = nullptr;      // not saved: dgamma comes from the raw pw2 weight gradient (kernels.h: cnn_gamma_finish)
         void* y = out_buf((size_t)N * C);
         BlockRunFwdItem& it = ra.it[j];
         it.W1 = c->WC(bp.c_pw1p); it.W2 = c->WC(bp.c_pw2p); it.wdw = c->P(bp.dw_w); it.bdw = c->P(bp.dw_b);
@@ -538,8 +540,12 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
       bs.mean = (float*)A.alloc((size_t)N * sizeof(float));
       bs.rstd = (float*)A.alloc((size_t)N * sizeof(float));
       bs.u = A.alloc((size_t)N * 2 * C * es);
-      bs.h = A.alloc((size_t)N * 2 * C * es);
-      bs.z = A.alloc((size_t)N * C * es);
+      // h = gelu(u): an operand of the pw2 weight gradient - re-formed from u by the one-launch small-C backward, read from
+      // memory by the weight-gradient riders of the wider Blocks.  z: saved by nobody since round 4 (dgamma comes from the
+      // raw pw2 weight gradient, kernels.h: cnn_gamma_finish): 7 -> 6 (4 for C <= 8) stored tensors of N C elements per Block
+      const bool small_full = C <= 8 && c->fuse && !(c->nochain & 512);
+      bs.h = small_full ? nullptr : A.alloc((size_t)N * 2 * C * es);
+      bs.z = nullptr;
       TailLn tl{};
       if (tail_ln && j + 1 == st.blocks.size() && (C <= 8 || !(c->nochain & 1))) {
         if (si + 1 < cfg.n_stages) {          // the next stage's Downsample norm
@@ -1152,11 +1158,11 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
         void* dx = late_mode ? keep_alloc((size_t)Nn * C * es) : dbuf[di];
         SmallBwdArgs sa;
         memset(&sa, 0, sizeof(sa));
-        sa.dY = dy; sa.X = bs.x; sa.U = bs.u; sa.Hh = bs.h; sa.Z = bs.z; sa.LN = bs.ln; sa.mean = bs.mean; sa.rstd = bs.rstd;
+        sa.dY = dy; sa.X = bs.x; sa.U = bs.u; sa.LN = bs.ln; sa.mean = bs.mean; sa.rstd = bs.rstd;
         sa.w2tg = c->WC(bp.c_pw2tg); sa.w1t = c->WC(bp.c_pw1t); sa.wdw = c->P(bp.dw_w); sa.bdw = c->P(bp.dw_b);
         sa.lnw = c->P(bp.ln_w); sa.gamma = c->P(bp.gamma); sa.dX = dx;
         sa.dW1 = G(bp.pw1_w); sa.db1 = G(bp.pw1_b); sa.dW2 = G(bp.pw2_w); sa.db2 = G(bp.pw2_b); sa.dlnw = G(bp.ln_w);
-        sa.dlnb = G(bp.ln_b); sa.dwdw = G(bp.dw_w); sa.dbdw = G(bp.dw_b); sa.dgamma = G(bp.gamma);
+        sa.dlnb = G(bp.ln_b); sa.dwdw = G(bp.dw_w); sa.dbdw = G(bp.dw_b);
         sa.B = B; sa.L = Lcur; sa.C = C;
         block_small_bwd_full(s, dt, sa, &sink);
         dcur = dx;
@@ -1164,10 +1170,10 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
         end_scope();
         continue;
       }
-      // layer scale folded away: dz = gamma * dy is never materialised.  The data-gradient GEMM uses a
-      // gamma-scaled copy of pw2^T, the pw2 weight/bias gradients are row-scaled in their epilogue
-      // and dgamma = sum dy * z is formed in the fused tail kernel.
-      wgrad(dy, C, bs.h, 2 * C, Nn, C, 2 * C, bp.pw2_w, 2 * C, (long)bp.pw2_b, 0, c->P(bp.gamma));
+      // layer scale folded away: dz = gamma * dy is never materialised.  The data-gradient GEMM uses a gamma-scaled copy of
+      // pw2^T; the pw2 weight / bias gradients are accumulated RAW (sum dy h, sum dy) and cnn_gamma_finish, at the end of
+      // the pass, forms dgamma = <W2, dW2raw> + b2 db2raw from them and scales them by gamma (kernels.h): no z anywhere.
+      wgrad(dy, C, bs.h, 2 * C, Nn, C, 2 * C, bp.pw2_w, 2 * C, (long)bp.pw2_b, 0);
       void* du = late_mode ? keep_alloc((size_t)Nn * 2 * C * es) : A.alloc((size_t)Nn * 2 * C * es);
       if (c->fuse && C >= 16 && !(c->nochain & 2)) {
         wgrad(du, 2 * C, bs.ln, C, Nn, 2 * C, C, bp.pw1_w, C, (long)bp.pw1_b, 0);
@@ -1175,10 +1181,10 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
         void* dx = late_mode ? keep_alloc((size_t)Nn * C * es) : dbuf[di];   // late: the next Block's dy operand must survive
         BlockBwdArgs ba;
         memset(&ba, 0, sizeof(ba));
-        ba.dY = dy; ba.X = bs.x; ba.U = bs.u; ba.Z = bs.z; ba.W2tg = c->WC(bp.c_pw2tgp); ba.W1t = c->WC(bp.c_pw1tp);
+        ba.dY = dy; ba.X = bs.x; ba.U = bs.u; ba.Z = nullptr; ba.W2tg = c->WC(bp.c_pw2tgp); ba.W1t = c->WC(bp.c_pw1tp);
         ba.wdw = c->P(bp.dw_w); ba.bdw = c->P(bp.dw_b); ba.lnw = c->P(bp.ln_w); ba.mean = bs.mean; ba.rstd = bs.rstd;
         ba.dU = du; ba.dX = dx; ba.B = B; ba.L = Lcur; ba.C = C; ba.dbg_slot = 64 + dbg_bwd++;
-        block_bwd_fused(s, dt, ba, G(bp.ln_w), G(bp.ln_b), G(bp.dw_w), G(bp.dw_b), G(bp.gamma), &sink,
+        block_bwd_fused(s, dt, ba, G(bp.ln_w), G(bp.ln_b), G(bp.dw_w), G(bp.dw_b), nullptr, &sink,
                         deferred.data(), (int)deferred.size());
         deferred.clear();
         dcur = dx;
@@ -1199,8 +1205,8 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       wgrad(du, 2 * C, bs.ln, C, Nn, 2 * C, C, bp.pw1_w, C, (long)bp.pw1_b, 0);
       di = (di + 1) % 4;
       void* dx = late_mode ? keep_alloc((size_t)Nn * C * es) : dbuf[di];
-      dwblock_bwd(s, dt, dln, bs.x, dy, bs.z, c->P(bp.dw_w), c->P(bp.dw_b), bs.mean, bs.rstd, c->P(bp.ln_w), dx,
-                  G(bp.ln_w), G(bp.ln_b), G(bp.dw_w), G(bp.dw_b), G(bp.gamma), B, Lcur, C, &sink);
+      dwblock_bwd(s, dt, dln, bs.x, dy, nullptr, c->P(bp.dw_w), c->P(bp.dw_b), bs.mean, bs.rstd, c->P(bp.ln_w), dx,
+                  G(bp.ln_w), G(bp.ln_b), G(bp.dw_w), G(bp.dw_b), nullptr, B, Lcur, C, &sink);
       dcur = dx;
       signal_first_half();
       end_scope();
@@ -1247,9 +1253,12 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   c->part_total = sink.off;
   if (phase == 2 || phase == 3) {
     RUN(reduce_partials(s, c->part_desc_dev + c->n_part_desc_half, c->n_part_desc - c->n_part_desc_half, c->partials, grads));
+    if (acc_last) RUN(cnn_gamma_finish(s, dt, c->params, grads, c->gamma_desc_dev, c->n_gamma_desc, c->gamma_rows));
     if (acc_last && grads_out != nullptr) RUN(grads_finalize(s, grads, grads_out, L.fn_w, out_mul, grads_valid));
   } else {
     RUN(reduce_partials(s, c->part_desc_dev, c->n_part_desc, c->partials, grads));
+    // layer-scale gradients from the raw pw2 gradients, which it then scales (kernels.h); once, over the accumulated sums
+    if (acc_last) RUN(cnn_gamma_finish(s, dt, c->params, grads, c->gamma_desc_dev, c->n_gamma_desc, c->gamma_rows));
     if (acc_last && grads_out != nullptr) RUN(grads_finalize(s, grads, grads_out, L.n_params, out_mul, grads_valid));
   }
   // keep the fused protocol's invariant (accumulator clean between steps) when the two protocols are mixed on one context
@@ -1504,6 +1513,21 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
     for (size_t o : {l0.ln1_b, l0.wqc, l0.wkv, l0.wo, l0.ln2_w, l0.ln2_b, l0.w1, l0.b1, l0.w2, l0.b2}) a0 = o < a0 ? o : a0;
     c->gacc_pad = 64 + (int)((64 - a0 % 64) % 64);
   }
+  {
+    std::vector<GammaDesc> gd;
+    int row0 = 0;
+    for (const StageP& st : L.stages)
+      for (const BlockP& b : st.blocks) {
+        gd.push_back(GammaDesc{b.pw2_w, b.pw2_b, b.gamma, st.C, row0});
+        row0 += st.C;
+      }
+    c->n_gamma_desc = (int)gd.size();
+    c->gamma_rows = row0;
+    if (!gd.empty()) {
+      if ((he = hipMalloc(reinterpret_cast<void**>(&c->gamma_desc_dev), gd.size() * sizeof(GammaDesc))) != hipSuccess) return fail("hipMalloc", he);
+      (void)hipMemcpy(c->gamma_desc_dev, gd.data(), gd.size() * sizeof(GammaDesc), hipMemcpyHostToDevice);
+    }
+  }
   std::vector<int> prefix(L.conv.size() + 1, 0);
   for (size_t i = 0; i < L.conv.size(); ++i)
     prefix[i + 1] = prefix[i] + ((L.conv[i].rows + 31) / 32) * ((L.conv[i].cols + 63) / 64);   // head.hip: convert_batch_kernel tiles
@@ -1521,7 +1545,7 @@ void amt_destroy(amt_ctx* c) {
   (void)hipSetDevice(c->device);
   void* ptrs[] = {c->params, c->wc, c->head_bias, c->conv_dev, c->conv_prefix_dev, c->rope_cos, c->rope_sin,
                   c->arena.base, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, c->norm2, c->loss_acc,
-                  c->partials, c->amax, c->gacc, c->team, c->seed_word, c->lr_idx, c->lr_tab, c->half_sig};
+                  c->partials, c->amax, c->gacc, c->team, c->seed_word, c->lr_idx, c->lr_tab, c->half_sig, c->gamma_desc_dev};
   if (c->half_host) { (void)hipDeviceSynchronize(); (void)hipHostFree(const_cast<unsigned*>(c->half_host)); }
   for (const amt_ctx::PlanRec& r : c->plans)
     if (r.desc_dev) (void)hipFree(r.desc_dev);
