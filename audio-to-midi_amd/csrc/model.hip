@@ -847,6 +847,12 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   // work of scope j-2 before it reuses that scope's region / buffer.
   const bool side_on = c->use_side && c->side != nullptr;
   hipStream_t ws = side_on ? c->side : s;
+  // Riders are a small-N device: they fill the compute units a chain's ~250 workgroups leave idle.  From ~8 000 tokens on
+  // the chains fill the chip themselves, a rider only delays its carrier, and the weight gradients run better as grouped
+  // launches of their own: at 32 clips per GPU 8.59 -> 8.38 ms from taking the riders out, 8.25 with 512 workgroups per
+  // grouped launch (profiles/r04_notes.md).  AMT_RIDER_MAX_TOKENS moves the switch (0: riders at every size).
+  static const long rider_max_tokens = getenv("AMT_RIDER_MAX_TOKENS") ? atol(getenv("AMT_RIDER_MAX_TOKENS")) : 8192;
+  const bool no_riders = rider_max_tokens > 0 && (long)B * (T / 320) >= rider_max_tokens;
   std::vector<hipEvent_t> side_done;
   size_t mark = 0;
   size_t scratch_used = 0;
@@ -861,10 +867,14 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   // The buffers they read stay valid for exactly one more scope (two alternating scratch regions,
   // four rotating residual-gradient buffers; "pass" scopes below stretch it by one short scope).
   std::vector<WgradArgs> deferred;
+  // (without riders the grouped launches have the chip to themselves: 512 workgroups - two per compute unit - instead of the
+  // 336 that suit a launch shared with a chain; at 32 clips per GPU 336 / 512 / 768: 8.38 / 8.25 / 8.56 ms, profiles/r04_notes.md)
+  static const int flush_target_big = getenv("AMT_WGRAD_TARGET_LARGE") ? atoi(getenv("AMT_WGRAD_TARGET_LARGE")) : 512;
   auto flush_deferred = [&]() {
     for (size_t i = 0; i < deferred.size(); i += 8) {
       int cnt = (int)std::min<size_t>(8, deferred.size() - i);
-      gemm_tn_wgrad_group(s, dt, deferred.data() + i, cnt, &sink);
+      if (no_riders && cnt > 1) gemm_tn_wgrad_group(s, dt, deferred.data() + i, cnt, &sink, flush_target_big);
+      else gemm_tn_wgrad_group(s, dt, deferred.data() + i, cnt, &sink);
     }
     deferred.clear();
   };
@@ -995,7 +1005,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
                           cfg.kv_compress == 64;
     // the two backward chain launches of this layer carry the previous scope's weight gradients: the
     // smaller problems ride on lnout_bwd_fused, the larger ones on qkv_bwd_fused
-    begin_scope(chain_ok && !side_on && !(c->nochain & 128));
+    begin_scope(chain_ok && !side_on && !(c->nochain & 128) && !no_riders);
     std::vector<WgradArgs> riders_a, riders_b;
     for (const WgradArgs& w : deferred) {
       const int tiles = ((w.M + 63) / 64) * ((w.Kp + 63) / 64);
@@ -1149,7 +1159,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     for (int j = (int)st.blocks.size() - 1; j >= 0; --j) {
       const BlockP& bp = st.blocks[j];
       const BlockSave& bs = sv.blocks[j];
-      const bool carrier = c->fuse && C >= 16 && !side_on && !(c->nochain & 2) && !(c->nochain & 64);
+      const bool carrier = c->fuse && C >= 16 && !side_on && !(c->nochain & 2) && !(c->nochain & 64) && !no_riders;
       begin_scope(carrier);
       const void* dy = dcur;
       if (C <= 8 && c->fuse && !(c->nochain & 512)) {
@@ -1346,13 +1356,31 @@ int plan(amt_ctx* c, int B, int T, int train_mode, hipStream_t s) {
     c->arena.base = nullptr;
     c->arena.cap = 0;
     c->plan_gen++;                      // graphs captured earlier hold pointers into the old arena
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->arena.base), need));
+    const hipError_t ea = hipMalloc(reinterpret_cast<void**>(&c->arena.base), need);
+    if (ea != hipSuccess) {             // the plan is NOT recorded: give its descriptors back and point at no plan
+      if (rec.desc_dev) (void)hipFree(rec.desc_dev);
+      c->part_desc_dev = nullptr;
+      c->n_part_desc = c->n_part_desc_half = 0;
+      c->plan_B = c->plan_T = 0; c->plan_train = -1;
+      c->err = std::string("hipMalloc(workspace): ") + hipGetErrorString(ea);
+      return 1;
+    }
     c->arena.cap = need;
   }
   // the record is kept only now that every allocation it describes exists: after a failed hipMalloc above the next
   // call for this shape plans again and reports the out-of-memory error instead of running in a missing workspace
-  for (auto it = c->plans.begin(); it != c->plans.end();)
-    it = (it->B == B && it->T == T && it->train == train_mode) ? c->plans.erase(it) : it + 1;
+  for (auto it = c->plans.begin(); it != c->plans.end();) {
+    if (it->B == B && it->T == T && it->train == train_mode) {
+      if (it->desc_dev && it->desc_dev != rec.desc_dev) {     // an older plan of the same shape: its descriptors go with it
+        (void)hipDeviceSynchronize();                          // (a graph captured for it may still be replaying them)
+        (void)hipFree(it->desc_dev);
+        c->plan_gen++;
+      }
+      it = c->plans.erase(it);
+    } else {
+      ++it;
+    }
+  }
   c->plans.push_back(rec);
   c->arena.off = 0;
   c->arena.peak = 0;

@@ -217,6 +217,11 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
   }
 }
 
+// (Round 4 built a large-N form of this body - 128 x 128 and 128 x 64 output tiles, each wave a 64 x 64 quadrant, two MFMAs
+// per column-fragment read - and measured it SLOWER at every shape of the 32-clip step: W1 (16 000 x 1024 x 256) 36.9 against
+// 35.4 us, the C = 128 Block pair 24.5 against 15.5 us, the grouped launches 57 against 39 us; with few, large tiles a launch
+// needs more token splits to fill the chip, every split adds its whole tile with atomics, and a workgroup is a serial chain
+// of ~35 stage latencies either way.  Removed again; numbers in profiles/r04_notes.md.)
 // several independent weight-gradient problems in one grid: b -> (problem, tile, token split)
 template <typename T>
 AMT_DEV void wgrad_group_dispatch(const WgradGroup& g, int b, unsigned char* smem) {
@@ -236,5 +241,4 @@ AMT_DEV void wgrad_group_dispatch(const WgradGroup& g, int b, unsigned char* sme
   }
   tn_body<T>(g.p[i], g.tiles_k[i], g.rps[i], local % g.tiles[i], local / g.tiles[i], smem);
 }
-
 }  // namespace amt

@@ -162,7 +162,9 @@ def test_gemm_glu_fwd_bwd(dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,M,Kp,mstore", [(500, 64, 64, 0), (4000, 320, 256, 0), (1000, 96, 256, 90), (3000, 8, 4, 0),
-                                           (3000, 4, 8, 0), (777, 1024, 256, 0), (129, 512, 64, 0), (20000, 16, 8, 0)])
+                                           (3000, 4, 8, 0), (777, 1024, 256, 0), (129, 512, 64, 0), (20000, 16, 8, 0),
+                                           # the 32-clip sizes (token splits capped at 48, ragged last stage)
+                                           (9001, 320, 256, 0), (16000, 1024, 256, 0)])
 def test_gemm_tn_wgrad(dtype, N, M, Kp, mstore):
     rng = np.random.default_rng(N + M)
     G = rounded(rng.standard_normal((N, M)), dtype)

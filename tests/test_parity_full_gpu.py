@@ -150,15 +150,22 @@ def _margin_mixed_track(st_ref, st_dev, m):
     return np.where(near, st_dev, st_ref), near
 
 
-@pytest.mark.parametrize("head_bias", [0.0, -6.0])
+# per track: (bound on the margin m, bound on the share of cells inside the margin, least unfiltered agreement, least events)
+EVENT_BOUNDS = {0.0: (3.0e-2, 0.65, 0.95, 1000), -3.0: (3.0e-2, 0.45, 0.95, 100), -6.0: (3.0e-2, 0.20, 0.95, 20)}
+
+
+@pytest.mark.parametrize("head_bias", [0.0, -3.0, -6.0])
 def test_bf16_events_are_bit_exact_outside_the_bf16_margin(tmp_path, head_bias):
     """BASELINE north_star "bit-exact MIDI events", production dtype: WAV -> windows -> bf16 model ->
     stitch -> extract_events against the float64 oracle + the Python restatement of common.rs.  The margin is DERIVED:
-    m = the measured max |p_bf16 - p_f64| on the stitched track (asserted <= 6e-2: the head weights are scaled x 6 to spread
-    the sigmoids, which scales the 4e-2 logit error of the bf16 network to 0.24; measured 4.9e-2).  Events of the device
-    track equal, bit for bit, the events of the oracle track with the undecidable cells (see _margin_mixed_track) taken
-    from the device.  Without any filter the two event lists share > 90 % of their events on the dense track (head bias 0:
-    4200 events in 700 frames, every key flickering: the worst case for a threshold detector) and more on the sparse one."""
+    m = the measured max |p_bf16 - p_f64| on the stitched track (the head weights are scaled x 6 to spread the sigmoids, which
+    scales the logit error by 6 as well).  Round 3: m = 4.9e-2 (asserted <= 6e-2), 75-81 % of the dense track's cells inside
+    the margin.  Round 4 (residual stream and audio in fp16, csrc/common.h: Res<T>): m = 2.4e-2 / 2.1e-2, asserted <= 3e-2;
+    57 % of the cells of the dense track (head bias 0: 4200 events in 700 frames, every key flickering around the
+    thresholds - the worst case for a threshold detector), 12 % of the sparse one (bias -6) inside the margin; a third track
+    in between (bias -3).  Events of the device track equal, bit for bit, the events of the oracle track with the
+    undecidable cells (see _margin_mixed_track) taken from the device; without any filter the two event lists share >= 95 %
+    of their events on every track (measured 97 %)."""
     import wave
     from audio_to_midi_amd import infer
     conf = np_model.MODEL_CONFIG
@@ -178,18 +185,17 @@ def test_bf16_events_are_bit_exact_outside_the_bf16_margin(tmp_path, head_bias):
     pt = torch_model.to_torch(bf16_round_gemm_weights(params), torch.float64)
     _, probs_ref = torch_model.forward(pt, torch.from_numpy(windows).double(), conf)
     st_ref = opost.stitch_probs(probs_ref.numpy().astype(np.float32), 0.5, dpf)
+    m_max, near_max, agree_min, n_min = EVENT_BOUNDS[head_bias]
     m = float(np.abs(stitched - st_ref).max())
-    assert m <= 6e-2, m
+    assert m <= m_max, m
     mixed, near = _margin_mixed_track(st_ref, stitched, m)
     ev_mixed = opost.extract_events(mixed.astype(np.float32))
-    assert len(events) > (1000 if head_bias == 0.0 else 20)
+    assert len(events) > n_min
     assert events == ev_mixed
     ev_ref = opost.extract_events(st_ref)
     common = len(set(events) & set(ev_ref))
-    assert common >= 0.9 * max(len(ev_ref), len(events)), (common, len(ev_ref), len(events))
+    assert common >= agree_min * max(len(ev_ref), len(events)), (common, len(ev_ref), len(events))
     # how much of the track is decided by the oracle alone (the numbers are in DESIGN.md; a weak bound here)
     print(f"bf16 events, head bias {head_bias}: margin {m:.3e}, cells within the margin {near.mean():.3f}, events {len(events)} "
           f"(oracle {len(ev_ref)}, identical without any filter {common})")
-    # measured: 75 % of the cells of the dense track (every key flickers around the thresholds) and 18 % of the sparse one
-    # sit inside the margin of some decision
-    assert near.mean() < (0.85 if head_bias == 0.0 else 0.3), near.mean()
+    assert near.mean() < near_max, near.mean()
