@@ -329,7 +329,7 @@ class DataParallelStep:
     graph, so replays draw fresh masks."""
 
     def __init__(self, backend, bucket: GradBucket, split: int, dist=None, overlap: bool = False, graph: bool = True,
-                 lr_base: float = 1e-4, signal: Optional[bool] = None):
+                 lr_base: float = 1e-4, signal: Optional[bool] = None, wire: str = "fp32"):
         self.backend, self.bucket, self.split, self.dist = backend, bucket, int(split), dist
         self.world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
         # in-place protocol (HipTrainBackend(fused=True) over GradBucket.of_model): the collectives are SUMs over the
@@ -352,6 +352,17 @@ class DataParallelStep:
         if self.world >= 1000:
             raise ValueError("the device-side optimizer gate (mean flag >= 0.999) supports fewer than 1000 ranks")
         self.overlap = bool(overlap)
+        # wire = "bf16": the gradients cross the links as bfloat16 - 23.2 MB per rank and direction, the size of the
+        # reference's own message (XLA reduces the fp16 outputs of the backward pass, /root/reference/train.py:292-297 casts
+        # AFTER the reduction point) - with fp32 ACCUMULATION ON ARRIVAL: an all-to-all of bf16 shards (every rank receives
+        # shard r of every rank), a local fp32 sum, an all-gather of the reduced shards as bf16.  On a fully connected xGMI
+        # node both steps use all seven links at once and move 2 x 7/8 x 23.2 MB per rank against 2 x 7/8 x 46.4 MB for the
+        # fp32 all-reduce.  The loss word travels in fp32 (a 4-byte all-reduce).  Opt-in; "fp32" (one all-reduce per range)
+        # is the default.  NOT measured on hardware (no multi-GPU node in rounds 1-4); covered under gloo.
+        if wire not in ("fp32", "bf16"):
+            raise ValueError("wire must be 'fp32' or 'bf16'")
+        self.wire = wire
+        self._wire_buf = {}
         self.lr_base = lr_base
         self.cuda = bucket.buf.is_cuda
         self.graph = bool(graph) and self.cuda
@@ -369,8 +380,42 @@ class DataParallelStep:
             self._avg = self.dist.ReduceOp.AVG if self.dist.get_backend() == "nccl" else None
 
     # ---- collectives -------------------------------------------------------------------------------
+    def _reduce_bf16_wire(self, t: torch.Tensor, mean: bool):
+        """SUM (or mean) of the fp32 range ``t`` over the ranks, in place, with bfloat16 on the wire and fp32 accumulation
+        on arrival (see ``wire`` in __init__)."""
+        W, n = self.world, t.numel()
+        m = (n + W - 1) // W
+        key = (t.data_ptr(), n)
+        if key not in self._wire_buf:
+            self._wire_buf[key] = (torch.zeros(m * W, dtype=torch.bfloat16, device=t.device),
+                                   torch.empty(m * W, dtype=torch.bfloat16, device=t.device),
+                                   torch.empty(m * W, dtype=torch.bfloat16, device=t.device))
+        send, recv, out = self._wire_buf[key]
+        send[:n].copy_(t)                                              # fp32 -> bf16 (round to nearest even)
+        self.dist.all_to_all_single(recv, send)                        # recv[k m : (k + 1) m] = rank k's copy of MY shard
+        red = recv.view(W, m).to(torch.float32).sum(0)                 # fp32 accumulation on arrival
+        if mean:
+            red.mul_(1.0 / W)
+        self.dist.all_gather_into_tensor(out, red.to(torch.bfloat16))  # every rank gets every reduced shard (identical bits)
+        t.copy_(out[:n])
+
     def _mean_allreduce(self, t: torch.Tensor):
         if self.dist is None or not self.dist.is_initialized():
+            return
+        if self.wire == "bf16" and self.world > 1:
+            # the control / loss words of the range keep fp32: they sit at its ends (GradBucket layout)
+            b = self.bucket
+            lo, hi = t.data_ptr(), t.data_ptr() + 4 * t.numel()
+            g0, g1 = b.grads.data_ptr(), b.grads.data_ptr() + 4 * b.n
+            i0, i1 = max(lo, g0), min(hi, g1)
+            head, body, tail = t[:(i0 - lo) // 4], t[(i0 - lo) // 4:(i1 - lo) // 4], t[(i1 - lo) // 4:]
+            for ctl in (head, tail):
+                if ctl.numel():
+                    self.dist.all_reduce(ctl, op=self.dist.ReduceOp.SUM)
+                    if not self.in_place:
+                        ctl.mul_(1.0 / self.world)
+            if body.numel():
+                self._reduce_bf16_wire(body, mean=not self.in_place)
             return
         if self.in_place:          # raw sums: 1 / world is applied by the optimizer (and by result() to the loss)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)

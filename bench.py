@@ -208,7 +208,16 @@ def dominant_roofline(top, profile_steps):
             log(f"roofline: profiles/pmc_traffic_by_class.json is from build {pj.get('_build_id')}, this is {bid}: traffic = null")
     except OSError:
         pass
-    common = {"kernel": name, "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2),
+    # matrix-pipe duty cycle of the class from a committed rocprofv3 SQ pass of THIS build (profiles/make_mfma.py)
+    mfma_busy = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_mfma_by_class.json")) as f:
+            mj = json.load(f)
+        if mj.get("_build_id") == bid:
+            mfma_busy = mj.get(name, {}).get("mfma_busy_of_chip")
+    except OSError:
+        pass
+    common = {"kernel": name, "traffic": traffic, "mfma_busy": mfma_busy, "avg_launch_us": round(avg_s * 1e6, 2),
               "timing": "HIP events around eager launches (graph replay is shorter; see avg_launch_us_graph)",
               "avg_launch_us_graph": graph_us, "rocprof_stats": stats_file, "build_id": bid,
               "flops_per_launch": flops_l, "design_bytes_per_launch": design_l,
@@ -350,6 +359,9 @@ def main():
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-fused-optimizer", action="store_true",
                     help="N = 1: write the unscaled gradients to the bucket and run the three-pass optimizer (the N > 1 form)")
+    ap.add_argument("--wire", choices=["fp32", "bf16"], default="fp32",
+                    help="N > 1: gradient wire format - fp32 all-reduce (default) or bfloat16 shards with fp32 accumulation on "
+                         "arrival (the reference's message size; audio_to_midi_amd.train.DataParallelStep)")
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: one all-reduce after the whole backward pass instead of the two-bucket overlap")
@@ -431,7 +443,7 @@ def main():
     # finite check and the clip are all still computed, train.py:319-325)
     backend = amt_train.HipTrainBackend(model, audio, labels, bucket, scale=1.0, use_optimizer=not args.no_optimizer, fused=fused)
     dp = amt_train.DataParallelStep(backend, bucket, backend.split, dist=dist, overlap=overlap, graph=not args.no_graph,
-                                    lr_base=1e-4, signal=False if args.no_signal else None)
+                                    lr_base=1e-4, signal=False if args.no_signal else None, wire=args.wire)
     dp.prepare(seed=12345)       # every allocation (optimizer state, workspace plan) happens before graph capture
     graph = dp._graphs
     # A fresh batch per step (train.py:280: the reference uploads every minibatch): four distinct pinned host batches in
@@ -540,7 +552,8 @@ def main():
                        "global_batch": world * B_PER_GPU, "clip_seconds": CLIP_SECONDS, "frames": T_SAMPLES // 320,
                        "parallelism": f"dp{world}", "hipgraph": graph is not None,
                        "grad_allreduce": ((("two collectives, the first overlapped with the CNN backward" + (" behind a device-side signal of ONE launch sequence" if dp.signal else " (step cut in two host calls)")) if overlap else "one bucket")
-                                          + (" (SUM, in place on the context's accumulator; 1 / world in the optimizer)" if fused else " (ReduceOp.AVG on a separate bucket)")) if world > 1 or overlap else None,
+                                          + (" (SUM, in place on the context's accumulator; 1 / world in the optimizer)" if fused else " (ReduceOp.AVG on a separate bucket)")
+                                          + ("; bf16 on the wire, fp32 accumulation on arrival" if args.wire == "bf16" else "")) if world > 1 or overlap else None,
                        "optimizer": None if args.no_optimizer else ("fused: norm pass + commit pass over the context's gradient accumulator" if fused else "grads_finalize + adamw_compute + adamw_apply over the bucket"),
                        "weights": "random init (Equinox distributions), 11606230 params"},
             "model_tflops": round(world * FLOPS_PER_STEP / (elapsed / args.steps) / 1e12, 2),
