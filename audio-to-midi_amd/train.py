@@ -650,7 +650,7 @@ def train(model, data_loader, *, num_steps: int, base_learning_rate: float = 1e-
         if not have_batch:
             break
         feeder.take()                      # (batch k + 1 was sent on its way while step k was being issued)
-        dp.lr_base = schedule(applied)     # optax evaluates the schedule at its count BEFORE the increment (oracle/optim.py)
+        dp.lr_base = schedule(applied)     # optax evaluates the schedule at its count BEFORE the increment
         dp.step(seed=seed + step_no)
         issued += 1
         try:
