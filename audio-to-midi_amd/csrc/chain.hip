@@ -235,7 +235,9 @@ AMT_DEV void block_fwd_tile(const BlockFwdArgs& a_in, const long n0, const long 
         float u[4], h[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          u[i] = to_f(from_f<T>(acc[rb][ti][i] + bb1[rb][i]));
+          // h = gelu(u) from the UNROUNDED u (round 4); u is rounded only where it is stored for the backward pass
+          // (gemm_nt<gelu> does the same: the two forms still agree bit for bit)
+          u[i] = acc[rb][ti][i] + bb1[rb][i];
           h[i] = gelu_tanh(u[i]);
         }
         store4f(Hs + p * LDH + m, h);
@@ -273,7 +275,10 @@ AMT_DEV void block_fwd_tile(const BlockFwdArgs& a_in, const long n0, const long 
         load4f(Rs + p * LDX + m, x);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          z[i] = to_f(from_f<T>(acc[rb][ti][i] + bb2[rb][i]));
+          // z enters y UNROUNDED since round 4: nothing stores z any more (dgamma comes from the pw2 weight gradient), so the
+          // rounding to T "as stored" had become a pure loss (profiles/r04_notes.md: max |dlogit| 1.96e-2 -> 1.58e-2 in the
+          // rounding study).  gemm_nt<scale_resid> and block_small_fwd do the same: the three forms still agree bit for bit.
+          z[i] = acc[rb][ti][i] + bb2[rb][i];
           y[i] = x[i] + gm[rb][i] * z[i];
         }
         store4f(Xs + p * LDX + m, z);     // the LN panel is dead: z and y are staged in place

@@ -619,15 +619,17 @@ __global__ __launch_bounds__(256, 2) void block_small_fwd_kernel(
     const float rs = __builtin_amdgcn_rsqf(q * (1.f / C) + kLnEps);
     float ln[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) ln[c] = to_f(from_f<T>(d[c] * rs * slw[wz + c] + slb[wz + c]));
+    // Everything between the dwconv and y stays in fp32 registers (round 4): this kernel multiplies on the vector unit, so
+    // rounding ln / u / h to T "as the MFMA path would" only added error; what is STORED for the backward is rounded by its store
+    for (int c = 0; c < C; ++c) ln[c] = d[c] * rs * slw[wz + c] + slb[wz + c];
     float u[H2], h[H2];
 #pragma unroll
     for (int j = 0; j < H2; ++j) {
       float a = sb1[wz + j];
 #pragma unroll
       for (int c = 0; c < C; ++c) a += sw1[wz + j * C + c] * ln[c];
-      u[j] = to_f(from_f<T>(a));
-      h[j] = to_f(from_f<T>(gelu_tanh(u[j])));
+      u[j] = a;
+      h[j] = gelu_tanh(u[j]);
     }
     float z[C], y[C];
 #pragma unroll
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(256, 2) void block_small_fwd_kernel(
       float a = sb2[wz + c];
 #pragma unroll
       for (int j = 0; j < H2; ++j) a += sw2[wz + c * H2 + j] * h[j];
-      z[c] = to_f(from_f<T>(a));
+      z[c] = a;                                    // unrounded (chain.hip: block_fwd_tile)
       y[c] = x[3][c] + sg[wz + c] * z[c];
     }
     storevf<C>(Y + row * C, y);

@@ -55,14 +55,14 @@ AMT_DEV void epi_apply(const GemmArgs& a, int n, int m, float (&v)[4]) {
   } else if constexpr (EPI == EPI_GELU) {
     float h[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { v[i] = to_f(from_f<T>(v[i])); h[i] = gelu_tanh(v[i]); }
+    for (int i = 0; i < 4; ++i) h[i] = gelu_tanh(v[i]);      // from the unrounded u (chain.hip: block_fwd_tile)
     store4f(reinterpret_cast<T*>(a.Y) + (size_t)n * a.ldy + m, v);
     store4f(reinterpret_cast<T*>(a.Y2) + (size_t)n * a.ldy2 + m, h);
   } else if constexpr (EPI == EPI_SCALE_RESID) {
     float r[4], y[4];
     load4f(reinterpret_cast<const Res<T>*>(a.R) + (size_t)n * a.ldr + m, r);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { v[i] = to_f(from_f<T>(v[i])); y[i] = r[i] + a.gamma[m + i] * v[i]; }
+    for (int i = 0; i < 4; ++i) y[i] = r[i] + a.gamma[m + i] * v[i];      // z unrounded (chain.hip: block_fwd_tile)
     if (a.Y2 != nullptr) store4f(reinterpret_cast<T*>(a.Y2) + (size_t)n * a.ldy2 + m, v);
     store4f(reinterpret_cast<Res<T>*>(a.Y) + (size_t)n * a.ldy + m, y);
   } else if constexpr (EPI == EPI_GLU_BWD) {

@@ -350,11 +350,19 @@ void reduce_partials(hipStream_t s, const PartDesc* descs_dev, int n_desc, const
 template <typename T>
 __global__ __launch_bounds__(256) void cnn_gamma_finish_kernel(const float* __restrict__ params, float* __restrict__ grads,
                                                                const GammaDesc* __restrict__ descs, int n_desc, int total_rows) {
+  // the Block table goes to LDS first: scanned in global memory it was up to 39 dependent loads in front of every row
+  // (14.9 us per launch for 6 MB of traffic, profiles/r04_notes.md)
+  __shared__ GammaDesc s_d[64];
+  for (int i = threadIdx.x; i < n_desc && i < 64; i += 256) s_d[i] = descs[i];
+  __syncthreads();
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= total_rows) return;
-  int i = 0;
-  while (i + 1 < n_desc && row >= descs[i + 1].row0) ++i;      // (39 Blocks: a short scan)
-  const GammaDesc d = descs[i];
+  int lo = 0, hi = min(n_desc, 64) - 1;                       // last Block whose first row is <= row
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (s_d[mid].row0 <= row) lo = mid; else hi = mid - 1;
+  }
+  const GammaDesc d = s_d[lo];
   const int c = row - d.row0, H2 = 2 * d.C;
   const float g = params[d.gamma + c];
   const float* w = params + d.w2 + (size_t)c * H2;
@@ -374,6 +382,7 @@ __global__ __launch_bounds__(256) void cnn_gamma_finish_kernel(const float* __re
 }
 void cnn_gamma_finish(hipStream_t s, DType dt, const float* params, float* grads, const GammaDesc* descs_dev, int n_desc, int total_rows) {
   if (n_desc <= 0 || total_rows <= 0) return;
+  if (n_desc > 64) return;      // (amt_config allows 8 stages; validate() bounds the depths through this table: see amt_create)
   ProfScope ps(s, "cnn_gamma_finish", 0, 0);
   const int grid = (total_rows + 3) / 4;
   if (dt == DT_F32) hipLaunchKernelGGL(cnn_gamma_finish_kernel<float>, dim3(grid), dim3(256), 0, s, params, grads, descs_dev, n_desc, total_rows);

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/amt.h"
+#include "../../include/amt_ops.h"
 #include "kernels.h"
 #include "prof.h"
 
@@ -81,6 +82,9 @@ bool validate(const amt_config& c, std::string& err) {
     if (c.dims[i] != (4 << i)) { err = "dims[i] must equal 4 << i"; return false; }
     if (c.depths[i] < 0) { err = "negative depth"; return false; }
   }
+  int n_blocks = 0;
+  for (int i = 0; i < c.n_stages; ++i) n_blocks += c.depths[i];
+  if (n_blocks > 64) { err = "at most 64 CNN Blocks in total (sum of depths; the reference has 39)"; return false; }
   int H = c.dims[c.n_stages - 1];
   if (H != 256) { err = "hidden size (dims[-1]) must be 256"; return false; }
   if (c.n_heads * c.head_dim != H || c.head_dim != 64) { err = "n_heads*head_dim must be 256 with head_dim 64"; return false; }
@@ -1928,6 +1932,39 @@ int32_t amt_optimizer_count(amt_ctx* c) {
   if (hipMemcpy(w, c->norm2 + 2, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   if (w[4] != 0) (void)amt_optimizer_status(c);      // the sticky word: switch to the two launches, count the time-out
   return w[0];
+}
+
+// ---- residual-stream checkpoints of the last training-mode forward (include/amt_ops.h; probes/bf16_layer_probe.py)
+namespace {
+struct StreamCk { std::string name; void* ptr; long rows; int cols; };
+std::vector<StreamCk> stream_checkpoints(amt_ctx* c) {
+  std::vector<StreamCk> v;
+  if (c->plan_train != 1 || c->ssave.empty() || c->plan_B <= 0) return v;
+  const int B = c->plan_B;
+  int Lcur = c->plan_T / 5;
+  for (size_t si = 0; si < c->ssave.size(); ++si) {
+    if (si > 0) Lcur /= 2;
+    const int C = c->L.stages[si].C;
+    for (size_t j = 0; j < c->ssave[si].blocks.size(); ++j)
+      v.push_back(StreamCk{"cnn." + std::to_string(si) + "." + std::to_string(j + 1) + ".x", c->ssave[si].blocks[j].x, (long)B * Lcur, C});
+  }
+  const long N = (long)B * (c->plan_T / 320);
+  v.push_back(StreamCk{"cnn.norm.x", c->fn_x, N, c->L.H});
+  for (size_t li = 0; li < c->lsave.size(); ++li)
+    v.push_back(StreamCk{"tl." + std::to_string(li) + ".x", c->lsave[li].x, N, c->L.H});
+  v.push_back(StreamCk{"head.x", c->hd_x, N, c->L.H});
+  return v;
+}
+}  // namespace
+
+int32_t amt_op_stream_count(amt_ctx* c) { return (int32_t)stream_checkpoints(c).size(); }
+
+int32_t amt_op_stream_checkpoint(amt_ctx* c, int32_t index, char name[64], void** ptr, int64_t* rows, int32_t* cols) {
+  const std::vector<StreamCk> v = stream_checkpoints(c);
+  if (index < 0 || index >= (int32_t)v.size() || v[index].ptr == nullptr) { c->err = "amt_op_stream_checkpoint: bad index or no saved training forward"; return 1; }
+  snprintf(name, 64, "%s", v[index].name.c_str());
+  *ptr = v[index].ptr; *rows = v[index].rows; *cols = v[index].cols;
+  return 0;
 }
 
 int32_t amt_adamw_step(amt_ctx* c, const float* grads_flat, float lr_base, float layer_lr_decay, float b1, float b2,

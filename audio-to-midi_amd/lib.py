@@ -135,6 +135,8 @@ SIGNATURES = {
                                _u32, _f32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp]),
     "amt_op_bce_loss": (_i32, [_i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "amt_op_dropout": (_i32, [_i32, _vp, _vp, _u64, _u64, _u32, _f32, _vp]),
+    "amt_op_stream_count": (_i32, [_vp]),
+    "amt_op_stream_checkpoint": (_i32, [_vp, _i32, C.c_char_p, C.POINTER(_vp), C.POINTER(C.c_int64), C.POINTER(_i32)]),
     "amt_rng_u32": (_u32, [_u64, _u32, _u32]),
     "amt_drop_threshold24": (_u32, [_f32]),
 }

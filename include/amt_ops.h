@@ -19,6 +19,8 @@
 extern "C" {
 #endif
 
+typedef struct amt_ctx amt_ctx;   /* include/amt.h */
+
 /* Y = epilogue(X[N,K] . W[M,K]^T)  — eqx.nn.Linear / 1x1 Conv1d (model.py:141-153, 213-222, 300-334)
  * epi: 0 store, 1 store f32, 2 Y(Res) = R(Res) + dropout(.), 3 GELU (Y = u, Y2 = gelu(u)), 4 Y2 = z, Y(Res) = R(Res) + gamma z,
  * 5 GLU, 6 GLU', 7 GELU', 8 store Res */
@@ -76,6 +78,14 @@ int32_t amt_op_bce_loss(int32_t dtype, const float* logits_pad, int32_t ldl, con
                         void* dlogits, int32_t ldd, int32_t N, int32_t V, float scale, int32_t B, void* stream);
 int32_t amt_op_dropout(int32_t dtype, const void* X, void* Y, uint64_t n, uint64_t seed, uint32_t stream_id,
                        float drop_p, void* stream);
+/* Residual-stream checkpoints of the LAST training-mode forward of a context (amt_forward_backward* / amt_forward_train),
+ * for per-layer error probes (probes/bf16_layer_probe.py): index 0 .. amt_op_stream_count(ctx) - 1 in forward order - the
+ * input x of every CNN Block (channels-last [B * L][C]), the input of the final CNN LayerNorm, the input x of every
+ * transformer layer ([B * S][256]; layer 0's is the final norm's output) and the decoder's input.  `name` receives a label
+ * ("cnn.<stage>.<block>.x", "cnn.norm.x", "tl.<layer>.x", "head.x").  The tensors are Res (float32 | float16) and live in the
+ * context's workspace until its next call.  Returns 0, or 1 for a bad index / no saved forward. */
+int32_t amt_op_stream_count(amt_ctx* ctx);
+int32_t amt_op_stream_checkpoint(amt_ctx* ctx, int32_t index, char name[64], void** ptr, int64_t* rows, int32_t* cols);
 /* host mirrors of the counter-based dropout RNG (so the oracle can rebuild the device's masks) */
 uint32_t amt_rng_u32(uint64_t seed, uint32_t stream_id, uint32_t idx);
 uint32_t amt_drop_threshold24(float drop_p);
