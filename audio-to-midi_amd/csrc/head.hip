@@ -403,20 +403,27 @@ AMT_DEV bool adamw_gate_open(const int* gate_i, const float* gate_f) {
 // RECIPROCALS and the square root / the quotient are v_sqrt_f32 / v_rcp_f32 (1 ulp each): written with two IEEE divisions
 // and a correctly rounded sqrtf the update is ~170 vector instructions per element and both optimizer passes were bound
 // by vector issue, not by HBM (4 TB/s; found by counting v_div_fmas / v_sqrt in the ISA).
+// The fused multiply-adds are WRITTEN OUT and contraction is off inside these two functions (round 4): left to the compiler,
+// "b1 * mo + (1 - b1) * gi" was fused one way in one kernel and another way in the next, and the one-launch form, the
+// two-launch form and the lone-commit path of a timed-out launch differed in the last bit of m', v' and p from the second step
+// on (tests/test_step_surface_gpu.py: test_optimizer_forms_agree_bit_for_bit_on_the_same_gradients).  The callers pin their
+// own two fusable expressions the same way: acc = fma(u, u, acc) and p' = fma(u, f, p).
 AMT_DEV float adamw_update(float gi, float pi, float mo, float vo, float lrs, float lr, float b1, float b2, float eps, float wd,
                            float ibc1, float ibc2, float& mi, float& vi) {
-  mi = b1 * mo + (1.f - b1) * gi;
-  vi = b2 * vo + (1.f - b2) * gi * gi;
+#pragma clang fp contract(off)
+  mi = __builtin_fmaf(b1, mo, (1.f - b1) * gi);
+  vi = __builtin_fmaf(b2, vo, ((1.f - b2) * gi) * gi);
   float u = (mi * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vi * ibc2) + eps);
-  u += wd * pi;
+  u = __builtin_fmaf(wd, pi, u);
   u *= -lr * lrs;
   return u;
 }
 // the update from the NEW moments alone (the same expression, so the same bits): the one-launch form keeps m', v' in registers
 // across its grid barrier and forms u a second time behind it
 AMT_DEV float adamw_update_from_moments(float mi, float vi, float pi, float lrs, float lr, float eps, float wd, float ibc1, float ibc2) {
+#pragma clang fp contract(off)
   float u = (mi * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vi * ibc2) + eps);
-  u += wd * pi;
+  u = __builtin_fmaf(wd, pi, u);
   u *= -lr * lrs;
   return u;
 }
@@ -500,20 +507,36 @@ void adamw_apply(hipStream_t s, float* params, const float* upd, size_t n, float
 // three, no 46-MB zero fill at the start of the next step.
 // Both passes move 16 bytes per lane and array (f32x4) over the 16-byte-aligned body [0, n4 * 4) and finish the last
 // n % 4 elements (and everything, when a pointer is not 16-byte aligned: VEC = false) with scalar accesses.
+// The global norm is summed in a FIXED order (round 4): every workgroup of the norm pass stores its partial sum in its own
+// slot (norm2[kNormPartOffset + blockIdx.x]), and whoever needs the norm adds the slots with sum_partials - lane l of one
+// wave takes slots l, l + 64, ..., then a butterfly - so every workgroup, every launch and every RANK of a data-parallel job
+// gets the same bits from the same gradients.  (The float atomicAdd into norm2[0] of rounds 1-3 added in arrival order: with
+// the clip active the factor clip / norm differed in its last bits from rank to rank, and the replicas' parameters with it;
+// tests/test_dp_ranks_gpu.py.)  The norm pass of the two-launch form partitions the parameters exactly as the one-launch
+// form does (same grid, 512 threads, chunk k of a thread at base + k * stride), so the two forms agree bit for bit too - a
+// rank that fell back to two launches after a barrier time-out stays in step with the others.
+constexpr int kNormPartOffset = 8, kNormPartMax = 4096;
+AMT_DEV float sum_partials(const float* part, int np, int lane) {
+  float a = 0.f;
+  for (int j = lane; j < np; j += 64) a += __hip_atomic_load(part + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return group_sum<64>(a);
+}
+
 template <bool VEC>
-__global__ __launch_bounds__(256) void adamw_norm_kernel(const float* __restrict__ p, const float* __restrict__ g,
+__global__ __launch_bounds__(512) void adamw_norm_kernel(const float* __restrict__ p, const float* __restrict__ g,
                                                          const float* __restrict__ m, const float* __restrict__ v,
                                                          const float* __restrict__ lr_scale, size_t n, float gmul, float lr,
                                                          float b1, float b2, float eps, float wd, int step,
                                                          const int* __restrict__ count, float* __restrict__ norm2) {
-  __shared__ float red[4];
+  __shared__ float red[8];
   const float t = (float)(step > 0 ? step : count[0] + 1);
   const float bc1 = 1.f / (1.f - powf(b1, t)), bc2 = 1.f / (1.f - powf(b2, t));     // reciprocals (adamw_update)
   float acc = 0.f;
+  const int tid = threadIdx.x;
   const size_t n4 = VEC ? (n >> 2) : 0;
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+  const size_t stride = (size_t)gridDim.x * 512, base = (size_t)blockIdx.x * 512 + tid;
   if (VEC) {
-    for (size_t i = tid; i < n4; i += nthr) {
+    for (size_t i = base; i < n4; i += stride) {           // adamw_persist_kernel's chunks, in its order
       const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i], p4 = reinterpret_cast<const f32x4*>(p)[i];
       const f32x4 m4 = reinterpret_cast<const f32x4*>(m)[i], v4 = reinterpret_cast<const f32x4*>(v)[i];
       const f32x4 s4 = reinterpret_cast<const f32x4*>(lr_scale)[i];
@@ -521,19 +544,28 @@ __global__ __launch_bounds__(256) void adamw_norm_kernel(const float* __restrict
       for (int e = 0; e < 4; ++e) {
         float mi, vi;
         const float u = adamw_update(g4[e] * gmul, p4[e], m4[e], v4[e], s4[e], lr, b1, b2, eps, wd, bc1, bc2, mi, vi);
-        acc += u * u;
+        acc = __builtin_fmaf(u, u, acc);
       }
     }
-  }
-  for (size_t i = (n4 << 2) + tid; i < n; i += nthr) {
-    float mi, vi;
-    const float u = adamw_update(g[i] * gmul, p[i], m[i], v[i], lr_scale[i], lr, b1, b2, eps, wd, bc1, bc2, mi, vi);
-    acc += u * u;
+    const size_t jt = (n4 << 2) + tid;                     // the last n % 4 elements: threads 0 .. 2 of workgroup 0
+    if (blockIdx.x == 0 && jt < n) {
+      float mi, vi;
+      const float u = adamw_update(g[jt] * gmul, p[jt], m[jt], v[jt], lr_scale[jt], lr, b1, b2, eps, wd, bc1, bc2, mi, vi);
+      acc = __builtin_fmaf(u, u, acc);
+    }
+  } else {
+    for (size_t i = base; i < n; i += stride) {
+      float mi, vi;
+      const float u = adamw_update(g[i] * gmul, p[i], m[i], v[i], lr_scale[i], lr, b1, b2, eps, wd, bc1, bc2, mi, vi);
+      acc = __builtin_fmaf(u, u, acc);
+    }
   }
   acc = group_sum<64>(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(norm2, red[0] + red[1] + red[2] + red[3]);
+  if (tid == 0)
+    __hip_atomic_store(norm2 + kNormPartOffset + blockIdx.x, ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <bool VEC>
 __global__ __launch_bounds__(256) void adamw_commit_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
@@ -541,17 +573,19 @@ __global__ __launch_bounds__(256) void adamw_commit_kernel(float* __restrict__ p
                                                            float gmul, float lr, float b1, float b2, float eps, float wd, int step,
                                                            int* __restrict__ count, float* __restrict__ norm2, float clip,
                                                            const int* __restrict__ gate_i, const float* __restrict__ gate_f,
-                                                           const float* __restrict__ loss, int* __restrict__ valid_out) {
+                                                           const float* __restrict__ loss, int* __restrict__ valid_out, int norm_parts) {
   __shared__ float s_nrm2;
   __shared__ int s_cnt;
+  if (threadIdx.x < 64) {
+    const float nrm2 = sum_partials(norm2 + kNormPartOffset, norm_parts, threadIdx.x);     // the same bits in every workgroup
+    if (threadIdx.x == 0) s_nrm2 = nrm2;
+  }
   if (threadIdx.x == 0) {
-    s_nrm2 = __hip_atomic_load(norm2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_cnt = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // both values have ARRIVED before this workgroup counts itself as a reader
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the count has ARRIVED before this workgroup counts itself as a reader
     unsigned* rd = reinterpret_cast<unsigned*>(norm2 + 1);
-    if (atomicAdd(rd, 1u) == gridDim.x - 1) {          // last reader: everybody has the old norm2 / count
+    if (atomicAdd(rd, 1u) == gridDim.x - 1) {          // last reader: everybody has the old count
       const bool open = adamw_gate_open(gate_i, gate_f) && isfinite(s_nrm2) && (loss == nullptr || isfinite(loss[0]));
-      __hip_atomic_store(norm2, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(rd, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (open) count[0] = step > 0 ? step : s_cnt + 1;
       if (valid_out != nullptr) valid_out[0] = open ? 1 : 0;
@@ -576,7 +610,7 @@ __global__ __launch_bounds__(256) void adamw_commit_kernel(float* __restrict__ p
         for (int e = 0; e < 4; ++e) {
           float mi, vi;
           const float u = adamw_update(g4[e] * gmul, p4[e], m4[e], v4[e], s4[e], lr, b1, b2, eps, wd, bc1, bc2, mi, vi);
-          m4[e] = mi; v4[e] = vi; p4[e] = p4[e] + u * f;
+          m4[e] = mi; v4[e] = vi; p4[e] = __builtin_fmaf(u, f, p4[e]);
         }
         reinterpret_cast<f32x4*>(p)[i] = p4; reinterpret_cast<f32x4*>(m)[i] = m4; reinterpret_cast<f32x4*>(v)[i] = v4;
       }
@@ -590,27 +624,67 @@ __global__ __launch_bounds__(256) void adamw_commit_kernel(float* __restrict__ p
       const float u = adamw_update(g[i] * gmul, pi, m[i], v[i], lr_scale[i], lr, b1, b2, eps, wd, bc1, bc2, mi, vi);
       m[i] = mi;
       v[i] = vi;
-      p[i] = pi + u * f;
+      p[i] = __builtin_fmaf(u, f, pi);
     }
     g[i] = 0.f;
   }
 }
+// the commit pass of adamw_commit_kernel by ONE workgroup of 512 threads (adamw_persist_kernel's failed-barrier path)
+__device__ __attribute__((noinline)) void adamw_commit_alone(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                             float* __restrict__ v, const float* __restrict__ lr_scale, size_t n,
+                                                             float gmul, float lr, float b1, float b2, float eps, float wd,
+                                                             float bc1, float bc2, float f, bool open, int tid) {
+  const size_t n4 = n >> 2;
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (size_t i = tid; i < n4; i += 512) {
+    if (open) {
+      const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i];
+      f32x4 p4 = reinterpret_cast<f32x4*>(p)[i], m4 = reinterpret_cast<f32x4*>(m)[i], v4 = reinterpret_cast<f32x4*>(v)[i];
+      const f32x4 s4 = reinterpret_cast<const f32x4*>(lr_scale)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float mi, vi;
+        const float u = adamw_update(g4[e] * gmul, p4[e], m4[e], v4[e], s4[e], lr, b1, b2, eps, wd, bc1, bc2, mi, vi);
+        m4[e] = mi; v4[e] = vi; p4[e] = __builtin_fmaf(u, f, p4[e]);
+      }
+      reinterpret_cast<f32x4*>(p)[i] = p4; reinterpret_cast<f32x4*>(m)[i] = m4; reinterpret_cast<f32x4*>(v)[i] = v4;
+    }
+    reinterpret_cast<f32x4*>(g)[i] = z4;
+  }
+  for (size_t i = (n4 << 2) + tid; i < n; i += 512) {
+    if (open) {
+      float mi, vi;
+      const float pi = p[i];
+      const float u = adamw_update(g[i] * gmul, pi, m[i], v[i], lr_scale[i], lr, b1, b2, eps, wd, bc1, bc2, mi, vi);
+      m[i] = mi; v[i] = vi; p[i] = __builtin_fmaf(u, f, pi);
+    }
+    g[i] = 0.f;
+  }
+}
+
 // One-launch form of the same protocol: ONE workgroup of 512 threads per compute unit, a grid barrier between the two passes.
 // Pass 1 reads g, p, m, v, forms m', v', u, adds |u|^2 to norm2 and KEEPS m', v' in registers (2 x 4 x NCH floats per
 // lane: the register files of the chip hold two of the four arrays, not more); behind the barrier pass 2 reads p again, forms
 // u from the kept moments (adamw_update_from_moments: the same bits), and writes p, m', v' and the zeroed g: 34.5 instead of
 // 56 bytes per parameter (the learning-rate factor as one byte, below), one launch instead of two.
 // The barrier is an arrival counter that only grows (norm2[4]; the launch index norm2[5] is advanced behind it) plus ONE
-// DECISION WORD per launch (norm2[7]): the arrival that completes the count proposes "open", a workgroup whose spin limit
-// expires proposes "failed", both by compare-and-swap from "undecided" - the first proposal stands - and EVERY workgroup,
-// the one that completed the count and any that becomes resident later included, takes its verdict from that word.  The
-// update is therefore all-or-nothing (round 3 let each workgroup judge by its own spin: a workgroup that gave up while a
-// late arrival let the others through left a partially applied step).  Every workgroup must be RESIDENT for the
-// barrier to open, which holds when the grid is the number of compute units and nothing else runs on the device (the
-// optimizer is issued behind the step's collectives in stream order; the host takes the two-launch form under stream
-// capture and after a time-out).  A "failed" decision sets the sticky word norm2[6] and a mapped host word: that launch
-// and every later one skip the update (valid_out = 0, g zeroed), amt_optimizer_status reports it - a time-out is NOT a
-// non-finite step - and the host goes back to the two-launch form at its next call.
+// DECISION WORD per launch (norm2[7]; launch e: any value below 4 e + 1 = undecided, 4 e + 1 = open, 4 e + 2 = failed, so the
+// word only ever grows and needs no reset between launches): the arrival that completes the count proposes "open", a
+// workgroup whose spin limit expires proposes "failed", both by compare-and-swap from "undecided" - the first proposal stands
+// - and EVERY workgroup, the one that completed the count and any that becomes resident later included, takes its verdict
+// from that word.  The update is therefore all-or-nothing (round 3 let each workgroup judge by its own spin: a workgroup that
+// gave up while a late arrival let the others through left a partially applied step).
+// Every workgroup must be RESIDENT for the barrier to open, which holds when the grid is the number of compute units and
+// nothing else runs on the device (the optimizer is issued behind the step's collectives in stream order).  When it does not
+// hold - a second process on the same device: tests/test_dp_ranks_gpu.py - the verdict is "failed", and a failed launch
+// LOSES NOTHING (round 4; before, it skipped the update and zeroed g, which at N > 1 would let one rank's parameters part
+// from the others'): every workgroup still runs pass 1 and arrives (its |u|^2 is in norm2 before its arrival), the
+// workgroups that read "failed" leave without touching p, m, v or g, and the arrival that COMPLETES the count - by then
+// every other workgroup has arrived and norm2 is whole - runs the commit pass over all parameters alone (the expressions of
+// adamw_commit_kernel: the same bits as the two-launch form; ~36 bytes per parameter through one compute unit, a few ms,
+// once).  A failed verdict sets the sticky word norm2[6] and a mapped host word: amt_optimizer_status counts it and the host
+// goes back to the two-launch form at its next call; launches issued before the host has seen it (sticky word set) keep
+// the protocol but give the barrier only a short spin.
 // spin_limit / delay_wg / delay_spins: the limit (polls of ~0.5 us) and a test hook that holds one workgroup back in front
 // of its arrival (tests/test_step_surface_gpu.py: a late arrival inside and outside the limit).
 constexpr int kAdamPersistChunks = 24;
@@ -626,8 +700,8 @@ __global__ __launch_bounds__(512) void adamw_persist_kernel(float* __restrict__ 
                                                             unsigned delay_spins) {
   __shared__ float red[8];
   __shared__ float s_nrm2;
-  __shared__ int s_cnt, s_fail;
-  __shared__ unsigned s_epoch;
+  __shared__ int s_cnt, s_mode;       // s_mode: 0 = barrier open (pass 2 from the kept moments), 1 = failed: leave, 2 = failed and last arrival: commit alone
+  __shared__ unsigned s_epoch, s_sticky;
   // the per-parameter learning-rate factor takes few distinct values (one per depth of the layer-wise decay): one BYTE per
   // parameter indexes a table instead of 4 bytes of factor read in both passes (lr_idx[i] -> lr_tab[...] == lr_scale[i], same bits)
   __shared__ float s_tab[256];
@@ -637,16 +711,17 @@ __global__ __launch_bounds__(512) void adamw_persist_kernel(float* __restrict__ 
   if (tid == 0) {
     s_cnt = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_epoch = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_fail = (int)__hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_sticky = __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  const bool dead = s_fail != 0;                                // an earlier launch timed out: skip, keep the accumulator clean
   const float t = (float)(step > 0 ? step : s_cnt + 1);
   const float bc1 = 1.f / (1.f - powf(b1, t)), bc2 = 1.f / (1.f - powf(b2, t));     // reciprocals (adamw_update)
   const size_t n4 = n >> 2, stride = (size_t)gridDim.x * 512, base = (size_t)blockIdx.x * 512 + tid;
   f32x4 ms[NCH], vs[NCH];
   float acc = 0.f;
-  if (!dead) {
+  // (s_sticky is 0 or 1: the condition always holds.  Without a condition the compiler cannot see through around this loop
+  // it schedules the 24 chunks' loads together: 256 registers and 40 spilled ones instead of 224 and none.)
+  if (s_sticky < 2u) {
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const size_t i = base + (size_t)k * stride;
@@ -658,7 +733,7 @@ __global__ __launch_bounds__(512) void adamw_persist_kernel(float* __restrict__ 
         for (int e = 0; e < 4; ++e) {
           float mi, vi;
           const float u = adamw_update(g4[e] * gmul, p4[e], m4[e], v4[e], s_tab[(w >> (8 * e)) & 255u], lr, b1, b2, eps, wd, bc1, bc2, mi, vi);
-          acc += u * u;
+          acc = __builtin_fmaf(u, u, acc);
           ms[k][e] = mi; vs[k][e] = vi;
         }
       }
@@ -666,57 +741,78 @@ __global__ __launch_bounds__(512) void adamw_persist_kernel(float* __restrict__ 
   }
   // the last n % 4 elements: threads 0 .. 2 of workgroup 0
   const size_t jt = (n4 << 2) + tid;
-  const bool tail = !dead && blockIdx.x == 0 && jt < n;
+  const bool tail = blockIdx.x == 0 && jt < n;
   float mt = 0.f, vt = 0.f;
   if (tail) {
     const float u = adamw_update(g[jt] * gmul, p[jt], m[jt], v[jt], lr_scale[jt], lr, b1, b2, eps, wd, bc1, bc2, mt, vt);
-    acc += u * u;
+    acc = __builtin_fmaf(u, u, acc);
   }
   acc = group_sum<64>(acc);
   if ((tid & 63) == 0) red[tid >> 6] = acc;
   __syncthreads();
   if (tid == 0) {
-    int fail = dead ? 1 : 0;
-    if (!dead) {
-      atomicAdd(norm2, ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])));
-      __threadfence();
-      if ((int)blockIdx.x == delay_wg)                      // test hook: this workgroup arrives late
-        for (unsigned w = 0; w < delay_spins; ++w) __builtin_amdgcn_s_sleep(16);
-      // decision word of launch e: 2 e = undecided (the previous launch's "open"), 2 e + 2 = open, 2 e + 3 = failed
-      const unsigned undecided = 2u * s_epoch, open_v = undecided + 2u, fail_v = undecided + 3u;
-      const unsigned target = (s_epoch + 1u) * gridDim.x;
-      if (atomicAdd(bar, 1u) + 1u == target) atomicCAS(bar + 3, undecided, open_v);   // the arrival that completes the count proposes "open"
-      unsigned spins = 0, d;
-      while ((d = __hip_atomic_load(bar + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == undecided) {
+    // this workgroup's |u|^2 goes into its own slot (summed in a fixed order behind the barrier: sum_partials)
+    __hip_atomic_store(norm2 + kNormPartOffset + blockIdx.x, ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    if ((int)blockIdx.x == delay_wg)                      // test hook: this workgroup arrives late
+      for (unsigned w = 0; w < delay_spins; ++w) __builtin_amdgcn_s_sleep(16);
+    const unsigned open_v = 4u * s_epoch + 1u, fail_v = open_v + 1u;      // anything below open_v: undecided
+    const unsigned target = (s_epoch + 1u) * gridDim.x;
+    auto propose = [&](unsigned proposal) {               // the first proposal of the launch stands; returns the verdict
+      unsigned d = __hip_atomic_load(bar + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (d < open_v) {
+        const unsigned old = atomicCAS(bar + 3, d, proposal);
+        if (old == d) return proposal;
+        d = old;
+      }
+      return d;
+    };
+    const bool last = atomicAdd(bar, 1u) + 1u == target;  // every workgroup of the launch has arrived (its slot is written)
+    unsigned d;
+    if (last) {
+      d = propose(open_v);
+    } else {
+      const unsigned limit = s_sticky ? 64u : spin_limit;   // an earlier launch failed and the host has not switched yet: do not wait long again
+      unsigned spins = 0;
+      while ((d = __hip_atomic_load(bar + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < open_v) {
         __builtin_amdgcn_s_sleep(16);
-        if (++spins > spin_limit) atomicCAS(bar + 3, undecided, fail_v);              // an expired limit proposes "failed"; the first proposal stands
+        if (++spins > limit) { d = propose(fail_v); break; }
       }
-      if (d != open_v) {                                    // the launch's verdict, the same word for every workgroup
-        __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (fail_host != nullptr) __hip_atomic_store(fail_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // mapped host word: the next call sees it without a sync
-        fail = 1;
-      }
-      __threadfence();
     }
-    const float nrm2 = __hip_atomic_load(norm2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the value has ARRIVED before this workgroup counts itself as a reader
-    s_nrm2 = nrm2;
-    s_fail = fail;
-    unsigned* rd = reinterpret_cast<unsigned*>(norm2 + 1);
-    if (atomicAdd(rd, 1u) == gridDim.x - 1) {            // last reader: everybody has norm2
-      const bool open = !fail && adamw_gate_open(gate_i, gate_f) && isfinite(nrm2) && (loss == nullptr || isfinite(loss[0]));
-      __hip_atomic_store(norm2, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(rd, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!dead) __hip_atomic_store(bar + 1, s_epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (open) count[0] = step > 0 ? step : s_cnt + 1;
-      if (valid_out != nullptr) valid_out[0] = open ? 1 : 0;
+    int mode = 0;
+    if (d != open_v) {                                      // the launch's verdict, the same word for every workgroup
+      __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (fail_host != nullptr) __hip_atomic_store(fail_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // mapped host word: the next call sees it without a sync
+      mode = last ? 2 : 1;
     }
+    __threadfence();
+    s_mode = mode;
   }
   __syncthreads();
-  const bool open = s_fail == 0 && adamw_gate_open(gate_i, gate_f) && isfinite(s_nrm2) && (loss == nullptr || isfinite(loss[0]));
+  if (s_mode == 1) return;                                  // failed, and not the last to arrive: nothing was touched
+  // every workgroup has arrived (open: the barrier; failed: this workgroup completed the count): all slots are written
+  if (tid < 64) {
+    const float nrm2 = sum_partials(norm2 + kNormPartOffset, (int)gridDim.x, tid);
+    if (tid == 0) s_nrm2 = nrm2;
+  }
+  __syncthreads();
+  const bool open = adamw_gate_open(gate_i, gate_f) && isfinite(s_nrm2) && (loss == nullptr || isfinite(loss[0]));
+  // the launch's bookkeeping, by one workgroup: every workgroup read the count and the launch index before it arrived
+  if (tid == 0 && (s_mode == 2 || (s_mode == 0 && blockIdx.x == 0))) {
+    __hip_atomic_store(bar + 1, s_epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (open) count[0] = step > 0 ? step : s_cnt + 1;
+    if (valid_out != nullptr) valid_out[0] = open ? 1 : 0;
+  }
   const float nrm = sqrtf(s_nrm2);
   const float f = (clip > 0.f && nrm > clip) ? clip / nrm : 1.f;
   const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (s_mode == 2) {
+    // failed, and this workgroup completed the count: every other workgroup has left or is leaving, the norm is whole - the
+    // commit pass over ALL parameters by this one workgroup (out of line: a rare path kept out of the kernel's body)
+    adamw_commit_alone(p, g, m, v, lr_scale, n, gmul, lr, b1, b2, eps, wd, bc1, bc2, f, open, tid);
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
     const size_t i = base + (size_t)k * stride;
@@ -726,7 +822,7 @@ __global__ __launch_bounds__(512) void adamw_persist_kernel(float* __restrict__ 
         const unsigned w = reinterpret_cast<const unsigned*>(lr_idx)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          p4[e] = p4[e] + adamw_update_from_moments(ms[k][e], vs[k][e], p4[e], s_tab[(w >> (8 * e)) & 255u], lr, eps, wd, bc1, bc2) * f;
+          p4[e] = __builtin_fmaf(adamw_update_from_moments(ms[k][e], vs[k][e], p4[e], s_tab[(w >> (8 * e)) & 255u], lr, eps, wd, bc1, bc2), f, p4[e]);
         reinterpret_cast<f32x4*>(p)[i] = p4; reinterpret_cast<f32x4*>(m)[i] = ms[k]; reinterpret_cast<f32x4*>(v)[i] = vs[k];
       }
       reinterpret_cast<f32x4*>(g)[i] = z4;
@@ -735,7 +831,7 @@ __global__ __launch_bounds__(512) void adamw_persist_kernel(float* __restrict__ 
   if (blockIdx.x == 0 && jt < n) {
     if (open && tail) {
       const float pi = p[jt];
-      p[jt] = pi + adamw_update_from_moments(mt, vt, pi, lr_scale[jt], lr, eps, wd, bc1, bc2) * f;
+      p[jt] = __builtin_fmaf(adamw_update_from_moments(mt, vt, pi, lr_scale[jt], lr, eps, wd, bc1, bc2), f, pi);
       m[jt] = mt;
       v[jt] = vt;
     }
@@ -745,28 +841,30 @@ __global__ __launch_bounds__(512) void adamw_persist_kernel(float* __restrict__ 
 
 void adamw_fused(hipStream_t s, float* params, float* gacc, float* m, float* v, const float* lr_scale, size_t n, float gmul,
                  float lr, float b1, float b2, float eps, float wd, int step, int* count, float* norm2, float clip,
-                 const int* gate_i, const float* gate_f, const float* loss, int* valid_out, int persist_grid,
+                 const int* gate_i, const float* gate_f, const float* loss, int* valid_out, int grid, bool persist,
                  const unsigned char* lr_idx, const float* lr_tab, int* persist_fail_host, unsigned spin_limit, int delay_wg,
                  unsigned delay_spins) {
   const bool vec = ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(gacc) | reinterpret_cast<uintptr_t>(m) |
                      reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(lr_scale)) & 15) == 0;
-  // one-launch form: every parameter chunk has a register slot (persist_grid workgroups x 512 threads x kAdamPersistChunks)
-  if (vec && persist_grid > 0 && lr_idx != nullptr && (reinterpret_cast<uintptr_t>(lr_idx) & 3) == 0 &&
-      (n >> 2) <= (size_t)persist_grid * 512 * kAdamPersistChunks) {
+  if (grid <= 0) grid = 256;
+  if (grid > kNormPartMax) grid = kNormPartMax;
+  // one-launch form: every parameter chunk has a register slot (grid workgroups x 512 threads x kAdamPersistChunks)
+  if (vec && persist && lr_idx != nullptr && (reinterpret_cast<uintptr_t>(lr_idx) & 3) == 0 &&
+      (n >> 2) <= (size_t)grid * 512 * kAdamPersistChunks) {
     ProfScope ps(s, "adamw_persist", 0, 34.5 * n);
-    hipLaunchKernelGGL(adamw_persist_kernel<kAdamPersistChunks>, dim3(persist_grid), dim3(512), 0, s, params, gacc, m, v, lr_scale, lr_idx, lr_tab, n,
+    hipLaunchKernelGGL(adamw_persist_kernel<kAdamPersistChunks>, dim3(grid), dim3(512), 0, s, params, gacc, m, v, lr_scale, lr_idx, lr_tab, n,
                        gmul, lr, b1, b2, eps, wd, step, count, norm2, clip, gate_i, gate_f, loss, valid_out, persist_fail_host,
-                       spin_limit > 0 ? spin_limit : (1u << 21), delay_wg, delay_spins);
+                       spin_limit > 0 ? spin_limit : (1u << 15), delay_wg, delay_spins);
     return;
   }
-  {
+  {   // the norm pass takes the one-launch form's partition (grid x 512 threads): the same partial sums, the same norm
     ProfScope ps(s, "adamw_norm", 0, 20.0 * n);
-    if (vec) hipLaunchKernelGGL(adamw_norm_kernel<true>, dim3(2048), dim3(256), 0, s, params, gacc, m, v, lr_scale, n, gmul, lr, b1, b2, eps, wd, step, count, norm2);
-    else hipLaunchKernelGGL(adamw_norm_kernel<false>, dim3(2048), dim3(256), 0, s, params, gacc, m, v, lr_scale, n, gmul, lr, b1, b2, eps, wd, step, count, norm2);
+    if (vec) hipLaunchKernelGGL(adamw_norm_kernel<true>, dim3(grid), dim3(512), 0, s, params, gacc, m, v, lr_scale, n, gmul, lr, b1, b2, eps, wd, step, count, norm2);
+    else hipLaunchKernelGGL(adamw_norm_kernel<false>, dim3(grid), dim3(512), 0, s, params, gacc, m, v, lr_scale, n, gmul, lr, b1, b2, eps, wd, step, count, norm2);
   }
   ProfScope ps(s, "adamw_commit", 0, 36.0 * n);
-  if (vec) hipLaunchKernelGGL(adamw_commit_kernel<true>, dim3(2048), dim3(256), 0, s, params, gacc, m, v, lr_scale, n, gmul, lr, b1, b2, eps, wd, step, count, norm2, clip, gate_i, gate_f, loss, valid_out);
-  else hipLaunchKernelGGL(adamw_commit_kernel<false>, dim3(2048), dim3(256), 0, s, params, gacc, m, v, lr_scale, n, gmul, lr, b1, b2, eps, wd, step, count, norm2, clip, gate_i, gate_f, loss, valid_out);
+  if (vec) hipLaunchKernelGGL(adamw_commit_kernel<true>, dim3(2048), dim3(256), 0, s, params, gacc, m, v, lr_scale, n, gmul, lr, b1, b2, eps, wd, step, count, norm2, clip, gate_i, gate_f, loss, valid_out, grid);
+  else hipLaunchKernelGGL(adamw_commit_kernel<false>, dim3(2048), dim3(256), 0, s, params, gacc, m, v, lr_scale, n, gmul, lr, b1, b2, eps, wd, step, count, norm2, clip, gate_i, gate_f, loss, valid_out, grid);
 }
 
 // ------------------------------------------------------------------ profiler (prof.h)

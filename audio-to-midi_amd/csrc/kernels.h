@@ -381,10 +381,12 @@ void adamw_compute(hipStream_t s, const float* params, const float* grads, float
 bool step_begin(hipStream_t s, float* grads, size_t n, float* loss_acc, int* valid);   // false: not applicable (alignment)
 void pack_tail(hipStream_t s, const float* loss, const int* valid, float* head_valid, float* tail_loss, float* tail_valid);
 // AdamW straight from the context's gradient accumulator (head.hip): norm pass + commit pass, g is read as g * gmul and left
-// ZEROED; the all-finite flag is isfinite(|update|^2) && isfinite(loss) and goes to valid_out (device int, optional)
+// ZEROED; the all-finite flag is isfinite(|update|^2) && isfinite(loss) and goes to valid_out (device int, optional).
+// norm2: float[8 + 4096] (control words + one partial-sum slot per workgroup of the norm pass); grid: workgroups of the norm
+// pass = of the one-launch form (the number of compute units); persist: take the one-launch form
 void adamw_fused(hipStream_t s, float* params, float* gacc, float* m, float* v, const float* lr_scale, size_t n, float gmul,
                  float lr, float b1, float b2, float eps, float wd, int step, int* count, float* norm2, float clip,
-                 const int* gate_i, const float* gate_f, const float* loss, int* valid_out, int persist_grid = 0,
+                 const int* gate_i, const float* gate_f, const float* loss, int* valid_out, int grid = 0, bool persist = false,
                  const unsigned char* lr_idx = nullptr, const float* lr_tab = nullptr,
                  int* persist_fail_host = nullptr, unsigned spin_limit = 0, int delay_wg = -1, unsigned delay_spins = 0);
 // gate_i / gate_f (device, either may be null): both passes are no-ops unless *gate_i != 0 and *gate_f >= 0.999;

@@ -1781,8 +1781,11 @@ int32_t amt_optimizer_init(amt_ctx* c, float layer_lr_decay) {
     } else {                                                                                 // no mapped word: two launches
       c->persist_fail = c->persist_fail_dev = nullptr; (void)hipGetLastError(); c->opt_persist = false;
     }
-    HIPCHK(c, hipMalloc(&c->norm2, 8 * sizeof(float)));   // [sum of squares, reader count]: adamw_apply leaves both zero; [2]: int count of applied updates; [4..6]: grid barrier of the one-launch fused form (arrivals, launches, sticky timeout)
-    HIPCHK(c, hipMemset(c->norm2, 0, 8 * sizeof(float)));
+    // [sum of squares, reader count]: adamw_apply leaves both zero; [2]: int count of applied updates; [4..7]: grid barrier of the
+    // one-launch fused form (arrivals, launches, sticky timeout, decision word); [8 ..): one partial-sum slot per workgroup of
+    // the fused forms' norm pass (head.hip: sum_partials)
+    HIPCHK(c, hipMalloc(&c->norm2, (8 + 4096) * sizeof(float)));
+    HIPCHK(c, hipMemset(c->norm2, 0, (8 + 4096) * sizeof(float)));
     HIPCHK(c, hipMemset(c->adam_m, 0, n * sizeof(float)));
     HIPCHK(c, hipMemset(c->adam_v, 0, n * sizeof(float)));
   }
@@ -1821,19 +1824,19 @@ int adamw_from_accumulator(amt_ctx* c, hipStream_t s, float lr_base, float b1, f
   int* count = reinterpret_cast<int*>(c->norm2 + 2);
   if (!c->fused_used) { c->err = "amt_adamw_step(grads_flat = NULL): no backward pass has left gradients in the context (call amt_forward_backward* with grads_flat = NULL first)"; return 1; }
   if (c->opt_persist && c->persist_fail != nullptr && *reinterpret_cast<volatile int*>(c->persist_fail) != 0) {
-    c->opt_persist = false;         // its grid barrier did not open (workgroups not co-resident): two launches from now on
+    c->opt_persist = false;         // its grid barrier did not open (workgroups not co-resident; the step was still applied, head.hip): two launches from now on
     c->persist_timeouts++;
     *reinterpret_cast<volatile int*>(c->persist_fail) = 0;
-    c->err = "the one-launch fused optimizer timed out at its grid barrier (that step was skipped); using the two-launch form";
+    c->err = "the one-launch fused optimizer timed out at its grid barrier (one workgroup committed that step alone: nothing was lost); using the two-launch form";
   }
-  // A captured launch would replay whatever the barrier words hold at replay time with no host in between to see a
-  // time-out: under stream capture the step takes the two launches.
+  // A captured launch would replay with no host in between to see a time-out and switch forms (each replay would wait for
+  // its short spin limit and commit through one workgroup): under stream capture the step takes the two launches.
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &cs);
   const bool persist = c->opt_persist && c->lr_idx_ok && cs == hipStreamCaptureStatusNone;
   adamw_fused(s, c->params, c->gacc + c->gacc_pad, c->adam_m, c->adam_v, c->lr_scale, n, c->gacc_mul * grad_mul, lr_base, b1, b2,
               eps, weight_decay, step, count, c->norm2, clip_norm, nullptr, valid_f32, loss_dev ? loss_dev : c->loss_acc, valid_out,
-              persist ? c->n_cus + c->persist_grid_extra : 0, c->lr_idx, c->lr_tab, c->persist_fail_dev, c->persist_spins,
+              c->n_cus + c->persist_grid_extra, persist, c->lr_idx, c->lr_tab, c->persist_fail_dev, c->persist_spins,
               c->persist_delay_wg, c->persist_delay_spins);
   return refresh(c, s);
 }
@@ -1913,7 +1916,7 @@ int32_t amt_optimizer_status(amt_ctx* c) {
     *reinterpret_cast<volatile int*>(c->persist_fail) = 0;      // counted; the device's sticky word keeps later launches of the one-launch form dead
     if (c->opt_persist) {
       c->opt_persist = false;
-      c->err = "the one-launch fused optimizer timed out at its grid barrier (that step was skipped); using the two-launch form";
+      c->err = "the one-launch fused optimizer timed out at its grid barrier (one workgroup committed that step alone: nothing was lost); using the two-launch form";
     }
   }
   return c->persist_timeouts;

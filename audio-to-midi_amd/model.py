@@ -335,7 +335,7 @@ class OutputSequenceGenerator:
         return int(self._L.amt_first_half_status(self._h))
 
     def optimizer_status(self) -> int:
-        """Optimizer steps lost to a barrier time-out of the one-launch form (include/amt.h: amt_optimizer_status)."""
+        """Barrier time-outs of the one-launch optimizer seen so far (no step is lost to one; include/amt.h: amt_optimizer_status)."""
         return int(self._L.amt_optimizer_status(self._h))
 
     def reset_grad_accumulator(self):

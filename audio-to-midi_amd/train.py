@@ -368,7 +368,7 @@ class DataParallelStep:
         self.graph = bool(graph) and self.cuda
         self.step_no = 0
         self.applied = 0          # optimizer updates actually applied (device count, refreshed by result())
-        self.optimizer_timeouts = 0   # steps lost to a barrier time-out of the one-launch optimizer (refreshed by result())
+        self.optimizer_timeouts = 0   # barrier time-outs of the one-launch optimizer (no step is lost to one; refreshed by result())
         self._graphs = None
         self._half_done = None
         self._gen = None
@@ -569,8 +569,8 @@ class DataParallelStep:
         if hasattr(self.backend, "applied_steps"):
             self.applied = int(self.backend.applied_steps())
         m = getattr(self.backend, "model", None)
-        # a barrier time-out of the one-launch optimizer skipped that step as a whole: reported as such, NOT as non-finite
-        # gradients (a loss-scale controller must not halve its scale for it); the context has taken the two launches since
+        # a barrier time-out of the one-launch optimizer (something else held compute units): that step was committed by
+        # one workgroup, nothing was lost, and the context has taken the two launches since; reported, not acted upon
         self.optimizer_timeouts = int(m.optimizer_status()) if (m is not None and hasattr(m, "optimizer_status")) else 0
         if m is not None and hasattr(m, "team_status") and m.team_status() != 0:     # polled where the loop synchronises anyway
             raise RuntimeError("an in-launch XCD-team hand-off timed out (amt_team_status != 0): the outputs of that step are "
@@ -601,8 +601,8 @@ def train(model, data_loader, *, num_steps: int, base_learning_rate: float = 1e-
     * non-finite step (train.py:369-377): the device gate leaves parameters, m, v and the update count untouched, so there is
       nothing to roll back; with ``loss_scaling`` the scale is halved (and doubled while scaled_loss < 1e4, train.py:379-382:
       ``LossScaleController``), which re-captures the step - bf16 needs no scaling, so it is off by default and the scale
-      stays ``grad_scale``.  A barrier time-out of the one-launch optimizer (``DataParallelStep.optimizer_timeouts``) also
-      skips a step but is not a numerical event: the scale is left alone;
+      stays ``grad_scale``.  A barrier time-out of the one-launch optimizer (``DataParallelStep.optimizer_timeouts``) loses
+      nothing - that step is committed by one workgroup - and is only logged;
     * checkpoints (train.py:384-394, 799-812): every ``checkpoint_every`` steps the flat weight file + metadata
       (``infer.save_checkpoint``), the newest ``checkpoints_to_keep`` are kept; rank 0 only;
     * ``check_every``: how often the host synchronises to read (loss, valid) - the reference does every step (it decides on
@@ -665,9 +665,8 @@ def train(model, data_loader, *, num_steps: int, base_learning_rate: float = 1e-
             new_timeouts = dp.optimizer_timeouts - timeouts_seen
             timeouts_seen = dp.optimizer_timeouts
             if new_timeouts:
-                skipped += new_timeouts
-                log(f"step {step_no}: the one-launch optimizer timed out at its grid barrier - step skipped, scale unchanged")
-            elif controller.update(valid, loss, loss * controller.scale):
+                log(f"step {step_no}: the one-launch optimizer timed out at its grid barrier (step applied; two launches from now on)")
+            if controller.update(valid, loss, loss * controller.scale):
                 skipped += 1
                 log(f"Encountered NAN/inf loss at step {step_no}, loss = {loss}. Skipped on the device; grad scale -> {controller.scale}")
                 if controller.enabled:

@@ -495,7 +495,7 @@ def main():
     if model.team_status() != 0:
         raise SystemExit("bench: an XCD-team launch timed out (amt_team_status != 0)")
     if dp.optimizer_timeouts:
-        raise SystemExit("bench: the one-launch optimizer timed out at its grid barrier in the timed run (a step was skipped)")
+        raise SystemExit("bench: the one-launch optimizer timed out at its grid barrier in the timed run (something else holds compute units)")
     # the same loop on the batch that is already in HBM: what the uploads cost on top (0 when they are hidden)
     resident_ms = None
     if feeder is not None:

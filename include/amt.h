@@ -227,15 +227,16 @@ int32_t amt_optimizer_count(amt_ctx* ctx);
  * By default the two passes are ONE launch with a grid barrier between them (one workgroup per compute unit; the new moments
  * stay in registers across it): it needs the device to itself for those ~100 us - issue it in stream order behind the
  * step's collectives.  The barrier's verdict is one word per launch that every workgroup reads (all-or-nothing).  If it does
- * not open within ~1 s (another stream holds compute units) the update of that step is skipped as a whole (valid = 0,
- * accumulator zeroed), a sticky device word and a mapped host word are set, and the next optimizer call of the context (or
+ * not open within ~15 ms (another process or stream holds compute units) the step is STILL APPLIED, with the same bits as
+ * the two-launch form: the workgroups leave without touching anything and the one whose arrival completes the count commits
+ * the whole update alone (a few ms, once) - a rank of a data-parallel job therefore never parts from the others because of a
+ * time-out.  A sticky device word and a mapped host word are set, and the next optimizer call of the context (or
  * amt_optimizer_status / amt_optimizer_count) switches it to the two launches for good and records the reason in
- * amt_last_error.  A time-out is NOT a non-finite step: amt_optimizer_status counts them, so that a loss-scale controller
- * does not halve its scale for one.  Under stream capture the two launches are taken (a replayed launch would have no
- * host between replays to see a time-out).  AMT_OPT_PERSIST=0 selects the two launches from the start. */
+ * amt_last_error.  Under stream capture the two launches are taken (a replayed launch would have no host between replays
+ * to switch forms).  AMT_OPT_PERSIST=0 selects the two launches from the start. */
 int32_t amt_grad_accumulator_reset(amt_ctx* ctx, void* stream);
-/* Number of optimizer steps this context has lost to a barrier time-out of the one-launch form (0 in normal operation;
- * reads a mapped host word: no synchronisation, but only steps whose launch has completed are seen). */
+/* Number of barrier time-outs of the one-launch form this context has seen (0 in normal operation; no step is lost to
+ * one, see above; reads a mapped host word: no synchronisation, but only steps whose launch has completed are seen). */
 int32_t amt_optimizer_status(amt_ctx* ctx);
 
 /* ---- the same protocol across ranks: the collectives run ON the context's accumulator ---------------------------------

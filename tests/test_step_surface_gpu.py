@@ -182,8 +182,10 @@ def test_fused_optimizer_protocol_equals_the_three_pass_form(small_conf, dtype):
 def test_one_launch_optimizer_times_out_safely_and_falls_back(small_conf, monkeypatch):
     """head.hip: adamw_persist_kernel runs its two passes around a grid barrier that only opens when every workgroup is
     resident.  With more workgroups than the device can hold (AMT_OPT_PERSIST_EXTRA) the barrier cannot open: the launch must
-    end by its spin limit (not hang), skip the update (flag 0, parameters and count untouched, accumulator zeroed), and the
-    next call must take the two-launch form and apply a normal update equal to the three-pass form's."""
+    end by its spin limit (not hang) and STILL APPLY the step - the resident workgroups leave untouched, the rest run, and the
+    arrival that completes the count commits the whole update alone, with the bits of the two-launch form (round 4; round 3
+    skipped such a step, which would let one rank of a data-parallel job part from the others).  The time-out is counted and
+    the next call takes the two launches."""
     monkeypatch.setenv("AMT_OPT_PERSIST_EXTRA", "64")
     audio, labels = synth.make_batch(2, 320 * 48, seed=21)
     a, y = torch.from_numpy(audio), torch.from_numpy(labels)
@@ -192,19 +194,16 @@ def test_one_launch_optimizer_times_out_safely_and_falls_back(small_conf, monkey
     plain = amt.OutputSequenceGenerator(small_conf, key=3, dtype="float32", gamma=1.0)
     fused.init_optimizer(); plain.init_optimizer()
     flag = torch.full((1,), -7, dtype=torch.int32, device="cuda")
-    p0 = fused.weights_tensor().clone()
-    fused.loss_and_grads(a, y, scale=2.0, seed=10, train=True, fused_optimizer=True)
-    fused.adamw_step(None, lr_base=2e-2, step=-1, valid=flag)            # times out (~1-3 s), skipped
-    torch.cuda.synchronize()
-    assert int(flag.item()) == 0 and torch.equal(fused.weights_tensor(), p0)
-    assert fused.optimizer_count() == 0                                   # (also where the host notices the sticky word)
-    fused.loss_and_grads(a, y, scale=2.0, seed=10, train=True, fused_optimizer=True)   # a clean accumulator: not 2x the gradients
-    fused.adamw_step(None, lr_base=2e-2, step=-1, valid=flag)            # two launches now
-    out = plain.loss_and_grads(a, y, scale=2.0, seed=10, train=True)
-    plain.adamw_step(out.grads_flat, lr_base=2e-2, step=1)
-    torch.cuda.synchronize()
-    assert int(flag.item()) == 1 and fused.optimizer_count() == 1
-    assert float((fused.weights_tensor() - plain.weights_tensor()).abs().max()) < 2e-6
+    for step in (1, 2, 3):          # step 1: time-out + lone commit; step 2 on: two launches
+        fused.loss_and_grads(a, y, scale=2.0, seed=10 + step, train=True, fused_optimizer=True)
+        fused.adamw_step(None, lr_base=2e-2, step=-1, valid=flag)
+        out = plain.loss_and_grads(a, y, scale=2.0, seed=10 + step, train=True)
+        plain.adamw_step(out.grads_flat, lr_base=2e-2, step=step)
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 1 and fused.optimizer_count() == step      # (also where the host notices the sticky word)
+        assert fused.optimizer_status() == 1                                   # one time-out, counted once
+        assert float((fused.weights_tensor() - plain.weights_tensor()).abs().max()) < 2e-6 * step, step
+    assert float(train.GradBucket.of_model(fused).grads.abs().max()) == 0.0   # every commit left a clean accumulator
 
 
 @pytest.mark.parametrize("late", ["inside", "outside"])
@@ -213,10 +212,9 @@ def test_one_launch_optimizer_verdict_is_unanimous_with_a_late_workgroup(small_c
     (AMT_OPT_PERSIST_DELAY=<wg>:<polls>) while the others spin with a short limit (AMT_OPT_PERSIST_SPINS).
       inside  - it arrives before the limit: the barrier opens, the update is applied in full and equals the three-pass form;
       outside - the others' limit expires first: the launch's decision word says "failed", and the late workgroup - the arrival
-                that completes the count - must take THAT verdict: nothing of the update is applied (parameters, m, v: checked
-                through the next step; count 0), flag 0, accumulator zeroed, amt_optimizer_status counts one time-out, and the
-                next call takes the two launches and applies the whole step.  (Round 3's per-workgroup verdict committed the
-                late workgroup's slice of p / m / v here.)"""
+                that completes the count - must take THAT verdict, not commit its own slice from its registers (round 3's
+                per-workgroup verdict did: a partially applied step): it commits the WHOLE update alone.  The step equals the
+                three-pass form's, amt_optimizer_status counts one time-out, and the next call takes the two launches."""
     monkeypatch.setenv("AMT_OPT_PERSIST_SPINS", "4000")
     monkeypatch.setenv("AMT_OPT_PERSIST_DELAY", "7:%d" % (400 if late == "inside" else 40000))
     audio, labels = synth.make_batch(2, 320 * 48, seed=21)
@@ -226,25 +224,62 @@ def test_one_launch_optimizer_verdict_is_unanimous_with_a_late_workgroup(small_c
     plain = amt.OutputSequenceGenerator(small_conf, key=3, dtype="float32", gamma=1.0)
     fused.init_optimizer(); plain.init_optimizer()
     flag = torch.full((1,), -7, dtype=torch.int32, device="cuda")
-    p0 = fused.weights_tensor().clone()
     fused.loss_and_grads(a, y, scale=2.0, seed=10, train=True, fused_optimizer=True)
     fused.adamw_step(None, lr_base=2e-2, step=-1, valid=flag)
     out = plain.loss_and_grads(a, y, scale=2.0, seed=10, train=True)
     plain.adamw_step(out.grads_flat, lr_base=2e-2, step=1)
     torch.cuda.synchronize()
-    if late == "inside":
-        assert int(flag.item()) == 1 and fused.optimizer_status() == 0 and fused.optimizer_count() == 1
-        assert float((fused.weights_tensor() - plain.weights_tensor()).abs().max()) < 2e-6
-        return
-    assert int(flag.item()) == 0 and torch.equal(fused.weights_tensor(), p0)          # NOTHING was committed
-    assert fused.optimizer_status() == 1 and fused.optimizer_count() == 0
-    assert fused.optimizer_status() == 1                                               # counted once
-    # the next step (two launches now) starts from untouched m / v and a clean accumulator: it equals the three-pass step 1
-    fused.loss_and_grads(a, y, scale=2.0, seed=10, train=True, fused_optimizer=True)
-    fused.adamw_step(None, lr_base=2e-2, step=-1, valid=flag)
-    torch.cuda.synchronize()
     assert int(flag.item()) == 1 and fused.optimizer_count() == 1
     assert float((fused.weights_tensor() - plain.weights_tensor()).abs().max()) < 2e-6
+    assert fused.optimizer_status() == (0 if late == "inside" else 1)
+    assert fused.optimizer_status() == (0 if late == "inside" else 1)                  # counted once
+    # the next step (two launches after a time-out) starts from whole m / v and a clean accumulator
+    fused.loss_and_grads(a, y, scale=2.0, seed=11, train=True, fused_optimizer=True)
+    fused.adamw_step(None, lr_base=2e-2, step=-1, valid=flag)
+    out = plain.loss_and_grads(a, y, scale=2.0, seed=11, train=True)
+    plain.adamw_step(out.grads_flat, lr_base=2e-2, step=2)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1 and fused.optimizer_count() == 2
+    assert float((fused.weights_tensor() - plain.weights_tensor()).abs().max()) < 4e-6
+
+
+@pytest.mark.parametrize("clip_active", [True, False])
+def test_optimizer_forms_agree_bit_for_bit_on_the_same_gradients(small_conf, monkeypatch, clip_active):
+    """The global norm of the updates is summed in a fixed order (head.hip: sum_partials; per-workgroup slots instead of a
+    float atomicAdd in arrival order), and the two-launch form partitions the parameters as the one-launch form does: from
+    the SAME accumulator contents the one-launch form, the two-launch form and a one-launch step whose barrier timed out (one
+    workgroup commits) write the same bits - which is what keeps the replicas of a data-parallel job identical when the clip
+    is active, also when one rank has fallen back to two launches (tests/test_dp_ranks_gpu.py has the ranks)."""
+    audio, labels = synth.make_batch(2, 320 * 48, seed=21)
+    a, y = torch.from_numpy(audio), torch.from_numpy(labels)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    models = {}
+    for form in ("one-launch", "two-launch", "timed-out"):
+        if form == "two-launch":
+            monkeypatch.setenv("AMT_OPT_PERSIST", "0")
+        if form == "timed-out":
+            monkeypatch.setenv("AMT_OPT_PERSIST_SPINS", "4000")
+            monkeypatch.setenv("AMT_OPT_PERSIST_DELAY", "7:40000")
+        m = amt.OutputSequenceGenerator(small_conf, key=3, dtype="float32", gamma=1.0)
+        for k in ("AMT_OPT_PERSIST", "AMT_OPT_PERSIST_SPINS", "AMT_OPT_PERSIST_DELAY"):
+            monkeypatch.delenv(k, raising=False)
+        m.init_optimizer()
+        models[form] = (m, train.GradBucket.of_model(m))
+    n = models["one-launch"][0].n_params
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for step in (1, 2, 3):
+        # the same gradient sums in every context (a backward pass of its own would differ in its last bits: fp32 atomics)
+        g = (torch.randn(n, generator=gen) * (1.0 if clip_active else 1e-3)).cuda()
+        for form, (m, bucket) in models.items():
+            m.loss_and_grads(a, y, seed=step, train=True, fused_optimizer=True)        # marks the accumulator as holding a step
+            bucket.grads.copy_(g)
+            m.adamw_step(None, lr_base=(1e-2 if clip_active else 1e-6), step=-1, valid=flag)
+            torch.cuda.synchronize()
+            assert int(flag.item()) == 1 and m.optimizer_count() == step, form
+        w = {form: m.weights_tensor() for form, (m, _) in models.items()}
+        assert torch.equal(w["one-launch"], w["two-launch"]), step
+        assert torch.equal(w["one-launch"], w["timed-out"]), step
+    assert models["one-launch"][0].optimizer_status() == 0 and models["timed-out"][0].optimizer_status() == 1
 
 
 def test_in_place_protocol_on_the_models_own_bucket(small_conf):
@@ -360,7 +395,7 @@ def test_captured_optimizer_takes_the_two_launch_form(small_conf, monkeypatch):
     time-out.  Under stream capture the fused protocol therefore takes the norm + commit launches: with a context whose
     one-launch form WOULD time out (64 workgroups more than can be resident, a short spin limit), a captured step replays
     three times, applies three updates and reports no time-out - while the same context's EAGER call does time out (and
-    says so through amt_optimizer_status, not through grads_valid alone)."""
+    says so through amt_optimizer_status; the step is applied all the same)."""
     audio, labels = synth.make_batch(2, 320 * 48, seed=21)
     a, y = torch.from_numpy(audio).cuda().to(torch.float16), torch.from_numpy(labels).cuda()
     warm = amt.OutputSequenceGenerator(small_conf, key=3, dtype="bfloat16", gamma=1.0)      # loads every kernel once, eagerly
@@ -391,10 +426,11 @@ def test_captured_optimizer_takes_the_two_launch_form(small_conf, monkeypatch):
         g.replay()
     torch.cuda.synchronize()
     assert model.optimizer_count() == 3 and int(flag.item()) == 1 and model.optimizer_status() == 0
-    # the same context, eagerly: the one-launch form cannot get its 64 extra workgroups resident - skipped as a whole, reported
+    # the same context, eagerly: the one-launch form cannot get its 64 extra workgroups resident - it times out, says so,
+    # and the step is applied all the same (one workgroup commits it)
     p = model.weights_tensor().clone()
     model.loss_and_grads(a, y, seed=9, train=True, fused_optimizer=True)
     model.adamw_step(None, lr_base=1e-3, step=-1, valid=flag)
     torch.cuda.synchronize()
-    assert int(flag.item()) == 0 and torch.equal(model.weights_tensor(), p)
-    assert model.optimizer_status() == 1 and model.optimizer_count() == 3
+    assert int(flag.item()) == 1 and not torch.equal(model.weights_tensor(), p)
+    assert model.optimizer_status() == 1 and model.optimizer_count() == 4
