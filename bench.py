@@ -396,13 +396,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # AMT_BENCH_REHEARSE_ON_ONE_GPU=1: every rank uses cuda:0 and the ranks exchange through gloo (RCCL refuses two ranks on
+    # one device).  A FUNCTIONAL rehearsal of the N > 1 program on a one-GPU box - launcher, rank set-up, signalled overlap,
+    # in-place collectives, max-over-ranks timing, the JSON line - not a scaling number: the line says so ("rehearsal").
+    rehearse = world > 1 and os.environ.get("AMT_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import audio_to_midi_amd as amt
     from audio_to_midi_amd import lib as amtlib
@@ -494,7 +503,7 @@ def main():
         raise SystemExit(f"bench: non-finite step in the timed run (loss {loss_val}, grads_valid {grads_valid})")
     if model.team_status() != 0:
         raise SystemExit("bench: an XCD-team launch timed out (amt_team_status != 0)")
-    if dp.optimizer_timeouts:
+    if dp.optimizer_timeouts and not rehearse:      # (ranks sharing one device hold each other's compute units: expected there)
         raise SystemExit("bench: the one-launch optimizer timed out at its grid barrier in the timed run (something else holds compute units)")
     # the same loop on the batch that is already in HBM: what the uploads cost on top (0 when they are hidden)
     resident_ms = None
@@ -542,7 +551,7 @@ def main():
         out = {
             "metric": "audio-sec/s (fwd+bwd, 10 s clips)", "value": round(value, 1), "unit": "audio-sec/s",
             "n_gpus": world, "ranks_seen": dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1,
-            "comm_backend": (dist.get_backend() + " (RCCL over xGMI)") if (dist is not None and dist.is_initialized()) else None,
+            "comm_backend": (dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else " (host-staged)")) if (dist is not None and dist.is_initialized()) else None,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 (fp8 e4m3 QK^T / PV in the global-attention forward)" if args.attn_fp8 else "bf16", "data": "synthetic",
@@ -558,6 +567,8 @@ def main():
                        "weights": "random init (Equinox distributions), 11606230 params"},
             "model_tflops": round(world * FLOPS_PER_STEP / (elapsed / args.steps) / 1e12, 2),
             "host_issue_ms_per_step": round(host_issue_ms, 4),
+            **({"rehearsal": f"{world} ranks share ONE GPU and exchange through gloo: a functional rehearsal of the N > 1 program, "
+                             "not a scaling measurement", "optimizer_timeouts": int(dp.optimizer_timeouts)} if rehearse else {}),
             "inputs": ("resident in HBM (same batch every step)" if feeder is None else
                        f"fresh batch per step: {feeder.bytes_per_batch / 1e6:.2f} MB from pinned host memory over PCIe on a copy stream, "
                        "double-buffered (train.py:280)"),

@@ -136,3 +136,67 @@ def test_bf16_wire_between_rank_processes(one_rank):
         # gradients cross the wire in bf16 (8 significand bits), the update is normalised by AdamW: parameters stay close
         assert float(np.abs(w - w1).max()) < 5e-3
     assert np.array_equal(outs[0][6], outs[1][6])
+
+
+def _train_rank(rank, world, port, q, tmp):
+    import torch.distributed as dist
+    import audio_to_midi_amd as amt
+    from audio_to_midi_amd import synth, train
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    model = amt.OutputSequenceGenerator(_conf(), key=11, dtype="bfloat16", gamma=1.0)
+    batches = [synth.make_batch(4 * world, 320 * 48, seed=30 + j) for j in range(3)]
+
+    def loader():                                            # this rank's shard of every global batch; (events, audio)
+        for k in range(12):
+            au, ev = batches[k % 3]
+            au, ev = au[rank * 4:rank * 4 + 4], ev[rank * 4:rank * 4 + 4]
+            if k == 5 and rank == world - 1:
+                au = au.copy(); au[1, 0, 1000] = np.nan     # a poisoned sample on ONE rank: every rank must skip that step
+            yield ev, au
+
+    logs = []
+    out = train.train(model, loader(), num_steps=12, base_learning_rate=2e-3, warmup_steps=3, dist=dist, checkpoint_dir=tmp,
+                      checkpoint_every=10, print_every=0, log=logs.append)
+    q.put((rank, out["steps"], out["applied"], out["skipped"], [h[0] for h in out["history"]], [h[1] for h in out["history"]],
+           model.weights_tensor().cpu().numpy().copy(), sorted(os.listdir(tmp))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_entry_across_rank_processes(tmp_path):
+    """audio_to_midi_amd.train.train(dist=...) - the reference's loop (train.py:211-452) with its data-parallel step - in two
+    rank processes: schedule, input feeder, signalled overlap, in-place collectives, device-gated optimizer, rank-0 checkpoints.
+    The step whose batch is poisoned on ONE rank is skipped by BOTH (the non-finite value travels through the SUM), the
+    update counts agree, and the replicas end bit-identical."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    dirs = [tmp_path / f"rank{r}" for r in range(world)]
+    for d in dirs:
+        d.mkdir()
+    procs = [ctx.Process(target=_train_rank, args=(r, world, port, q, str(dirs[r]))) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {}
+    try:
+        for _ in range(world):
+            o = q.get(timeout=600)
+            outs[o[0]] = o
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    for r in range(world):
+        _, steps, applied, skipped, hsteps, hloss, w, files = outs[r]
+        assert steps == 12 and applied == 11 and skipped == 1 and 6 not in hsteps and len(hsteps) == 11, (r, steps, applied, skipped, hsteps)
+        assert np.isfinite(w).all()
+        assert files == (["metadata_10.json", "params_10.f32"] if r == 0 else [])        # rank 0 writes the checkpoints
+    assert np.array_equal(outs[0][6], outs[1][6])
+    assert np.allclose(outs[0][5], outs[1][5], rtol=1e-6)        # the loss every rank reports is the global mean
+    assert np.mean(outs[0][5][-3:]) < np.mean(outs[0][5][:3])
