@@ -354,8 +354,13 @@ int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* si
   memset(&g, 0, sizeof(g));
   if (n <= 0) return 0;
   g.n = n;
-  static const int xcd_order = getenv("AMT_WGRAD_XCD") ? atoi(getenv("AMT_WGRAD_XCD")) : 0;   // measured: 0 (profiles/r02_notes.md)
-  g.xcd = xcd_order;
+  // XCD-aware item order (kernels.h).  At cfg2 (riders inside latency-bound chain launches) it measured slower: off
+  // (profiles/r02_notes.md).  The stand-alone grouped launches of the large-N schedule (target_override >= 512: no riders from
+  // 8192 tokens on) run at 5.6 TB/s of fabric reads - 208 MB per launch for 119 MB of operands (profiles/r04_pmc_traffic_b32.json)
+  // - and there "every XCD keeps its eighth of every problem" pays: 32 clips 8.21 -> 8.06 ms (0 / 1 / 2: 8.214 / 8.154 / 8.055;
+  // with more token splits so that a split never straddles two XCDs, targets 768 / 1120 / 1536: 8.20 / 8.13 / 8.21).
+  static const int xcd_order = getenv("AMT_WGRAD_XCD") ? atoi(getenv("AMT_WGRAD_XCD")) : -1;
+  g.xcd = xcd_order >= 0 ? xcd_order : (target_override >= 512 ? 2 : 0);
   int total_tiles = 0;
   bool skinny[8];
   for (int i = 0; i < n; ++i) {

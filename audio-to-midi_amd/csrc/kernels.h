@@ -61,7 +61,8 @@ void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a, PartialSink* sin
 // up to 8 independent problems in one launch
 // xcd = 1: workgroup b of the group takes work item (b % 8) * (total / 8) + b / 8 (wgrad.h), so that the tiles of one token
 // split - which read the same two operand panels - run on ONE XCD and the panels cross the fabric once, not up to 8 times;
-// xcd = 2: the same within each problem.  Opt-in (AMT_WGRAD_XCD): fabric reads fall by 40-55 % and the step gets slower.
+// xcd = 2: the same within each problem.  AMT_WGRAD_XCD; default 0 for riders (fabric reads fall by 40-55 % and the cfg2 step
+// gets slower) and 2 for the stand-alone grouped launches of the large-N schedule (gemm.hip: wgrad_group_prepare).
 struct WgradGroup { int n; int prefix[9]; int tiles[8]; int tiles_k[8]; int rps[8]; int xcd; WgradArgs p[8]; };
 // target_wgs > 0: aim for about that many workgroups (default: AMT_WGRAD_TARGET_WGS / 336)
 void gemm_tn_wgrad_group(hipStream_t s, DType dt, const WgradArgs* probs, int n, PartialSink* sink = nullptr, int target_wgs = 0);

@@ -64,6 +64,17 @@ def load(d, counter):
     return acc
 
 
+def total(d, counter):
+    """sum of the counter over EVERY kernel of the run (classified or not), and the number of profiled launches"""
+    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    t, n, steps = 0.0, 0, 0
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            t += float(r["Counter_Value"]); n += 1
+            steps += "bce_kernel" in r["Kernel_Name"]          # one launch per training step
+    return t, n, steps
+
+
 def graph_durations(stats_csv):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(stats_csv)):
@@ -100,5 +111,13 @@ if __name__ == "__main__":
                                           else "x2 (wide coalesced reads, MI355X_MICROARCH.md)"}
             if c in gd:
                 out[c]["avg_launch_us_graph"] = round(gd[c], 2)
+    # the whole run (bench.py --steps 3 --warmup 1 --no-graph: 4 training steps + the eager preparation runs; divide by the
+    # steps the caller knows it ran): every kernel, classified or not
+    ft, fn, fs = total(sys.argv[1], "FETCH_SIZE")
+    wt, wn, ws = total(sys.argv[2], "WRITE_SIZE")
+    out["_run_total"] = {"fetch_size_kb_raw": ft, "write_size_kb": wt, "launches": fn, "training_steps": fs,
+                         "hbm_bytes_fetch_x2": (2 * ft + wt) * 1024, "hbm_bytes_fetch_x1": (ft + wt) * 1024,
+                         "hbm_bytes_per_step_fetch_x2": (2 * ft + wt) * 1024 / max(fs, 1),
+                         "hbm_bytes_per_step_fetch_x1": (ft + wt) * 1024 / max(fs, 1)}
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))

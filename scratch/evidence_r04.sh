@@ -1,5 +1,6 @@
 # Round-4 evidence: tests, benches, rocprofv3 kernel stats (graph replay), PMC traffic, SQ (MFMA) counters.  On the GPU box:
-#   gpurun --timeout 1190 -- 'bash scratch/evidence_r04.sh'
+#   gpurun --timeout 1190 -- 'bash scratch/evidence_r04.sh'      (part A: tests, bench lines, rocprofv3 kernel stats)
+#   gpurun --timeout 1190 -- 'bash scratch/evidence_r04_pmc.sh'  (part B: PMC passes, final bench line with them, N > 1 rehearsal)
 set -u
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/ev4
@@ -17,22 +18,16 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/kstats -o ks -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --profile-steps 0 > $R/$O/kstats.log 2>&1; echo kstats rc=$?
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/kstats_b32 -o ks -- python3 $R/bench.py --no-cpu-baseline --clips-per-gpu 32 --steps 10 --warmup 3 --profile-steps 0 > $R/$O/kstats_b32.log 2>&1; echo kstats_b32 rc=$?
-P="--steps 3 --warmup 1 --no-cpu-baseline --no-graph --profile-steps 0 --resident-inputs"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_fetch -- python3 $R/bench.py $P > $R/$O/pmc_fetch.log 2>&1; echo pmc_fetch rc=$?
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_write -- python3 $R/bench.py $P > $R/$O/pmc_write.log 2>&1; echo pmc_write rc=$?
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $R/$O/pmc_sq -- python3 $R/bench.py $P > $R/$O/pmc_sq.log 2>&1; echo pmc_sq rc=$?
 cd $R
 cp $O/kstats/ks_kernel_stats.csv $O/r04_kernel_stats_graph.csv 2>/dev/null || cp $O/kstats/*/*kernel_stats.csv $O/r04_kernel_stats_graph.csv
 cp $O/kstats_b32/ks_kernel_stats.csv $O/r04_kernel_stats_b32.csv 2>/dev/null || cp $O/kstats_b32/*/*kernel_stats.csv $O/r04_kernel_stats_b32.csv
-python profiles/make_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic_by_class.json $O/r04_kernel_stats_graph.csv > $O/make_traffic.log 2>&1; echo traffic rc=$?
-python profiles/make_mfma.py $O/pmc_sq $O/pmc_mfma_by_class.json > $O/make_mfma.log 2>&1; echo mfma rc=$?
-find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
+find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete
 ls $O
 python - <<'PY'
 import json
 for f in ('bench','bench_resident','bench_infer','bench_b32','bench_overlap','bench_overlap_two_calls','bench_overlap_round3_protocol'):
     try:
         d=json.loads(open(f'gpurun_out/ev4/{f}.json').read().strip().splitlines()[-1])
-        print(f, d['value'], d['ms_per_step'], d.get('ms_per_step_resident_inputs'), d.get('roofline') and {k:d['roofline'].get(k) for k in ('kernel','bound','achieved','frac','traffic','mfma_busy','avg_launch_us')}, d.get('cpu_baseline') and d['cpu_baseline']['value'])
+        print(f, d['value'], d['ms_per_step'], d.get('ms_per_step_resident_inputs'), d.get('cpu_baseline') and d['cpu_baseline']['value'])
     except Exception as e: print(f, 'ERR', e)
 PY
