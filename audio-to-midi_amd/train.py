@@ -136,14 +136,33 @@ class HipTrainBackend:
         self.accum_steps = int(accum_steps)
         if self.accum_steps < 1 or audio.shape[0] % self.accum_steps:
             raise ValueError("the rank's batch must be divisible by accum_steps")
-        mb = audio.shape[0] // self.accum_steps
-        self._mb = [(audio[i * mb:(i + 1) * mb], labels[i * mb:(i + 1) * mb]) for i in range(self.accum_steps)]
+        # input sets: the step reads FIXED device tensors (its launches are captured); a second set (add_input_set) lets the
+        # upload of the next batch land where the NEXT step reads it while this step still reads its own (InputFeeder)
+        self._sets = [(audio, labels)]
+        self.active = 0
+        self._mb = self._minibatches(audio, labels)
         dev = audio.device
         self.loss_buf = torch.zeros(2, dtype=torch.float32, device=dev)
         self.valid_buf = torch.ones(1, dtype=torch.int32, device=dev)
         self.split = model.grad_bucket_split()
         if use_optimizer:
             model.init_optimizer(self.optimizer_args.get("layer_lr_decay", 0.7))
+
+    def _minibatches(self, audio, labels):
+        mb = audio.shape[0] // self.accum_steps
+        return [(audio[i * mb:(i + 1) * mb], labels[i * mb:(i + 1) * mb]) for i in range(self.accum_steps)]
+
+    def add_input_set(self):
+        """A further pair of input tensors (a copy of set 0, so that rehearsal runs on it are finite); returns its index."""
+        a0, y0 = self._sets[0]
+        self._sets.append((a0.clone(), y0.clone()))
+        return len(self._sets) - 1
+
+    def use_set(self, i: int):
+        """The input set the NEXT issued (or captured) step reads."""
+        self.active = int(i)
+        self.audio, self.labels = self._sets[self.active]
+        self._mb = self._minibatches(self.audio, self.labels)
 
     def full(self, seed: int):
         b, k = self.bucket, self.accum_steps
@@ -239,25 +258,40 @@ class InputFeeder:
     (the reference uploads each minibatch inside its step: ``jax.device_put(batch, batch_sharding)``, train.py:280).
 
     The step (a captured hipGraph) reads FIXED device tensors, and it reads them until its very end (the Stem's backward
-    re-reads the audio), so the upload of batch k + 1 goes into one of two staging pairs while step k runs; ``take()`` - in
-    front of step k + 1 on the compute stream - waits for it and copies staging -> inputs on the device (6.6 MB at the
-    reference configuration: two small launches).  ``prefetch()`` may be called right after the step has been issued.
+    re-reads the audio), so batch k + 1 cannot be uploaded over batch k while step k runs.  Two forms:
 
-    Which way the streams wait for each other matters on this platform (scratch/feeder_cost.py, profiles/r04_notes.md): the
-    compute stream waiting for an event of the copy stream costs ~20 us per step, but ANOTHER stream waiting for an event
-    recorded on the busy compute stream costs 0.12 ms per step (round 4's first form: 3.15 against 3.02 ms).  So the
-    "staging consumed" hand-back is a HOST wait on an event the compute stream recorded a step earlier (long complete by
-    then), and no stream ever waits for the compute stream: 3.045 ms."""
+    * ``InputFeeder(backend=be)`` (bench.py, train()): the backend gets a SECOND input set and the step is captured once per
+      set (DataParallelStep.prepare); the upload of batch k + 1 goes straight into the set step k does not read, ``take()``
+      makes the compute stream wait for it and switches the backend to that set.  Nothing is copied on the device.
+    * ``InputFeeder(audio_dev, labels_dev)``: one input pair, two staging pairs; ``take()`` copies staging -> inputs on the
+      device in front of the step (6.6 MB at the reference configuration: two small launches, ~1 % of the step).
 
-    def __init__(self, audio_dev: torch.Tensor, labels_dev: torch.Tensor):
-        self.audio, self.labels = audio_dev, labels_dev
-        self.stage = [(torch.empty_like(audio_dev), torch.empty_like(labels_dev)) for _ in range(2)]
-        self.copy_stream = torch.cuda.Stream(device=audio_dev.device)
+    ``prefetch()`` may be called right after the step has been issued.  Which way the streams wait for each other matters
+    on this platform (scratch/feeder_cost.py, profiles/r04_notes.md): the compute stream waiting for an event of the copy
+    stream costs ~20 us per step, and ANOTHER stream waiting for an event recorded on the busy compute stream costs
+    0.12 ms per step (round 4's first form: 3.15 against 3.02 ms).  So both hand-overs are HOST waits on events that are long
+    complete when they are waited for - "this buffer may be overwritten" on an event the compute stream recorded a step
+    earlier, "the upload has landed" on the copy stream's event, 0.13 ms after it was issued a step ago - and no stream ever
+    waits for another."""
+
+    def __init__(self, audio_dev: Optional[torch.Tensor] = None, labels_dev: Optional[torch.Tensor] = None, backend=None):
+        self.backend = backend
+        if backend is not None:
+            while len(backend._sets) < 2:
+                backend.add_input_set()
+            self.stage = list(backend._sets[:2])                         # uploads land where a step reads them
+            self.audio, self.labels = backend._sets[0]
+            self.up = 1 - backend.active                                 # first upload: the set the NEXT step will read
+        else:
+            self.audio, self.labels = audio_dev, labels_dev
+            self.stage = [(torch.empty_like(audio_dev), torch.empty_like(labels_dev)) for _ in range(2)]
+            self.up = 0
+        self.down = self.up                                              # next pair to take from
+        self.copy_stream = torch.cuda.Stream(device=self.audio.device)
         self.ready = [torch.cuda.Event(), torch.cuda.Event()]         # upload into pair i finished (copy stream)
-        self.consumed = [None, None]                                   # pair i copied into the inputs (compute stream)
-        self.up, self.down = 0, 0                                      # next pair to upload into / to take from
+        self.consumed = [None, None]                                   # pair i has been read for the last time (compute stream)
         self.pending = 0
-        self.bytes_per_batch = audio_dev.numel() * audio_dev.element_size() + labels_dev.numel() * labels_dev.element_size()
+        self.bytes_per_batch = self.audio.numel() * self.audio.element_size() + self.labels.numel() * self.labels.element_size()
         self._ring, self._ring_ev, self._slot = None, None, 0      # two pinned host pairs for prefetch_from_host
 
     @staticmethod
@@ -269,8 +303,8 @@ class InputFeeder:
         return a, y
 
     def prefetch(self, host_audio: torch.Tensor, host_labels: torch.Tensor):
-        if self.pending >= 2:
-            raise RuntimeError("both staging pairs hold batches that have not been taken")
+        if self.pending >= (1 if self.backend is not None else 2):
+            raise RuntimeError("the staging pairs hold batches that have not been taken")
         i = self.up
         self.up ^= 1
         if self.consumed[i] is not None:
@@ -301,17 +335,28 @@ class InputFeeder:
         self._ring_ev[k] = ev
 
     def take(self):
+        """In front of a step, on the compute stream: the step issued next reads the batch uploaded last."""
         if not self.pending:
             return
         i = self.down
         self.down ^= 1
         cur = torch.cuda.current_stream(self.audio.device)
-        cur.wait_event(self.ready[i])
-        self.audio.copy_(self.stage[i][0], non_blocking=True)
-        self.labels.copy_(self.stage[i][1], non_blocking=True)
-        if self.consumed[i] is None:
-            self.consumed[i] = torch.cuda.Event()
-        self.consumed[i].record(cur)
+        if self.backend is not None:
+            # everything issued so far - the last step that read the OTHER set included - is in front of this event: once
+            # it has completed, that set may be overwritten by the upload after next
+            j = self.backend.active
+            if self.consumed[j] is None:
+                self.consumed[j] = torch.cuda.Event()
+            self.consumed[j].record(cur)
+            self.ready[i].synchronize()      # HOST wait for the upload (issued a step ago, 0.13 ms long): no stream waits at all
+            self.backend.use_set(i)
+        else:
+            self.ready[i].synchronize()
+            self.audio.copy_(self.stage[i][0], non_blocking=True)
+            self.labels.copy_(self.stage[i][1], non_blocking=True)
+            if self.consumed[i] is None:
+                self.consumed[i] = torch.cuda.Event()
+            self.consumed[i].record(cur)
         self.pending -= 1
 
 
@@ -370,6 +415,7 @@ class DataParallelStep:
         self.applied = 0          # optimizer updates actually applied (device count, refreshed by result())
         self.optimizer_timeouts = 0   # barrier time-outs of the one-launch optimizer (no step is lost to one; refreshed by result())
         self._graphs = None
+        self._graph_sets = []
         self._half_done = None
         self._gen = None
         self._comm = torch.cuda.Stream(device=bucket.buf.device) if self.cuda else None
@@ -471,27 +517,40 @@ class DataParallelStep:
                 be.half(1, seed); be.half(2, seed)
                 discard()
         torch.cuda.current_stream().wait_stream(side)
+        # one capture per input set of the backend (HipTrainBackend.add_input_set): the same launches on other input pointers
+        nsets = len(getattr(be, "_sets", [None]))
+        active = getattr(be, "active", 0)
+        self._graph_sets = []
+        for i in range(nsets):
+            if nsets > 1:
+                be.use_set(i)
+            self._graph_sets.append(self._capture(seed))
+        if nsets > 1:
+            be.use_set(active)
+        self._graphs = self._graph_sets[active if nsets > 1 else 0]
+        self._gen = be.generation() if hasattr(be, "generation") else None
+
+    def _capture(self, seed: int):
+        be = self.backend
         if self.signal:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 be.advance_seed()
                 be.full_signal(seed)
-            self._graphs = (g,)
-        elif self.overlap:
+            return (g,)
+        if self.overlap:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga):
                 be.advance_seed()
                 be.half(1, seed)
             with torch.cuda.graph(gb, pool=ga.pool()):
                 be.half(2, seed)
-            self._graphs = (ga, gb)
-        else:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                be.advance_seed()
-                be.full(seed)
-            self._graphs = (g,)
-        self._gen = be.generation() if hasattr(be, "generation") else None
+            return (ga, gb)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            be.advance_seed()
+            be.full(seed)
+        return (g,)
 
     def _check_generation(self):
         if self._graphs is not None and self._gen is not None and self.backend.generation() != self._gen:
@@ -506,6 +565,8 @@ class DataParallelStep:
         be, b = self.backend, self.bucket
         seed = self.step_no if seed is None else seed
         self._check_generation()
+        if self._graphs is not None and len(self._graph_sets) > 1:
+            self._graphs = self._graph_sets[be.active]      # the graph captured on the input set this step reads
         if self.signal:
             # ONE graph (the single-rank step's launch sequence).  The host waits for the signal the graph publishes behind
             # its first CNN Block chain (mapped host memory), then issues the collective of [split, n) + loss on the
@@ -631,16 +692,20 @@ def train(model, data_loader, *, num_steps: int, base_learning_rate: float = 1e-
     schedule = create_learning_rate_schedule(base_learning_rate, warmup_steps, num_steps)
     hyper = dict(layer_lr_decay=layer_lr_decay, weight_decay=weight_decay)
 
-    def build(scale):
+    def build(scale, old=None):
         be = HipTrainBackend(model, audio_dev, labels_dev, bucket, scale=scale, fused=True, accum_steps=accum_steps,
                              optimizer_args=hyper)
+        if old is None:
+            be.add_input_set()             # two input sets, the step captured on each: uploads land where a step reads them
+        else:                              # a re-capture (new loss scale) keeps the input tensors and the one in use
+            be._sets = old._sets
+            be.use_set(old.active)
         step = DataParallelStep(be, bucket, be.split, dist=dist, overlap=overlap, graph=True, lr_base=schedule(0))
         step.prepare(seed=seed)
         return be, step
 
     be, dp = build(controller.scale)
-    feeder = InputFeeder(audio_dev, labels_dev)      # (the backend reads these very tensors: same dtype, no copy was made)
-    assert be.audio.data_ptr() == audio_dev.data_ptr()
+    feeder = InputFeeder(backend=be)
     history, skipped, issued, timeouts_seen = [], 0, 0, 0
     loss_sum, loss_n = 0.0, 0
     saved = []
@@ -670,11 +735,13 @@ def train(model, data_loader, *, num_steps: int, base_learning_rate: float = 1e-
                 skipped += 1
                 log(f"Encountered NAN/inf loss at step {step_no}, loss = {loss}. Skipped on the device; grad scale -> {controller.scale}")
                 if controller.enabled:
-                    be, dp = build(controller.scale)       # the scale is an argument of the captured launches
+                    be, dp = build(controller.scale, be)   # the scale is an argument of the captured launches
+                    feeder.backend = be
                 continue
             elif controller.enabled and be.scale != controller.scale:
                 log(f"Grad scale: {be.scale} -> {controller.scale}")
-                be, dp = build(controller.scale)
+                be, dp = build(controller.scale, be)
+                feeder.backend = be
             if valid:
                 loss_sum += loss; loss_n += 1
                 history.append((step_no, loss))

@@ -453,13 +453,15 @@ def main():
     backend = amt_train.HipTrainBackend(model, audio, labels, bucket, scale=1.0, use_optimizer=not args.no_optimizer, fused=fused)
     dp = amt_train.DataParallelStep(backend, bucket, backend.split, dist=dist, overlap=overlap, graph=not args.no_graph,
                                     lr_base=1e-4, signal=False if args.no_signal else None, wire=args.wire)
+    if not args.resident_inputs:
+        backend.add_input_set()  # a second input set: the step is captured once per set, uploads land where a step reads them
     dp.prepare(seed=12345)       # every allocation (optimizer state, workspace plan) happens before graph capture
     graph = dp._graphs
     # A fresh batch per step (train.py:280: the reference uploads every minibatch): four distinct pinned host batches in
     # rotation, batch k + 1 on its way over PCIe on a copy stream while step k computes (audio_to_midi_amd.train.InputFeeder)
     feeder, host_pool = None, []
     if not args.resident_inputs:
-        feeder = amt_train.InputFeeder(backend.audio, labels)
+        feeder = amt_train.InputFeeder(backend=backend)
         host_pool = [amt_train.InputFeeder.pin(audio_np, labels_np, model.audio_dtype)]
         for j in range(1, 4):
             an, yn = amt.synth.make_batch_fast(B_PER_GPU, T_SAMPLES, seed=1000 * j + rank)
@@ -571,7 +573,7 @@ def main():
                              "not a scaling measurement", "optimizer_timeouts": int(dp.optimizer_timeouts)} if rehearse else {}),
             "inputs": ("resident in HBM (same batch every step)" if feeder is None else
                        f"fresh batch per step: {feeder.bytes_per_batch / 1e6:.2f} MB from pinned host memory over PCIe on a copy stream, "
-                       "double-buffered (train.py:280)"),
+                       "straight into the input set the next step reads (two input sets, the step captured on each; train.py:280)"),
             "h2d_overlapped": None if feeder is None else True,
             "ms_per_step_resident_inputs": None if resident_ms is None else round(resident_ms, 4),
             "loss": round(loss_val, 3), "grads_valid": bool(grads_valid), "loss_finite": True,

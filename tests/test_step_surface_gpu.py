@@ -355,6 +355,45 @@ def test_data_parallel_step_uses_the_fused_protocol_under_graph_replay(small_con
     assert float((outs[True][1] - outs[False][1]).abs().max()) < 5e-6
 
 
+@pytest.mark.parametrize("form", ["two input sets", "staging copies"])
+def test_input_feeder_hands_every_step_its_own_batch(small_conf, form):
+    """train.InputFeeder (train.py:280: a fresh batch per step) in both forms - uploads straight into the input set the next
+    captured step reads (the step is captured once per set), and staging pairs copied on the device in front of the step.
+    With a zero learning rate the parameters stay put, so the loss of step k is a function of batch k alone: six steps over
+    three distinct batches must report, in order, the losses of those batches evaluated one by one."""
+    conf = dict(small_conf); conf["transformer_dropout_rate"] = 0.0
+    model = amt.OutputSequenceGenerator(conf, key=8, dtype="float32", gamma=1.0)
+    batches = [synth.make_batch(2, 320 * 48, seed=50 + j) for j in range(3)]
+    want = []
+    for au, ev in batches:
+        out = model.loss_and_grads(torch.from_numpy(au), torch.from_numpy(ev), seed=1, train=True)
+        want.append(float(out.loss))
+    assert len({round(w, 3) for w in want}) == 3
+    a0, y0 = torch.from_numpy(batches[0][0]).cuda(), torch.from_numpy(batches[0][1]).cuda()
+    bucket = train.GradBucket.of_model(model)
+    be = train.HipTrainBackend(model, a0, y0, bucket, fused=True)
+    if form == "two input sets":
+        be.add_input_set()
+    dp = train.DataParallelStep(be, bucket, be.split, dist=None, graph=True, lr_base=0.0)
+    dp.prepare(seed=5)
+    feeder = train.InputFeeder(backend=be) if form == "two input sets" else train.InputFeeder(be.audio, be.labels)
+    pinned = [train.InputFeeder.pin(au, ev, model.audio_dtype) for au, ev in batches]
+    feeder.prefetch(*pinned[0])
+    got = []
+    for k in range(6):
+        feeder.take()
+        dp.step()
+        if k + 1 < 6:
+            feeder.prefetch(*pinned[(k + 1) % 3])
+        loss, valid = dp.result()
+        assert valid
+        got.append(loss)
+    for k in range(6):
+        assert abs(got[k] - want[k % 3]) <= 2e-5 * abs(want[k % 3]), (form, k, got, want)
+    if form == "two input sets":
+        assert len(dp._graph_sets) == 2 and be.active in (0, 1)
+
+
 def test_train_entry_loss_falls_and_a_skipped_step_rolls_nothing_forward(small_conf, tmp_path):
     """audio_to_midi_amd.train.train(): the reference's loop (train.py:211-452) wired from the schedule, the loss-scale
     controller, DataParallelStep on the model's own bucket, the double-buffered input feeder and the checkpoint cadence.
