@@ -352,7 +352,8 @@ struct amt_ctx {
   unsigned* half_host_dev = nullptr;       // ... its device address
   int half_timeouts = 0;
   uint32_t half_base = 0, half_waits = 0;
-  int cnn_late_max_c = 0;       // AMT_CNN_WGRAD_LATE=C: weight gradients of the CNN stages with <= C channels as one batch of launches after the pass (1 = all)
+  int cnn_late_max_c = 0;       // AMT_CNN_WGRAD_LATE=C: weight gradients of the CNN stages with <= C channels as one batch of launches after the pass (1 = all, 0 = none)
+  bool cnn_late_env = false;    // not set: none while riders are on, all from 8192 tokens on (run_backward)
   bool fuse_ffn = true;         // AMT_FUSE_FFN=0: second half of a layer as chain + two tiled GEMM launches
   bool lr_idx_ok = false;       // lr_idx / lr_tab describe lr_scale (fewer than 255 depths)
   bool opt_persist = true;      // one-launch fused optimizer (head.hip: adamw_persist_kernel); AMT_OPT_PERSIST=0 or a barrier timeout: two launches
@@ -828,7 +829,8 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   // weight gradient is queued instead, its operands (du, dy) stay in buffers of their own (~220 MB at cfg2) and the
   // batch runs after the pass as 9 grouped launches.  Measured: Block backward 29.4 -> 22.1 us per launch, but the
   // 64 x 64-tile weight-gradient kernel reaches only 87-100 TFLOP/s on the batch (9 x 36-41 us): 3.85-3.91 ms/step
-  // against 3.77 with riders (profiles/r02_notes.md).  Riders stay the default.
+  // against 3.77 with riders (profiles/r02_notes.md).  Riders stay the default at cfg2; at large N, where nothing rides any
+  // more, the late batch is the default (late_for below).
   std::vector<WgradArgs> cnn_late;
   bool late_mode = false;
   auto wgrad = [&](const void* Gm, int ldg, const void* Am, int lda, int n, int M, int Kp, size_t w_off, int ldw,
@@ -1152,7 +1154,12 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
                              1.f / (float)acc_count));
   };
   // CNN stages, last to first
-  auto late_for = [&](int si) { return si >= 0 && !side_on && L.stages[si].C <= c->cnn_late_max_c; };
+  // Default at large N (no riders, from 8192 tokens on): ALL CNN weight gradients late.  A Block's pair of 1x1-conv problems is
+  // 16 tiles - as a launch of its own that is 32 token splits of 500 tokens, four stages and a 16-KB atomic tile per workgroup;
+  // eight problems (four Blocks) per launch: 32 clips per GPU 8.065 -> 7.94 ms (49 -> 25 grouped launches; 512 / 1024 / 2048
+  // workgroups per late launch: 7.94 / 7.99 / 7.94; only C <= 128: 7.96; profiles/r04_notes.md).  At cfg2 riders stay (round 2).
+  const int late_max_c = c->cnn_late_env ? c->cnn_late_max_c : (no_riders ? (1 << 20) : 0);
+  auto late_for = [&](int si) { return si >= 0 && !side_on && L.stages[si].C <= late_max_c; };
   int Lcur = S;
   for (int si = cfg.n_stages - 1; si >= 0; --si) {
     const StageP& st = L.stages[si];
@@ -1250,7 +1257,8 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   signal_first_half();     // (a model without Blocks)
   late_mode = false;
   {   // the CNN weight gradients, 8 problems per launch, many token splits (the launches are large and independent)
-    static const int late_target = getenv("AMT_LATE_WGRAD_WGS") ? atoi(getenv("AMT_LATE_WGRAD_WGS")) : 1024;
+    static const int late_target_env = getenv("AMT_LATE_WGRAD_WGS") ? atoi(getenv("AMT_LATE_WGRAD_WGS")) : 0;
+    const int late_target = late_target_env > 0 ? late_target_env : (no_riders ? 512 : 1024);
     for (size_t i = 0; i < cnn_late.size(); i += 8) {
       const int cnt = (int)std::min<size_t>(8, cnn_late.size() - i);
       gemm_tn_wgrad_group(s, dt, cnn_late.data() + i, cnt, &sink, late_target);
@@ -1503,7 +1511,8 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
     c->team = team_state_create();
     if (c->team == nullptr) { g_create_error = "hipMalloc(team state)"; delete c; return 1; }
   }
-  c->cnn_late_max_c = getenv("AMT_CNN_WGRAD_LATE") ? atoi(getenv("AMT_CNN_WGRAD_LATE")) : 0;
+  c->cnn_late_env = getenv("AMT_CNN_WGRAD_LATE") != nullptr;
+  c->cnn_late_max_c = c->cnn_late_env ? atoi(getenv("AMT_CNN_WGRAD_LATE")) : 0;
   if (c->cnn_late_max_c == 1) c->cnn_late_max_c = 1 << 20;
   if (c->nochain == 0) {   // keep only the conversions the selected execution mode reads (debug mask: keep all)
     const bool chain_tr = c->fuse && cfg->dims[cfg->n_stages - 1] == 256 && cfg->ffn_inter == 512 &&
