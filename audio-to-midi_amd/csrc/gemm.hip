@@ -293,9 +293,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs a, int tiles_k, 
 // several independent weight-gradient problems in ONE launch (all wgrads of a transformer layer or
 // of a CNN block)
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_group_kernel(WgradGroup g) {
+__global__ __launch_bounds__(256) void gemm_tn_group_kernel(WgradGroupWide g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
-  wgrad_group_dispatch<T>(g, blockIdx.x, tn_smem);
+  wgrad_group_dispatch<T, WgradGroupWide>(g, blockIdx.x, tn_smem);
 }
 
 void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a_in, PartialSink* sink) {
@@ -348,11 +348,13 @@ void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a_in, PartialSink* 
 // Fills `g` for up to 8 problems and returns the number of workgroups (0: nothing to launch, e.g.
 // while planning).  One-tile problems with a very long token axis ("skinny", C <= 32 blocks) get many
 // short splits that write per-split records into the sink instead of atomics.
-int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* sink, WgradGroup* gp, double* flops,
-                        double* bytes, int target_override) {
-  WgradGroup& g = *gp;
+template <int CAP>
+static int wgrad_group_prepare_t(DType dt, const WgradArgs* probs, int n, PartialSink* sink, WgradGroupN<CAP>* gp, double* flops,
+                                 double* bytes, int target_override) {
+  WgradGroupN<CAP>& g = *gp;
   memset(&g, 0, sizeof(g));
   if (n <= 0) return 0;
+  if (n > CAP) n = CAP;      // (callers hand over at most CAP problems)
   g.n = n;
   // XCD-aware item order (kernels.h).  At cfg2 (riders inside latency-bound chain launches) it measured slower: off
   // (profiles/r02_notes.md).  The stand-alone grouped launches of the large-N schedule (target_override >= 512: no riders from
@@ -362,7 +364,7 @@ int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* si
   static const int xcd_order = getenv("AMT_WGRAD_XCD") ? atoi(getenv("AMT_WGRAD_XCD")) : -1;
   g.xcd = xcd_order >= 0 ? xcd_order : (target_override >= 512 ? 2 : 0);
   int total_tiles = 0;
-  bool skinny[8];
+  bool skinny[CAP];
   for (int i = 0; i < n; ++i) {
     g.p[i] = probs[i];
     g.tiles_k[i] = (probs[i].Kp + 63) / 64;
@@ -426,10 +428,19 @@ int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* si
   return g.prefix[n];
 }
 
+int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* sink, WgradGroup* g, double* flops, double* bytes,
+                        int target_override) {
+  return wgrad_group_prepare_t<8>(dt, probs, n, sink, g, flops, bytes, target_override);
+}
+int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* sink, WgradGroupWide* g, double* flops, double* bytes,
+                        int target_override) {
+  return wgrad_group_prepare_t<16>(dt, probs, n, sink, g, flops, bytes, target_override);
+}
+
 void gemm_tn_wgrad_group(hipStream_t s, DType dt, const WgradArgs* probs, int n, PartialSink* sink, int target_wgs) {
   if (n <= 0) return;
   if (n == 1 && target_wgs <= 0) { gemm_tn_wgrad(s, dt, probs[0], sink); return; }
-  WgradGroup g;
+  WgradGroupWide g;
   double fl = 0, by = 0;
   const int nwg = wgrad_group_prepare(dt, probs, n, sink, &g, &fl, &by, target_wgs);
   if (nwg <= 0) return;

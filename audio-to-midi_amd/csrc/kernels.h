@@ -58,12 +58,14 @@ struct WgradArgs {
 };
 struct PartialSink;
 void gemm_tn_wgrad(hipStream_t s, DType dt, const WgradArgs& a, PartialSink* sink = nullptr);
-// up to 8 independent problems in one launch
+// up to 16 independent problems in one launch (8 as riders of a chain kernel)
 // xcd = 1: workgroup b of the group takes work item (b % 8) * (total / 8) + b / 8 (wgrad.h), so that the tiles of one token
 // split - which read the same two operand panels - run on ONE XCD and the panels cross the fabric once, not up to 8 times;
 // xcd = 2: the same within each problem.  AMT_WGRAD_XCD; default 0 for riders (fabric reads fall by 40-55 % and the cfg2 step
 // gets slower) and 2 for the stand-alone grouped launches of the large-N schedule (gemm.hip: wgrad_group_prepare).
-struct WgradGroup { int n; int prefix[9]; int tiles[8]; int tiles_k[8]; int rps[8]; int xcd; WgradArgs p[8]; };
+template <int CAP> struct WgradGroupN { int n; int prefix[CAP + 1]; int tiles[CAP]; int tiles_k[CAP]; int rps[CAP]; int xcd; WgradArgs p[CAP]; };
+using WgradGroup = WgradGroupN<8>;        // what a chain kernel carries as riders (a kernel argument of every backward chain)
+using WgradGroupWide = WgradGroupN<16>;   // stand-alone grouped launches (gemm_tn_wgrad_group): up to 16 problems
 // target_wgs > 0: aim for about that many workgroups (default: AMT_WGRAD_TARGET_WGS / 336)
 void gemm_tn_wgrad_group(hipStream_t s, DType dt, const WgradArgs* probs, int n, PartialSink* sink = nullptr, int target_wgs = 0);
 // fills the group (one-tile / long-N problems get per-split records from `sink`); returns the number of
@@ -72,6 +74,8 @@ void gemm_tn_wgrad_group(hipStream_t s, DType dt, const WgradArgs* probs, int n,
 // target_override > 0: aim for about that many workgroups instead of the default (a carrier whose own workgroups
 // leave compute units free asks for as many riders as there are free units).
 int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* sink, WgradGroup* g, double* flops = nullptr,
+                        double* bytes = nullptr, int target_override = 0);
+int wgrad_group_prepare(DType dt, const WgradArgs* probs, int n, PartialSink* sink, WgradGroupWide* g, double* flops = nullptr,
                         double* bytes = nullptr, int target_override = 0);
 
 // ----------------------------------------------------------------------------- per-block partial sums

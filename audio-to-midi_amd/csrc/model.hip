@@ -1157,7 +1157,8 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   // Default at large N (no riders, from 8192 tokens on): ALL CNN weight gradients late.  A Block's pair of 1x1-conv problems is
   // 16 tiles - as a launch of its own that is 32 token splits of 500 tokens, four stages and a 16-KB atomic tile per workgroup;
   // eight problems (four Blocks) per launch: 32 clips per GPU 8.065 -> 7.94 ms (49 -> 25 grouped launches; 512 / 1024 / 2048
-  // workgroups per late launch: 7.94 / 7.99 / 7.94; only C <= 128: 7.96; profiles/r04_notes.md).  At cfg2 riders stay (round 2).
+  // workgroups per late launch: 7.94 / 7.99 / 7.94; only C <= 128: 7.96; profiles/r04_notes.md); sixteen problems and 768
+  // workgroups: 7.88.  At cfg2 riders stay (AMT_CNN_WGRAD_LATE=1 / 32 / 64 there: 3.126 / 2.985 / 3.000 against 2.976 ms).
   const int late_max_c = c->cnn_late_env ? c->cnn_late_max_c : (no_riders ? (1 << 20) : 0);
   auto late_for = [&](int si) { return si >= 0 && !side_on && L.stages[si].C <= late_max_c; };
   int Lcur = S;
@@ -1256,11 +1257,14 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   flush_deferred();
   signal_first_half();     // (a model without Blocks)
   late_mode = false;
-  {   // the CNN weight gradients, 8 problems per launch, many token splits (the launches are large and independent)
+  {   // the CNN weight gradients, 8 problems per launch (16 at large N: 8 / 12 / 16 problems at 512 workgroups 7.943 / 7.906 /
+      // 7.942 ms, 16 at 768 / 1024: 7.882 / 7.891), many token splits (the launches are large and independent)
     static const int late_target_env = getenv("AMT_LATE_WGRAD_WGS") ? atoi(getenv("AMT_LATE_WGRAD_WGS")) : 0;
-    const int late_target = late_target_env > 0 ? late_target_env : (no_riders ? 512 : 1024);
-    for (size_t i = 0; i < cnn_late.size(); i += 8) {
-      const int cnt = (int)std::min<size_t>(8, cnn_late.size() - i);
+    const int late_target = late_target_env > 0 ? late_target_env : (no_riders ? 768 : 1024);
+    static const int late_group = getenv("AMT_LATE_WGRAD_GROUP") ? std::max(1, std::min(16, atoi(getenv("AMT_LATE_WGRAD_GROUP")))) : 16;
+    const size_t per = no_riders ? (size_t)late_group : 8;
+    for (size_t i = 0; i < cnn_late.size(); i += per) {
+      const int cnt = (int)std::min<size_t>(per, cnn_late.size() - i);
       gemm_tn_wgrad_group(s, dt, cnn_late.data() + i, cnt, &sink, late_target);
     }
   }

@@ -223,8 +223,8 @@ AMT_DEV void tn_body(const WgradArgs& a, int tiles_k, int rows_per_split, int bx
 // needs more token splits to fill the chip, every split adds its whole tile with atomics, and a workgroup is a serial chain
 // of ~35 stage latencies either way.  Removed again; numbers in profiles/r04_notes.md.)
 // several independent weight-gradient problems in one grid: b -> (problem, tile, token split)
-template <typename T>
-AMT_DEV void wgrad_group_dispatch(const WgradGroup& g, int b, unsigned char* smem) {
+template <typename T, typename GROUP = WgradGroup>
+AMT_DEV void wgrad_group_dispatch(const GROUP& g, int b, unsigned char* smem) {
   // Workgroups go to the XCDs round robin (b, b + 8, ... share one), work items are numbered problem by problem, split by
   // split, tile by tile: give every XCD a CONTIGUOUS range of items, i.e. whole token splits, whose tiles then find each
   // other's operand panels in their own L2 (the L2s do not share: a panel read on 8 XCDs crosses the fabric 8 times).
