@@ -876,19 +876,33 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
   // (without riders the grouped launches have the chip to themselves: 512 workgroups - two per compute unit - instead of the
   // 336 that suit a launch shared with a chain; at 32 clips per GPU 336 / 512 / 768: 8.38 / 8.25 / 8.56 ms, profiles/r04_notes.md)
   static const int flush_target_big = getenv("AMT_WGRAD_TARGET_LARGE") ? atoi(getenv("AMT_WGRAD_TARGET_LARGE")) : 512;
+  // AMT_FLUSH_SCOPES=2 (without riders only): the deferred problems of TWO scopes go into one grouped launch - what scope
+  // t - 2 queued reads the scratch region scope t is about to reuse, and is launched at the very beginning of scope t, before
+  // anything of scope t is allocated or written; the residual-gradient buffers rotate over four.  Measured at 32 clips per GPU:
+  // 14 launches of 106 us against 21 of 71 us, 7.878 against 7.863 ms - a transformer layer's five problems (140 tiles) are
+  // already past the size where a grouped launch gets better with more tiles.  Default 1.
+  static const int flush_scopes_env = getenv("AMT_FLUSH_SCOPES") ? atoi(getenv("AMT_FLUSH_SCOPES")) : 1;
+  const int flush_scopes = no_riders ? std::max(1, std::min(2, flush_scopes_env)) : 1;
+  int deferred_scopes = 0;
   auto flush_deferred = [&]() {
-    for (size_t i = 0; i < deferred.size(); i += 8) {
-      int cnt = (int)std::min<size_t>(8, deferred.size() - i);
+    const size_t per = no_riders ? 16 : 8;
+    for (size_t i = 0; i < deferred.size(); i += per) {
+      int cnt = (int)std::min<size_t>(per, deferred.size() - i);
       if (no_riders && cnt > 1) gemm_tn_wgrad_group(s, dt, deferred.data() + i, cnt, &sink, flush_target_big);
       else gemm_tn_wgrad_group(s, dt, deferred.data() + i, cnt, &sink);
     }
     deferred.clear();
+    deferred_scopes = 0;
   };
   auto begin_scope = [&](bool carrier = false) {
     const size_t j = side_done.size();
     if (side_on && j >= 2 && side_done[j - 2] != nullptr) RUN((void)hipStreamWaitEvent(s, side_done[j - 2], 0));
     A.off = mark + (j & 1) * c->scratch_max;
-    if (!carrier || deferred.size() > 8) flush_deferred();
+    if (no_riders) {
+      if (flush_scopes <= 1 || deferred_scopes >= flush_scopes) flush_deferred();
+    } else if (!carrier || deferred.size() > 8) {
+      flush_deferred();
+    }
   };
   auto end_scope = [&]() {
     const size_t j = side_done.size();
@@ -900,6 +914,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
       deferred.insert(deferred.end(), pending.begin(), pending.end());
       pending.clear();
       pending_skinny.clear();
+      if (!deferred.empty()) deferred_scopes++;      // the age, in scopes, of the oldest problem that waits
     }
     if (!pending.empty() || !pending_skinny.empty()) {
       if (side_on) {
@@ -1013,12 +1028,14 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     // smaller problems ride on lnout_bwd_fused, the larger ones on qkv_bwd_fused
     begin_scope(chain_ok && !side_on && !(c->nochain & 128) && !no_riders);
     std::vector<WgradArgs> riders_a, riders_b;
-    for (const WgradArgs& w : deferred) {
-      const int tiles = ((w.M + 63) / 64) * ((w.Kp + 63) / 64);
-      static const int split_tiles = getenv("AMT_RIDER_SPLIT") ? atoi(getenv("AMT_RIDER_SPLIT")) : 24;
-      (tiles < split_tiles ? riders_a : riders_b).push_back(w);
+    if (!no_riders) {     // (without riders what is still deferred here waits for its grouped launch: begin_scope)
+      for (const WgradArgs& w : deferred) {
+        const int tiles = ((w.M + 63) / 64) * ((w.Kp + 63) / 64);
+        static const int split_tiles = getenv("AMT_RIDER_SPLIT") ? atoi(getenv("AMT_RIDER_SPLIT")) : 24;
+        (tiles < split_tiles ? riders_a : riders_b).push_back(w);
+      }
+      deferred.clear();
     }
-    deferred.clear();
     const void* dy = dcur;
     const void* dyd = dy;
     if (dp.thr) {
@@ -1133,6 +1150,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
     end_pass_scope();
   }
   // ---- boundary between the two halves: every gradient of [L.fn_w, n_params) is complete here
+  if (no_riders) flush_deferred();      // (the last transformer scopes' problems: the first range ends here)
   if (dry) c->n_part_desc_half = (int)c->part_descs.size();
   if (phase == 1) {
     flush_deferred();   // the first transformer layer's weight gradients (in the one-call step they ride on stage 6)
