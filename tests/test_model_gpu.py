@@ -584,6 +584,40 @@ def test_large_n_chains_equal_the_short_tile_chains(small_conf, dtype, monkeypat
     assert rel < (1e-5 if dtype == "float32" else 1e-3), rel
 
 
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_large_n_weight_gradient_schedule_equals_the_rider_schedule(small_conf, dtype, monkeypatch):
+    """From 8192 tokens on the backward pass runs another weight-gradient schedule (csrc/model.hip, round 4): no launch
+    carries riders, a transformer scope's problems go out as one grouped launch (XCD-aware item order), and every CNN weight
+    gradient waits for a late batch of 16-problem launches whose operands are kept until the end of the pass.  Same products,
+    another summation order: loss and logits equal the rider schedule's bit for bit (AMT_RIDER_MAX_TOKENS=0: riders at every
+    size), gradients to the atomics' order.  AMT_FLUSH_SCOPES=2 (two scopes per grouped launch) is held to the same."""
+    audio, labels = synth.make_batch(41, 80000, seed=12)          # 10 250 tokens: past the switch
+    a, y = torch.from_numpy(audio), torch.from_numpy(labels)
+    outs = {}
+    for name, env in (("riders", {"AMT_RIDER_MAX_TOKENS": "0"}), ("large-n", {}), ("two-scopes", {"AMT_FLUSH_SCOPES": "2"}),
+                      ("late-off", {"AMT_CNN_WGRAD_LATE": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        model = amt.OutputSequenceGenerator(small_conf, key=31, dtype=dtype, gamma=1.0)
+        for k in env:
+            monkeypatch.delenv(k)
+        step = model.loss_and_grads(a, y, seed=7, train=True, return_logits=True)
+        again = model.loss_and_grads(a, y, seed=7, train=True)              # the second call of a planned shape
+        outs[name] = (step.logits.clone(), step.loss, step.grads_flat.clone(), again.grads_flat.clone())
+        assert step.grads_valid and again.grads_valid
+        model.close()
+    ref = outs["riders"]
+    for name in ("large-n", "two-scopes", "late-off"):
+        o = outs[name]
+        assert torch.equal(o[0], ref[0]), name
+        assert abs(o[1] - ref[1]) <= 1e-6 * abs(ref[1]), name
+        for g in (o[2], o[3]):
+            rel = float((g - ref[2]).norm() / ref[2].norm())
+            assert rel < (1e-5 if dtype == "float32" else 1e-3), (name, rel)
+            worst = float((g - ref[2]).abs().max() / ref[2].abs().max())
+            assert worst < (1e-5 if dtype == "float32" else 2e-3), (name, worst)
+
+
 def test_streaming_size_inference_forms_equal_the_short_tile_chains(small_conf, monkeypatch):
     """From 49 152 tokens on (streaming inference, BASELINE configs[3]) the bf16 forward runs `ffn_fwd_big` as two independent
     workgroups per compute unit on 64-token tiles and the C = 16 / 64 / 128 Blocks as two workgroups per compute unit on
