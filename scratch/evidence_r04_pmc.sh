@@ -33,3 +33,9 @@ for f in ('pmc_traffic_by_class','pmc_traffic_by_class_b32'):
     j=json.load(open(f'gpurun_out/ev4b/{f}.json'))
     print(f, {k:v for k,v in j.items() if k.startswith('_')})
 PY
+# (round 3's protocol once more: the run in part A is sometimes hit by a one-off start-up hiccup of the world-1 RCCL group)
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-fused-optimizer --force-overlap > $O/bench_overlap_round3_protocol.json 2> /dev/null; echo legacy rc=$?
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/ev4b/bench_overlap_round3_protocol.json').read().strip().splitlines()[-1]); print('legacy', d['ms_per_step'], d.get('ms_per_step_resident_inputs'))
+PY
