@@ -429,6 +429,34 @@ def test_train_entry_loss_falls_and_a_skipped_step_rolls_nothing_forward(small_c
     assert step == 40 and flat.size == model.n_params
 
 
+def test_train_entry_recaptures_on_a_new_loss_scale_and_keeps_its_batches_in_order(small_conf):
+    """train(loss_scaling=True): the scale doubles while scaled_loss < 1e4 (train.py:379-382) and is halved by a non-finite
+    step (train.py:369-377); the scale is an argument of the captured launches, so every change re-captures the step - on the
+    SAME two input sets, with the set in use carried over (InputFeeder keeps feeding).  The poisoned batch must still be the
+    one step 8 consumes, after three re-captures."""
+    model = amt.OutputSequenceGenerator(small_conf, key=11, dtype="bfloat16", gamma=1.0)
+    batches = [synth.make_batch(4, 320 * 48, seed=70 + j) for j in range(3)]
+
+    def loader():
+        for k in range(14):
+            au, ev = batches[k % 3]
+            if k == 7:
+                au = au.copy(); au[2, 1, 500] = np.inf
+            yield ev, au
+
+    logs = []
+    out = train.train(model, loader(), num_steps=14, base_learning_rate=1e-3, warmup_steps=2, loss_scaling=True, grad_scale=1.0,
+                      print_every=0, log=logs.append)
+    hist = dict(out["history"])
+    assert out["steps"] == 14 and out["skipped"] == 1 and 8 not in hist and len(hist) == 13, (out["skipped"], sorted(hist))
+    assert out["applied"] == 13 == model.optimizer_count()
+    assert sum("Grad scale" in ln for ln in logs) >= 2 and any("NAN/inf" in ln for ln in logs)
+    assert out["grad_scale"] >= 2.0
+    assert bool(torch.isfinite(model.weights_tensor()).all())
+    # the losses are unscaled whatever the scale was, and they fall over the same three batches
+    assert np.mean([hist[k] for k in (12, 13, 14)]) < np.mean([hist[k] for k in (1, 2, 3)])
+
+
 def test_captured_optimizer_takes_the_two_launch_form(small_conf, monkeypatch):
     """a one-launch optimizer captured into a hipGraph would replay with no host in between to notice a barrier
     time-out.  Under stream capture the fused protocol therefore takes the norm + commit launches: with a context whose
