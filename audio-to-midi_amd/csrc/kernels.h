@@ -311,6 +311,40 @@ struct FfnBwdArgs {
 void ffn_bwd_fused(hipStream_t s, DType dt, const FfnBwdArgs& a, float* dlnw, float* dlnb, PartialSink* sink,
                    const WgradArgs* riders = nullptr, int n_riders = 0);
 
+// ----------------------------------------------------------------------------- XCD-team layer forward (tlayer.hip)
+// The forward of the WHOLE transformer stack (model.py:529-556, 559-670) in ONE launch of one 512-thread workgroup per
+// compute unit.  Clip b is owned by the 32 workgroups of one XCD (team.h).  Inside a team the work of every per-token
+// stage is cut in TWO dimensions - token groups of TG rows x 8 feature groups - so that a workgroup streams 1/8 of a
+// stage's weights for TG (128) tokens instead of all of them for 16, and the stage outputs are exchanged through that
+// XCD's L2 (plain stores, sc1 loads, one flag word per workgroup).  Phases of a layer, all waits on 8 (phase B: 2 n_tg)
+// flag words:  A: LN1 + q / c / k / v projections (+ RoPE)   B: attention core (global: (head, 64-query tile) per
+// workgroup; local: (stripe, head) per wave)   C: output projection + residual   D: LN2 + W1 / GLU   E: W2 + dropout +
+// residual.  Saved tensors, roundings and K orders are those of qkv_fwd_fused / attn_*_fwd / ffn_fwd_fused: same bits.
+constexpr int TLAYER_MAX = 16;
+struct TLayerItem {
+  const void *Wqc, *Wkv, *Wo, *W1, *W2;                    // fragment-PACKED T copies
+  const float *ln1w, *ln1b, *ln2w, *ln2b, *b1, *b2;
+  void *xn, *qc, *kv, *ao, *h /* Res */, *hn, *u, *g, *y /* Res: the next layer's x */;
+  float *m1, *r1, *m2, *r2, *lse;
+  unsigned long long* keepbits;
+};
+struct TLayerArgs {
+  const void* X0;            // input of the first layer (Res)
+  TeamState* st;
+  unsigned long long* stamps;   // optional [grid][n_layers][8] wall-clock stamps (diagnostic builds of the bench)
+  const float *rope_cos, *rope_sin;
+  const uint64_t* seed_dev; uint64_t seed;
+  int B, S, n_layers;
+  int prerot;                // global layers: q / k leave phase A rotated (QkvFwdArgs::rope_cos)
+  int padL, nW;              // local-attention geometry (attn_fwd.h: local_geom)
+  uint32_t drop_thresh24; float inv_keep;
+  TLayerItem it[TLAYER_MAX];
+};
+// false: not served (dtype / size / device), the caller takes the launch-per-operator path
+bool tlayer_fwd(hipStream_t s, DType dt, const TLayerArgs& a);
+// the device part of that answer: 8 XCDs x 32 compute units (one workgroup per compute unit, all resident)
+bool tlayer_fwd_device_ok();
+
 // ----------------------------------------------------------------------------- attention
 struct AttnArgs {
   const void* QC; int ldqc;   // q = QC[:, 0:256] (un-roped)

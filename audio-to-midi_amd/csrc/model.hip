@@ -342,7 +342,10 @@ struct amt_ctx {
   bool attn_nobits = false;     // AMT_ATTN_BITS=0: the attention backward re-hashes its dropout masks (round-2 form, for A/B and the equality test)
   float* amax = nullptr;        // [layers][prev q,k,v,- | cur q,k,v,-]: delayed per-tensor scaling state
   uint64_t* seed_word = nullptr;   // device word added to every dropout seed (amt_seed_word / amt_advance_seed)
-  TeamState* team = nullptr;    // XCD-team protocol words (team.h); null: team launches disabled (AMT_TEAM=0)
+  TeamState* team = nullptr;    // XCD-team protocol words (team.h); null: no team launches (AMT_TEAM=0 and AMT_TLAYER=0)
+  bool team_cnn = false;        // AMT_TEAM=1: the Blocks of a CNN stage as one team launch (chain.hip: block_run_fwd)
+  bool tlayer = false;          // AMT_TLAYER: the transformer stack's forward as one team launch (tlayer.hip)
+  unsigned long long* tl_stamps = nullptr;   // AMT_TLAYER_STAMPS=1: per-phase wall-clock stamps of that launch (amt_tlayer_stamps)
   // run_backward phase 3 ("first half complete" published from inside the launch sequence): the counter, its mapped host
   // copy, and the host's bookkeeping of the value the next wait expects
   GammaDesc* gamma_desc_dev = nullptr;     // one entry per CNN Block (kernels.h: cnn_gamma_finish)
@@ -503,7 +506,7 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
     const int N = B * Lcur;
     sv.blocks.assign(st.blocks.size(), BlockSave());
     // XCD-team form: the whole stage in one launch (team.h; chain.hip: block_run_fwd)
-    if (save && c->fuse && c->team != nullptr && !c->team_dead && C >= 16 && st.blocks.size() >= 2 && st.blocks.size() <= (size_t)BLOCK_RUN_MAX &&
+    if (save && c->fuse && c->team != nullptr && c->team_cnn && !c->team_dead && C >= 16 && st.blocks.size() >= 2 && st.blocks.size() <= (size_t)BLOCK_RUN_MAX &&
         !(c->nochain & 1) && !(c->nochain & 1024)) {
       BlockRunFwdArgs ra;
       memset(&ra, 0, sizeof(ra));
@@ -617,7 +620,69 @@ int run_forward(amt_ctx* c, hipStream_t s, const void* audio, int B, int T, bool
   const size_t mark1 = A.off;
   bool qkv_done = false;   // the current layer's first half was computed by the previous layer's boundary launch
   int qkv_prerot = 0;      // ... and left q / k rotated (QkvFwdArgs::rope_cos)
-  for (size_t li = 0; li < L.layers.size(); ++li) {
+  // XCD-team form: the whole stack in ONE launch (kernels.h: TLayerArgs; tlayer.hip).  Training sizes, the configuration the
+  // chain kernels serve, bf16 attention; the saved tensors are the launch-per-operator path's, so the backward pass is unchanged.
+  bool stack_done = false;
+  if (save && c->tlayer && c->team != nullptr && !c->team_dead && c->fuse && c->fuse_ffn && !fp8 && N < 8192 &&
+      !(c->nochain & (4 | 8)) && H == 256 && cfg.ffn_inter == 512 && cfg.n_heads == 4 && cfg.head_dim == 64 &&
+      cfg.kv_compress == 64 && L.layers.size() >= 1 && L.layers.size() <= (size_t)TLAYER_MAX && (dt == DT_F32 || S > 256)) {
+    TLayerArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.X0 = cur; ta.st = c->team; ta.stamps = c->tl_stamps; ta.rope_cos = c->rope_cos; ta.rope_sin = c->rope_sin;
+    ta.seed_dev = c->seed_word; ta.seed = seed; ta.B = B; ta.S = S; ta.n_layers = (int)L.layers.size();
+    ta.prerot = c->prerot ? 1 : 0;
+    {
+      const int stride = 8, W = 16;             // attn.hip: local_geom
+      const int req = stride - (S - W) % stride;
+      const int pl = req != stride ? req / 2 : 0, pr = req != stride ? req / 2 + (req % 2) : 0;
+      ta.padL = pl; ta.nW = (S + pl + pr - W) / stride + 1;
+    }
+    ta.drop_thresh24 = dp.thr; ta.inv_keep = dp.inv_keep;
+    const void* x = cur;
+    for (size_t li = 0; li < L.layers.size(); ++li) {
+      const LayerP& lp = L.layers[li];
+      LayerSave& ls = c->lsave[li];
+      const bool local = (li % 2 == 0);
+      ls.x = const_cast<void*>(x);
+      ls.xn = A.alloc((size_t)N * H * es);
+      ls.m1 = (float*)A.alloc((size_t)N * sizeof(float));
+      ls.r1 = (float*)A.alloc((size_t)N * sizeof(float));
+      ls.qc = A.alloc((size_t)N * L.QC * es);
+      ls.kv = A.alloc((size_t)N * L.KVW * es);
+      ls.ao = A.alloc((size_t)N * H * es);
+      ls.lse = local ? nullptr : (float*)A.alloc((size_t)B * cfg.n_heads * S * sizeof(float));
+      {
+        const size_t nt = (size_t)(S + 63) / 64;
+        ls.keepbits = (!local && dp.thr && !c->attn_nobits)
+                          ? (unsigned long long*)A.alloc((size_t)B * cfg.n_heads * nt * nt * 64 * sizeof(unsigned long long)) : nullptr;
+      }
+      ls.hn = A.alloc((size_t)N * H * es);
+      ls.m2 = (float*)A.alloc((size_t)N * sizeof(float));
+      ls.r2 = (float*)A.alloc((size_t)N * sizeof(float));
+      ls.u = A.alloc((size_t)N * L.I2 * es);
+      ls.g = A.alloc((size_t)N * (L.I2 / 2) * es);
+      ls.h = A.alloc((size_t)N * H * es);
+      void* y = A.alloc((size_t)N * H * es);
+      ls.prerot = (!local && c->prerot) ? 1 : 0;
+      TLayerItem& it = ta.it[li];
+      it.Wqc = c->WC(lp.c_wqcp); it.Wkv = c->WC(lp.c_wkvp); it.Wo = c->WC(lp.c_wop); it.W1 = c->WC(lp.c_w1p); it.W2 = c->WC(lp.c_w2p);
+      it.ln1w = c->P(lp.ln1_w); it.ln1b = c->P(lp.ln1_b); it.ln2w = c->P(lp.ln2_w); it.ln2b = c->P(lp.ln2_b);
+      it.b1 = c->P(lp.b1); it.b2 = c->P(lp.b2);
+      it.xn = ls.xn; it.qc = ls.qc; it.kv = ls.kv; it.ao = ls.ao; it.h = ls.h; it.hn = ls.hn; it.u = ls.u; it.g = ls.g; it.y = y;
+      it.m1 = ls.m1; it.r1 = ls.r1; it.m2 = ls.m2; it.r2 = ls.r2; it.lse = ls.lse; it.keepbits = ls.keepbits;
+      x = y;
+    }
+    if (dry || A.overflow) {
+      stack_done = true;      // planning: the allocations above are the plan
+    } else if (tlayer_fwd(s, dt, ta)) {
+      stack_done = true;
+    } else {
+      c->err = "tlayer_fwd: not served (AMT_TLAYER=0 selects the launch-per-operator path)";
+      return 1;
+    }
+    cur = const_cast<void*>(x);
+  }
+  for (size_t li = 0; !stack_done && li < L.layers.size(); ++li) {
     const LayerP& lp = L.layers[li];
     LayerSave& ls = c->lsave[li];
     const bool local = (li % 2 == 0);   // model.py:609-611: local layer first, then global
@@ -1529,9 +1594,16 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
   }
   { hipDeviceProp_t pr; c->n_cus = (hipGetDeviceProperties(&pr, c->device) == hipSuccess) ? pr.multiProcessorCount : 0; }
   // XCD-team launches (team.h): opt-in while they are not faster than one launch per Block (profiles/r02_notes.md)
-  if (getenv("AMT_TEAM") && atoi(getenv("AMT_TEAM")) != 0) {
+  c->team_cnn = getenv("AMT_TEAM") && atoi(getenv("AMT_TEAM")) != 0;
+  // the transformer stack's forward as ONE team launch (tlayer.hip)
+  c->tlayer = (getenv("AMT_TLAYER") && atoi(getenv("AMT_TLAYER")) != 0) && tlayer_fwd_device_ok();   // opt-in while it is slower than the chains
+  if (c->team_cnn || c->tlayer) {
     c->team = team_state_create();
     if (c->team == nullptr) { g_create_error = "hipMalloc(team state)"; delete c; return 1; }
+  }
+  if (c->tlayer && getenv("AMT_TLAYER_STAMPS") && atoi(getenv("AMT_TLAYER_STAMPS")) != 0) {
+    if (hipMalloc(reinterpret_cast<void**>(&c->tl_stamps), sizeof(unsigned long long) * 256 * TLAYER_MAX * 8) != hipSuccess) c->tl_stamps = nullptr;
+    else (void)hipMemset(c->tl_stamps, 0, sizeof(unsigned long long) * 256 * TLAYER_MAX * 8);
   }
   c->cnn_late_env = getenv("AMT_CNN_WGRAD_LATE") != nullptr;
   c->cnn_late_max_c = c->cnn_late_env ? atoi(getenv("AMT_CNN_WGRAD_LATE")) : 0;
@@ -1608,7 +1680,7 @@ void amt_destroy(amt_ctx* c) {
   (void)hipSetDevice(c->device);
   void* ptrs[] = {c->params, c->wc, c->head_bias, c->conv_dev, c->conv_prefix_dev, c->rope_cos, c->rope_sin,
                   c->arena.base, c->adam_m, c->adam_v, c->adam_upd, c->lr_scale, c->norm2, c->loss_acc,
-                  c->partials, c->amax, c->gacc, c->team, c->seed_word, c->lr_idx, c->lr_tab, c->half_sig, c->gamma_desc_dev};
+                  c->partials, c->amax, c->gacc, c->team, c->seed_word, c->lr_idx, c->lr_tab, c->half_sig, c->gamma_desc_dev, c->tl_stamps};
   if (c->half_host) { (void)hipDeviceSynchronize(); (void)hipHostFree(const_cast<unsigned*>(c->half_host)); }
   for (const amt_ctx::PlanRec& r : c->plans)
     if (r.desc_dev) (void)hipFree(r.desc_dev);
@@ -1756,6 +1828,15 @@ int32_t amt_advance_seed(amt_ctx* c, uint64_t delta, void* stream) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { c->err = std::string("amt_advance_seed: ") + hipGetErrorString(e); return 1; }
   return 0;
+}
+
+int32_t amt_tlayer_active(const amt_ctx* c) { return c->tlayer && c->team != nullptr && !c->team_dead ? 1 : 0; }
+
+int32_t amt_tlayer_stamps(const amt_ctx* c, uint64_t* out, int32_t max_words) {
+  if (c->tl_stamps == nullptr || out == nullptr) return 0;
+  const int n = std::min<int>(max_words, 256 * TLAYER_MAX * 8);
+  if (hipMemcpy(out, c->tl_stamps, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return n;
 }
 
 int32_t amt_team_status(const amt_ctx* c) {

@@ -108,6 +108,37 @@ template <bool SC1> AMT_DEV void team_load8f(__amdgpu_buffer_rsrc_t rs, const fl
   }
 }
 
+// raw 8-element chunk (no conversion) at element offset `elem` of `base`; SC1 = false: a plain load
+template <bool SC1> AMT_DEV Chunk8<bf16> team_chunk_load(const bf16* base, size_t elem) {
+  if constexpr (SC1) {
+    Chunk8<bf16> c;
+    c.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(team_rsrc(base), (int)(elem * 2), 0, 16));
+    return c;
+  } else {
+    return chunk_load(base + elem);
+  }
+}
+template <bool SC1> AMT_DEV Chunk8<f16> team_chunk_load(const f16* base, size_t elem) {
+  if constexpr (SC1) {
+    Chunk8<f16> c;
+    c.v = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(team_rsrc(base), (int)(elem * 2), 0, 16));
+    return c;
+  } else {
+    return chunk_load(base + elem);
+  }
+}
+template <bool SC1> AMT_DEV Chunk8<float> team_chunk_load(const float* base, size_t elem) {
+  if constexpr (SC1) {
+    Chunk8<float> c;
+    const __amdgpu_buffer_rsrc_t rs = team_rsrc(base);
+    c.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 4), 0, 16));
+    c.b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 4 + 16), 0, 16));
+    return c;
+  } else {
+    return chunk_load(base + elem);
+  }
+}
+
 // Every workgroup of the launch calls team_register once, first, and team_assemble after it (work that needs only the
 // XCC id and the arrival rank - e.g. warming the first operands into the XCD's L2 - fits in between).
 // Team = XCC id; rank by arrival; team_assemble waits (bounded) until all gridDim.x workgroups have registered, so every

@@ -383,6 +383,24 @@ class OutputSequenceGenerator:
         """0 unless an in-launch XCD-team hand-off has timed out (fatal; include/amt.h: amt_team_status)."""
         return int(self._L.amt_team_status(self._h))
 
+    def tlayer_active(self) -> bool:
+        """True when training-size calls run the transformer stack's forward as ONE XCD-team launch (csrc/tlayer.hip;
+        include/amt.h: amt_tlayer_active); AMT_TLAYER=0 selects one launch per operator chain."""
+        return bool(self._L.amt_tlayer_active(self._h))
+
+    def tlayer_stamps(self, n_layers: int):
+        """Per-phase wall-clock stamps (100 MHz) of the last team launch as an int64 array [256 workgroups][n_layers][8]
+        (contexts created under AMT_TLAYER_STAMPS=1; None otherwise)."""
+        import ctypes
+
+        import numpy as np
+        n = 256 * n_layers * 8
+        buf = np.zeros(n, dtype=np.uint64)
+        got = int(self._L.amt_tlayer_stamps(self._h, buf.ctypes.data_as(ctypes.c_void_p), n))
+        if got <= 0:
+            return None
+        return buf.astype(np.int64).reshape(256, n_layers, 8)
+
 
 class _DevView:
     """Wrap a raw device pointer as a torch tensor through __cuda_array_interface__."""
