@@ -331,7 +331,7 @@ struct TLayerItem {
 struct TLayerArgs {
   const void* X0;            // input of the first layer (Res)
   TeamState* st;
-  unsigned long long* stamps;   // optional [grid][n_layers][8] wall-clock stamps (diagnostic builds of the bench)
+  unsigned long long* stamps;   // optional [grid][n_layers][32] wall-clock stamps (diagnostic builds of the bench)
   const float *rope_cos, *rope_sin;
   const uint64_t* seed_dev; uint64_t seed;
   int B, S, n_layers;

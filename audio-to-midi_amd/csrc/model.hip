@@ -1602,8 +1602,8 @@ int32_t amt_create(const amt_config* cfg, int32_t device, amt_ctx** out) {
     if (c->team == nullptr) { g_create_error = "hipMalloc(team state)"; delete c; return 1; }
   }
   if (c->tlayer && getenv("AMT_TLAYER_STAMPS") && atoi(getenv("AMT_TLAYER_STAMPS")) != 0) {
-    if (hipMalloc(reinterpret_cast<void**>(&c->tl_stamps), sizeof(unsigned long long) * 256 * TLAYER_MAX * 8) != hipSuccess) c->tl_stamps = nullptr;
-    else (void)hipMemset(c->tl_stamps, 0, sizeof(unsigned long long) * 256 * TLAYER_MAX * 8);
+    if (hipMalloc(reinterpret_cast<void**>(&c->tl_stamps), sizeof(unsigned long long) * 256 * TLAYER_MAX * 32) != hipSuccess) c->tl_stamps = nullptr;
+    else (void)hipMemset(c->tl_stamps, 0, sizeof(unsigned long long) * 256 * TLAYER_MAX * 32);
   }
   c->cnn_late_env = getenv("AMT_CNN_WGRAD_LATE") != nullptr;
   c->cnn_late_max_c = c->cnn_late_env ? atoi(getenv("AMT_CNN_WGRAD_LATE")) : 0;
@@ -1834,7 +1834,7 @@ int32_t amt_tlayer_active(const amt_ctx* c) { return c->tlayer && c->team != nul
 
 int32_t amt_tlayer_stamps(const amt_ctx* c, uint64_t* out, int32_t max_words) {
   if (c->tl_stamps == nullptr || out == nullptr) return 0;
-  const int n = std::min<int>(max_words, 256 * TLAYER_MAX * 8);
+  const int n = std::min<int>(max_words, 256 * TLAYER_MAX * 32);
   if (hipMemcpy(out, c->tl_stamps, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return n;
 }

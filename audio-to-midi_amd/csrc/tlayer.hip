@@ -26,10 +26,10 @@ namespace {
 // phases kept each other's addresses and weight fragments alive: 256 registers and 70 spilled)
 #define TL_PHASE __device__ __attribute__((noinline))
 constexpr int TL_THREADS = 512;
-constexpr int TL_NF = 8;            // feature groups per token group
+constexpr int TL_NF = 4;            // feature groups per token group (= heads)
 constexpr unsigned TL_SPIN_LIMIT = 1u << 21;
 
-template <typename T> struct TlTile { static constexpr int TG = sizeof(T) == 2 ? 128 : 64; };
+template <typename T> struct TlTile { static constexpr int TG = sizeof(T) == 2 ? 64 : 32; };   // rows per token group
 
 struct TlEnv {
   int tid, lane, wave;
@@ -49,7 +49,10 @@ struct TlConst {
   int B, S, n_layers, prerot, padL, nW;
   unsigned thr; float inv_keep;
   int xcc, rank, size;   // this workgroup's team (team.h)
+  unsigned long long* stamps;   // diagnostic (TLayerArgs::stamps)
 };
+constexpr int TL_STAMP_SLOTS = 32;   // per (workgroup, layer): 0..5 phase boundaries, 8.. inside the phases
+#define TL_SUB(k) do { unsigned long long* sp_ = tl_p(s_c.stamps); if (sp_ != nullptr && threadIdx.x == 0) sp_[((size_t)blockIdx.x * tl_u(s_c.n_layers) + l) * TL_STAMP_SLOTS + (k)] = wall_clock64(); } while (0)
 __shared__ TlConst s_c;
 __shared__ TLayerItem s_it[TLAYER_MAX];
 __shared__ int s_wait_ok;
@@ -135,6 +138,9 @@ AMT_DEV void tl_copy_in(E* Ps, const E* __restrict__ G, int ld, long tok0, int n
       v[i] = team_chunk_load<true>(G, (size_t)(tok0 + pc) * ld + col0 + 8 * c);
     }
   }
+  // the scheduler must not sink the loads to their stores (it did: one load, one s_waitcnt vmcnt(0), one ds_write - sixteen L2
+  // round trips in series per panel, 10 us of a 12-us phase)
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     const int id = tid + i * TL_THREADS;
@@ -200,27 +206,27 @@ AMT_DEV void tl_rope_quad(float (&v)[4], float2 c, float2 s) {
 
 template <typename T, int TG> struct TlDims {
   static constexpr int H = 256, QC = 320, CK = 64, KV = 512, I = 512, I2 = 1024;
-  static constexpr int NTB = TG / 16, NT2 = NTB / 2, NT4 = NTB / 4;
-  static constexpr int LDX = H + 8, LDC = CK + 8, LDS = 32 + 8, LDU = 128 + 8, LDGS = 64 + 8, LDG = I + 8;
-  static_assert(NT4 >= 1, "token group of at least 64 rows");
+  static constexpr int NTB = TG / 16, NTH = NTB / 2;         // token blocks of a group; of half a group
+  static constexpr int LDX = H + 8, LDC = CK + 8, LDQ = 64 + 8, LDGS = 128 + 8, LDG = I + 8;
+  static_assert(NTH >= 1 && TG % TL_NF == 0, "token group of at least 32 rows");
   static constexpr size_t ES = sizeof(T);
-  static constexpr size_t LDS_A = ES * TG * (LDX + LDC + 3 * LDS);
+  static constexpr size_t LDS_A = ES * TG * (LDX + LDC + 3 * LDQ);
   static constexpr size_t LDS_BG = ES * 2 * 3 * 64 * ALD;                                      // global attention, two key-tile groups
-  static constexpr size_t LDS_BL = ES * (size_t)(TG / 16) * LOCAL_FWD_LDS;                     // local attention, one stripe per wave
-  static constexpr size_t LDS_C = ES * TG * (LDX + LDS);
-  static constexpr size_t LDS_D = ES * TG * (LDX + LDU + LDGS);
-  static constexpr size_t LDS_E = ES * TG * (LDG + LDS);
+  static constexpr size_t LDS_BL = ES * (size_t)(TG / 8 < 8 ? TG / 8 : 8) * LOCAL_FWD_LDS;    // local attention, one stripe per wave
+  static constexpr size_t LDS_D = ES * TG * (3 * LDX + LDGS);
+  static constexpr size_t LDS_E = ES * TG * (LDG + LDQ);
   static constexpr size_t mx(size_t a, size_t b) { return a > b ? a : b; }
-  static constexpr size_t LDS_ALL = mx(mx(mx(LDS_A, LDS_BG), mx(LDS_BL, LDS_C)), mx(LDS_D, LDS_E));
+  static constexpr size_t LDS_ALL = mx(mx(LDS_A, LDS_BG), mx(LDS_BL, mx(LDS_D, LDS_E)));
 };
 
 // ------------------------------------------------------------------ phase A: LN1, q / c / k / v projections
+// role (tg, fg): rows of token group tg; q features 64 fg .. + 64 (= head fg), k and v features of the same head; c whole
 template <typename T, int TG>
 TL_PHASE bool tl_phase_a(int l, int clip, int role, unsigned need) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tl_smem[];
   using D = TlDims<T, TG>;
   using RT = Res<T>;
-  constexpr int H = D::H, QC = D::QC, CK = D::CK, KV = D::KV, LDX = D::LDX, LDC = D::LDC, LDS = D::LDS, NT2 = D::NT2, NT4 = D::NT4;
+  constexpr int H = D::H, QC = D::QC, CK = D::CK, KV = D::KV, LDX = D::LDX, LDC = D::LDC, LDQ = D::LDQ, NTB = D::NTB, NTH = D::NTH;
   l = tl_u(l);
   const TlEnv e = tl_env(clip, role, TG);
   const TLayerItem& it = s_it[l];
@@ -228,56 +234,28 @@ TL_PHASE bool tl_phase_a(int l, int clip, int role, unsigned need) {
   RT* Xr = reinterpret_cast<RT*>(tl_smem);
   T* Cs = Xs + TG * LDX;
   T* Qs = Cs + TG * LDC;
-  T* Ks = Qs + TG * LDS;
-  T* Vs = Ks + TG * LDS;
+  T* Ks = Qs + TG * LDQ;
+  T* Vs = Ks + TG * LDQ;
   const int tid = e.tid, lane = e.lane, w = e.wave, r = lane & 15, g = lane >> 4, fg = e.fg;
   const T* Wqc = reinterpret_cast<const T*>(tl_p(it.Wqc));
   const T* Wkv = reinterpret_cast<const T*>(tl_p(it.Wkv));
   const bool rope = (l & 1) != 0 && tl_u(s_c.prerot) != 0;      // global layers: q / k leave rotated
   constexpr int KCX = ChainChunk<T, 1, H>::KC, KCK = ChainChunk<T, 1, CK>::KC;
 
-  // the c stage's weights depend on nothing: requested before the wait
-  const int mC = 256 + 16 * (w & 3), tC = (w >> 2) * NT2 * 16;
+  // what depends on nothing is requested before the wait: the c stage's weights, the RoPE table entries of this lane's rows
+  const int fbh = w & 3, th = (w >> 2) * NTH * 16;       // (feature block, token half) of the c and q stages
+  const int mC = 256 + 16 * fbh, mQ = 64 * fg + 16 * fbh;
+  const bool isk = w < 4;                                // k / v stage: wave w multiplies feature block w of [k (4) | v (4)] for all rows
+  const int mK = (isk ? 0 : 256) + 64 * fg + 16 * (w & 3);
   Frag<T> wc[KCX][1];
   chain_load_w<T, 1, KCX, H>(wc, Wqc, mC, 0, lane);
-  if (l > 0 && !tl_wait(need, TL_NF, [&](int j) { return e.tg * TL_NF + j; })) return false;
-  const RT* xin = reinterpret_cast<const RT*>(l == 0 ? tl_p(s_c.X0) : tl_p(s_it[l > 0 ? l - 1 : 0].y));
-  tl_copy_in<RT, TG, H, LDX>(Xr, xin, H, e.tok0, e.nvalid, 0, tid);
-  __syncthreads();
-  tl_ln_rows<T, TG, LDX>(Xr, Xs, tl_p(it.ln1w), tl_p(it.ln1b), fg == 0 ? tl_p(it.m1) : nullptr,
-                         tl_p(it.r1), e.tok0, e.nvalid, tid);
-  __syncthreads();
-  tl_copy_out<T, H, LDX>(Xs, reinterpret_cast<T*>(tl_p(it.xn)), H, e.tok0, e.nvalid, 0, fg * (TG / TL_NF), (fg + 1) * (TG / TL_NF), tid);
-
-  // ---- c = xn . Wc^T (all 64 features: every feature group needs them for its k / v slice)
-  const int mQ = 32 * fg + 16 * (w & 1), tQ = (w >> 1) * NT4 * 16;
-  Frag<T> wq[KCX][1];
-  {
-    f32x4 acc[1][NT2];
-    chain_zero(acc);
-    chain_stage<T, 1, NT2, KCX, H>(acc, wc, Wqc, mC, Xs, LDX, tC, lane);
-    chain_load_w<T, 1, KCX, H>(wq, Wqc, mQ, 0, lane);
-#pragma unroll
-    for (int ti = 0; ti < NT2; ++ti) {
-      float v[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = acc[0][ti][i];
-      store4f(Cs + (tC + 16 * ti + r) * LDC + 16 * (w & 3) + 4 * g, v);
-    }
-  }
-  // k / v weights and the RoPE table entries of this lane's rows: in flight during the q products
-  const int fb4 = w & 3;
-  const bool isk = fb4 < 2;
-  const int mK = (isk ? 0 : 256) + 32 * fg + 16 * (fb4 & 1), tK = (w >> 2) * NT2 * 16;
-  Frag<T> wk[KCK][1];
-  chain_load_w<T, 1, KCK, CK>(wk, Wkv, mK, 0, lane);
-  float2 qcs[NT4], qsn[NT4], kcs[NT2], ksn[NT2];
+  float2 qcs[NTH], qsn[NTH], kcs[NTB], ksn[NTB];
   if (rope) {
     const float* rc = tl_p(s_c.rope_cos);
     const float* rsn = tl_p(s_c.rope_sin);
 #pragma unroll
-    for (int ti = 0; ti < NT4; ++ti) {
-      int p = tQ + 16 * ti + r;
+    for (int ti = 0; ti < NTH; ++ti) {
+      int p = th + 16 * ti + r;
       p = p < e.nvalid ? p : e.nvalid - 1;
       const int pos = e.tg * TG + p;
       qcs[ti] = *reinterpret_cast<const float2*>(rc + pos * 32 + (((mQ + 4 * g) & 63) >> 1));
@@ -285,8 +263,8 @@ TL_PHASE bool tl_phase_a(int l, int clip, int role, unsigned need) {
     }
     if (isk) {
 #pragma unroll
-      for (int ti = 0; ti < NT2; ++ti) {
-        int p = tK + 16 * ti + r;
+      for (int ti = 0; ti < NTB; ++ti) {
+        int p = 16 * ti + r;
         p = p < e.nvalid ? p : e.nvalid - 1;
         const int pos = e.tg * TG + p;
         kcs[ti] = *reinterpret_cast<const float2*>(rc + pos * 32 + (((mK + 4 * g) & 63) >> 1));
@@ -294,57 +272,85 @@ TL_PHASE bool tl_phase_a(int l, int clip, int role, unsigned need) {
       }
     }
   }
+  if (l > 0 && !tl_wait(need, TL_NF, [&](int j) { return e.tg * TL_NF + j; })) return false;
+  const RT* xin = reinterpret_cast<const RT*>(l == 0 ? tl_p(s_c.X0) : tl_p(s_it[l > 0 ? l - 1 : 0].y));
+  tl_copy_in<RT, TG, H, LDX>(Xr, xin, H, e.tok0, e.nvalid, 0, tid);
+  __syncthreads();
+  tl_ln_rows<T, TG, LDX>(Xr, Xs, tl_p(it.ln1w), tl_p(it.ln1b), fg == 0 ? tl_p(it.m1) : nullptr, tl_p(it.r1), e.tok0, e.nvalid, tid);
+  __syncthreads();
+  tl_copy_out<T, H, LDX>(Xs, reinterpret_cast<T*>(tl_p(it.xn)), H, e.tok0, e.nvalid, 0, fg * (TG / TL_NF), (fg + 1) * (TG / TL_NF), tid);
+
+  // ---- c = xn . Wc^T (all 64 features: every feature group needs them for its k / v slice)
+  Frag<T> wq[KCX][1];
+  {
+    f32x4 acc[1][NTH];
+    chain_zero(acc);
+    chain_stage<T, 1, NTH, KCX, H>(acc, wc, Wqc, mC, Xs, LDX, th, lane);
+    chain_load_w<T, 1, KCX, H>(wq, Wqc, mQ, 0, lane);
+#pragma unroll
+    for (int ti = 0; ti < NTH; ++ti) {
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = acc[0][ti][i];
+      store4f(Cs + (th + 16 * ti + r) * LDC + 16 * fbh + 4 * g, v);
+    }
+  }
+  Frag<T> wk[KCK][1];
+  chain_load_w<T, 1, KCK, CK>(wk, Wkv, mK, 0, lane);
   __syncthreads();   // c panel complete
   T* qc_out = reinterpret_cast<T*>(tl_p(it.qc));
   T* kv_out = reinterpret_cast<T*>(tl_p(it.kv));
   if (fg == 0) tl_copy_out<T, CK, LDC>(Cs, qc_out, QC, e.tok0, e.nvalid, 256, 0, TG, tid);
 
-  // ---- q slice = xn . Wq[32 fg .. + 32)^T
+  // ---- q slice = xn . Wq[64 fg .. + 64)^T
   {
-    f32x4 acc[1][NT4];
+    f32x4 acc[1][NTH];
     chain_zero(acc);
-    chain_stage<T, 1, NT4, KCX, H>(acc, wq, Wqc, mQ, Xs, LDX, tQ, lane);
+    chain_stage<T, 1, NTH, KCX, H>(acc, wq, Wqc, mQ, Xs, LDX, th, lane);
 #pragma unroll
-    for (int ti = 0; ti < NT4; ++ti) {
+    for (int ti = 0; ti < NTH; ++ti) {
       float v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = acc[0][ti][i];
       if (rope) tl_rope_quad<T>(v, qcs[ti], qsn[ti]);
-      store4f(Qs + (tQ + 16 * ti + r) * LDS + 16 * (w & 1) + 4 * g, v);
+      store4f(Qs + (th + 16 * ti + r) * LDQ + 16 * fbh + 4 * g, v);
     }
   }
   // ---- k / v slices = c . Wkv[..]^T, c as stored
   {
-    f32x4 acc[1][NT2];
+    f32x4 acc[1][NTB];
     chain_zero(acc);
-    chain_stage<T, 1, NT2, KCK, CK>(acc, wk, Wkv, mK, Cs, LDC, tK, lane);
+    chain_stage<T, 1, NTB, KCK, CK>(acc, wk, Wkv, mK, Cs, LDC, 0, lane);
 #pragma unroll
-    for (int ti = 0; ti < NT2; ++ti) {
+    for (int ti = 0; ti < NTB; ++ti) {
       float v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = acc[0][ti][i];
       if (rope && isk) tl_rope_quad<T>(v, kcs[ti], ksn[ti]);
-      store4f((isk ? Ks : Vs) + (tK + 16 * ti + r) * LDS + 16 * (fb4 & 1) + 4 * g, v);
+      store4f((isk ? Ks : Vs) + (16 * ti + r) * LDQ + 16 * (w & 3) + 4 * g, v);
     }
   }
   __syncthreads();
-  tl_copy_out<T, 32, LDS>(Qs, qc_out, QC, e.tok0, e.nvalid, 32 * fg, 0, TG, tid);
-  tl_copy_out<T, 32, LDS>(Ks, kv_out, KV, e.tok0, e.nvalid, 32 * fg, 0, TG, tid);
-  tl_copy_out<T, 32, LDS>(Vs, kv_out, KV, e.tok0, e.nvalid, 256 + 32 * fg, 0, TG, tid);
+  tl_copy_out<T, 64, LDQ>(Qs, qc_out, QC, e.tok0, e.nvalid, 64 * fg, 0, TG, tid);
+  tl_copy_out<T, 64, LDQ>(Ks, kv_out, KV, e.tok0, e.nvalid, 64 * fg, 0, TG, tid);
+  tl_copy_out<T, 64, LDQ>(Vs, kv_out, KV, e.tok0, e.nvalid, 256 + 64 * fg, 0, TG, tid);
   __syncthreads();   // the panels are rewritten by the workgroup's next role / phase
   return true;
 }
 
-// ------------------------------------------------------------------ phase B: attention core
+// ------------------------------------------------------------------ phase B: attention core of head fg
+// global layers: the 64-query tile that holds the group's rows (TG = 32: computed by the even group of the pair);
+// local layers: the group's TG / 8 stripes, one per wave
 template <typename T, int TG, bool DROP>
 TL_PHASE bool tl_phase_b(int l, int clip, int role, unsigned need) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tl_smem[];
+  static_assert(TG == 64 || TG == 32, "query tiles of 64 rows");
   l = tl_u(l);
   const TlEnv e = tl_env(clip, role, TG);
   const TLayerItem& it = s_it[l];
-  const int head = e.fg >> 1, j = e.fg & 1;
+  const int head = e.fg;
   const int n_tg = (e.S + TG - 1) / TG;
-  if (!tl_wait(need, 2 * n_tg, [&](int q) { return (q >> 1) * TL_NF + 2 * head + (q & 1); })) return false;
+  if (!tl_wait(need, n_tg, [&](int q) { return q * TL_NF + head; })) return false;
   const bool local = (l & 1) == 0;       // model.py:609-611: local layer first, then global
   AttnArgs aa;
   aa.QC = tl_p(it.qc); aa.ldqc = 320; aa.KV = tl_p(it.kv); aa.ldkv = 512; aa.O = tl_p(it.ao); aa.ldo = 256;
@@ -353,118 +359,113 @@ TL_PHASE bool tl_phase_b(int l, int clip, int role, unsigned need) {
   aa.seed = tl_u(s_c.seed); aa.stream = 2u * (uint32_t)l; aa.drop_thresh24 = tl_u(s_c.thr); aa.inv_keep = tl_u(s_c.inv_keep);
   aa.seed_dev = nullptr; aa.keepbits = tl_p(it.keepbits); aa.prerot = local ? 0 : tl_u(s_c.prerot);
   if (local) {
-    constexpr int NSTR = TG / 16;               // stripes of 8 rows per role: one per wave
+    constexpr int NSTR = TG / 8;                // stripes of 8 rows of the group: one per wave
     if (e.wave < NSTR) {
-      const int s = e.tg * (TG / 8) + j * NSTR + e.wave;
+      const int s = e.tg * NSTR + e.wave;
       if (8 * s < e.S)
         attn_local_fwd_wave<T, true, LocalWaveSync>(aa, tl_u(s_c.padL), tl_u(s_c.nW), s, head, e.clip,
                                                      reinterpret_cast<T*>(tl_smem) + e.wave * LOCAL_FWD_LDS, e.lane);
     }
   } else {
-    constexpr int NQ = TG / 64;                 // 64-query tiles per token group
-    const int qtile = e.tg * NQ + j;
-    if (j < NQ && qtile * 64 < e.S) attn_global_fwd_tile<T, 2, DROP, true>(aa, e.clip, head, qtile, tl_smem);
+    constexpr int GPQ = 64 / TG;                // token groups per 64-query tile
+    if (e.tg % GPQ == 0) attn_global_fwd_tile<T, 2, DROP, true>(aa, e.clip, head, e.tg / GPQ, tl_smem);
   }
   __syncthreads();
   return true;
 }
 
-// ------------------------------------------------------------------ phase C: h slice = x + ao . Wo^T
-template <typename T, int TG>
-TL_PHASE bool tl_phase_c(int l, int clip, int role, unsigned need) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char tl_smem[];
-  using D = TlDims<T, TG>;
-  using RT = Res<T>;
-  constexpr int H = D::H, LDX = D::LDX, LDS = D::LDS, NT4 = D::NT4;
-  l = tl_u(l);
-  const TlEnv e = tl_env(clip, role, TG);
-  const TLayerItem& it = s_it[l];
-  T* As = reinterpret_cast<T*>(tl_smem);
-  RT* Hs = reinterpret_cast<RT*>(As + TG * LDX);
-  const int tid = e.tid, lane = e.lane, w = e.wave, r = lane & 15, g = lane >> 4, fg = e.fg;
-  const T* Wo = reinterpret_cast<const T*>(tl_p(it.Wo));
-  constexpr int KCO = ChainChunk<T, 1, H>::KC;
-  const int mO = 32 * fg + 16 * (w & 1), tO = (w >> 1) * NT4 * 16;
-  Frag<T> wo[KCO][1];
-  chain_load_w<T, 1, KCO, H>(wo, Wo, mO, 0, lane);
-  if (!tl_wait(need, TL_NF, [&](int j) { return e.tg * TL_NF + j; })) return false;
-  const RT* xin = reinterpret_cast<const RT*>(l == 0 ? tl_p(s_c.X0) : tl_p(s_it[l > 0 ? l - 1 : 0].y));
-  tl_copy_in<T, TG, H, LDX>(As, reinterpret_cast<const T*>(tl_p(it.ao)), H, e.tok0, e.nvalid, 0, tid);
-  tl_copy_in<RT, TG, 32, LDS>(Hs, xin, H, e.tok0, e.nvalid, 32 * fg, tid);
-  __syncthreads();
-  f32x4 acc[1][NT4];
-  chain_zero(acc);
-  chain_stage<T, 1, NT4, KCO, H>(acc, wo, Wo, mO, As, LDX, tO, lane);
-#pragma unroll
-  for (int ti = 0; ti < NT4; ++ti) {
-    RT* hp = Hs + (tO + 16 * ti + r) * LDS + 16 * (w & 1) + 4 * g;
-    float x[4], h[4];
-    load4f(hp, x);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) h[i] = acc[0][ti][i] + x[i];
-    store4f(hp, h);
-  }
-  __syncthreads();
-  tl_copy_out<RT, 32, LDS>(Hs, reinterpret_cast<RT*>(tl_p(it.h)), H, e.tok0, e.nvalid, 32 * fg, 0, TG, tid);
-  __syncthreads();
-  return true;
-}
-
-// ------------------------------------------------------------------ phase D: hn = LN2(h); u, g slices
+// ------------------------------------------------------------------ phase D: h = x + ao . Wo^T (whole rows, every feature
+// group of the token group computes them: no exchange between the output projection and LN2); hn = LN2(h); u, g slices
 template <typename T, int TG>
 TL_PHASE bool tl_phase_d(int l, int clip, int role, unsigned need) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tl_smem[];
   using D = TlDims<T, TG>;
   using RT = Res<T>;
-  constexpr int H = D::H, I = D::I, I2 = D::I2, LDX = D::LDX, LDU = D::LDU, LDGS = D::LDGS, NT2 = D::NT2;
+  constexpr int H = D::H, I = D::I, I2 = D::I2, LDX = D::LDX, LDGS = D::LDGS, NTB = D::NTB;
   l = tl_u(l);
   const TlEnv e = tl_env(clip, role, TG);
   const TLayerItem& it = s_it[l];
-  T* Xs = reinterpret_cast<T*>(tl_smem);
-  RT* Xr = reinterpret_cast<RT*>(tl_smem);
-  T* Us = Xs + TG * LDX;
-  T* Gs = Us + TG * LDU;
+  T* As = reinterpret_cast<T*>(tl_smem);                 // ao, later the u slice (staging)
+  RT* Hs = reinterpret_cast<RT*>(As + TG * LDX);         // x, then h
+  T* Ns = reinterpret_cast<T*>(Hs + TG * LDX);           // hn
+  T* Gs = Ns + TG * LDX;                                 // g slice (staging)
+  T* Us = As;
   const int tid = e.tid, lane = e.lane, w = e.wave, r = lane & 15, g = lane >> 4, fg = e.fg;
+  const T* Wo = reinterpret_cast<const T*>(tl_p(it.Wo));
   const T* W1 = reinterpret_cast<const T*>(tl_p(it.W1));
-  constexpr int KC1 = ChainChunk<T, 2, H>::KC;
-  const int pair = w & 3, m1 = 128 * fg + 32 * pair, t1 = (w >> 2) * NT2 * 16;
-  Frag<T> w1[KC1][2];
-  chain_load_w<T, 2, KC1, H>(w1, W1, m1, 0, lane);
+  constexpr int KCO = ChainChunk<T, 2, H>::KC, KC1 = ChainChunk<T, 2, H>::KC;
+  const int mO = 32 * w;                                 // output projection: wave w owns features 32 w .. + 32 of every row
+  const int m1 = 256 * fg + 32 * w;                      // W1: (u1 | u2) row-block pair 8 fg + w
+  Frag<T> wo[KCO][2];
+  chain_load_w<T, 2, KCO, H>(wo, Wo, mO, 0, lane);
   float b1a[4], b1b[4];
   {
     const float* b1 = tl_p(it.b1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { b1a[i] = b1[m1 + 4 * g + i]; b1b[i] = b1[m1 + 16 + 4 * g + i]; }
   }
-  if (!tl_wait(need, TL_NF, [&](int j) { return e.tg * TL_NF + j; })) return false;
-  tl_copy_in<RT, TG, H, LDX>(Xr, reinterpret_cast<const RT*>(tl_p(it.h)), H, e.tok0, e.nvalid, 0, tid);
+  TL_SUB(20);
+  // ao rows of the group: written by the four heads' roles of this group (global, TG = 32: of the group that ran the tile)
+  const bool local = (l & 1) == 0;
+  const int tgp = local ? e.tg : e.tg - e.tg % (64 / TG);
+  if (!tl_wait(need, TL_NF, [&](int j) { return tgp * TL_NF + j; })) return false;
+  TL_SUB(21);
+  const RT* xin = reinterpret_cast<const RT*>(l == 0 ? tl_p(s_c.X0) : tl_p(s_it[l > 0 ? l - 1 : 0].y));
+  tl_copy_in<T, TG, H, LDX>(As, reinterpret_cast<const T*>(tl_p(it.ao)), H, e.tok0, e.nvalid, 0, tid);
+  tl_copy_in<RT, TG, H, LDX>(Hs, xin, H, e.tok0, e.nvalid, 0, tid);
   __syncthreads();
-  tl_ln_rows<T, TG, LDX>(Xr, Xs, tl_p(it.ln2w), tl_p(it.ln2b), fg == 0 ? tl_p(it.m2) : nullptr,
-                         tl_p(it.r2), e.tok0, e.nvalid, tid);
-  __syncthreads();
-  tl_copy_out<T, H, LDX>(Xs, reinterpret_cast<T*>(tl_p(it.hn)), H, e.tok0, e.nvalid, 0, fg * (TG / TL_NF), (fg + 1) * (TG / TL_NF), tid);
-  // ---- u = hn . W1^T + b1 (permuted rows: 16 x u1 | 16 x u2); g = gelu(u1) * u2
-  f32x4 acc[2][NT2];
-  chain_zero(acc);
-  chain_stage<T, 2, NT2, KC1, H>(acc, w1, W1, m1, Xs, LDX, t1, lane);
+  TL_SUB(22);
+  Frag<T> w1[KC1][2];
+  {
+    f32x4 acc[2][NTB];
+    chain_zero(acc);
+    chain_stage<T, 2, NTB, KCO, H>(acc, wo, Wo, mO, As, LDX, 0, lane);
+    chain_load_w<T, 2, KC1, H>(w1, W1, m1, 0, lane);      // in flight during the LayerNorm pass
 #pragma unroll
-  for (int ti = 0; ti < NT2; ++ti) {
-    const int p = t1 + 16 * ti + r;
-    float u1[4], u2[4], gl[4];
+    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      u1[i] = to_f(from_f<T>(acc[0][ti][i] + b1a[i]));
-      u2[i] = to_f(from_f<T>(acc[1][ti][i] + b1b[i]));
-      gl[i] = gelu_tanh(u1[i]) * u2[i];
-    }
-    store4f(Gs + p * LDGS + 16 * pair + 4 * g, gl);
-    store4f(Us + p * LDU + 32 * pair + 4 * g, u1);
-    store4f(Us + p * LDU + 32 * pair + 16 + 4 * g, u2);
+      for (int ti = 0; ti < NTB; ++ti) {
+        RT* hp = Hs + (16 * ti + r) * LDX + mO + 16 * rb + 4 * g;
+        float x[4], h[4];
+        load4f(hp, x);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = acc[rb][ti][i] + x[i];
+        store4f(hp, h);
+      }
   }
   __syncthreads();
-  tl_copy_out<T, 128, LDU>(Us, reinterpret_cast<T*>(tl_p(it.u)), I2, e.tok0, e.nvalid, 128 * fg, 0, TG, tid);
-  tl_copy_out<T, 64, LDGS>(Gs, reinterpret_cast<T*>(tl_p(it.g)), I, e.tok0, e.nvalid, 64 * fg, 0, TG, tid);
+  TL_SUB(23);
+  tl_copy_out<RT, H, LDX>(Hs, reinterpret_cast<RT*>(tl_p(it.h)), H, e.tok0, e.nvalid, 0, fg * (TG / TL_NF), (fg + 1) * (TG / TL_NF), tid);
+  tl_ln_rows<T, TG, LDX>(Hs, Ns, tl_p(it.ln2w), tl_p(it.ln2b), fg == 0 ? tl_p(it.m2) : nullptr, tl_p(it.r2), e.tok0, e.nvalid, tid);
   __syncthreads();
+  TL_SUB(24);
+  tl_copy_out<T, H, LDX>(Ns, reinterpret_cast<T*>(tl_p(it.hn)), H, e.tok0, e.nvalid, 0, fg * (TG / TL_NF), (fg + 1) * (TG / TL_NF), tid);
+  // ---- u = hn . W1^T + b1 (permuted rows: 16 x u1 | 16 x u2); g = gelu(u1) * u2
+  {
+    f32x4 acc[2][NTB];
+    chain_zero(acc);
+    chain_stage<T, 2, NTB, KC1, H>(acc, w1, W1, m1, Ns, LDX, 0, lane);
+    TL_SUB(25);
+#pragma unroll
+    for (int ti = 0; ti < NTB; ++ti) {
+      const int p = 16 * ti + r;
+      float u1[4], u2[4], gl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u1[i] = to_f(from_f<T>(acc[0][ti][i] + b1a[i]));
+        u2[i] = to_f(from_f<T>(acc[1][ti][i] + b1b[i]));
+        gl[i] = gelu_tanh(u1[i]) * u2[i];
+      }
+      store4f(Gs + p * LDGS + 16 * w + 4 * g, gl);
+      store4f(Us + p * LDX + 32 * w + 4 * g, u1);          // (As is dead: every wave has passed the barrier behind the projection)
+      store4f(Us + p * LDX + 32 * w + 16 + 4 * g, u2);
+    }
+  }
+  __syncthreads();
+  tl_copy_out<T, 256, LDX>(Us, reinterpret_cast<T*>(tl_p(it.u)), I2, e.tok0, e.nvalid, 256 * fg, 0, TG, tid);
+  tl_copy_out<T, 128, LDGS>(Gs, reinterpret_cast<T*>(tl_p(it.g)), I, e.tok0, e.nvalid, 128 * fg, 0, TG, tid);
+  __syncthreads();
+  TL_SUB(26);
   return true;
 }
 
@@ -474,7 +475,7 @@ TL_PHASE bool tl_phase_e(int l, int clip, int role, unsigned need) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tl_smem[];
   using D = TlDims<T, TG>;
   using RT = Res<T>;
-  constexpr int H = D::H, I = D::I, LDG = D::LDG, LDS = D::LDS, NT4 = D::NT4;
+  constexpr int H = D::H, I = D::I, LDG = D::LDG, LDQ = D::LDQ, NTH = D::NTH;
   l = tl_u(l);
   const TlEnv e = tl_env(clip, role, TG);
   const TLayerItem& it = s_it[l];
@@ -483,7 +484,8 @@ TL_PHASE bool tl_phase_e(int l, int clip, int role, unsigned need) {
   const int tid = e.tid, lane = e.lane, w = e.wave, r = lane & 15, g = lane >> 4, fg = e.fg;
   const T* W2 = reinterpret_cast<const T*>(tl_p(it.W2));
   constexpr int KC2 = ChainChunk<T, 1, I>::KC;
-  const int mO = 32 * fg + 16 * (w & 1), tO = (w >> 1) * NT4 * 16;
+  const int fbh = w & 3, th = (w >> 2) * NTH * 16;
+  const int mO = 64 * fg + 16 * fbh;
   Frag<T> w2[KC2][1];
   chain_load_w<T, 1, KC2, I>(w2, W2, mO, 0, lane);
   float bb[4];
@@ -492,21 +494,25 @@ TL_PHASE bool tl_phase_e(int l, int clip, int role, unsigned need) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) bb[i] = b2[mO + 4 * g + i];
   }
+  TL_SUB(27);
   if (!tl_wait(need, TL_NF, [&](int j) { return e.tg * TL_NF + j; })) return false;
+  TL_SUB(28);
   tl_copy_in<T, TG, I, LDG>(Gs, reinterpret_cast<const T*>(tl_p(it.g)), I, e.tok0, e.nvalid, 0, tid);
-  tl_copy_in<RT, TG, 32, LDS>(Hs, reinterpret_cast<const RT*>(tl_p(it.h)), H, e.tok0, e.nvalid, 32 * fg, tid);
+  tl_copy_in<RT, TG, 64, LDQ>(Hs, reinterpret_cast<const RT*>(tl_p(it.h)), H, e.tok0, e.nvalid, 64 * fg, tid);
   __syncthreads();
-  f32x4 acc[1][NT4];
+  TL_SUB(29);
+  f32x4 acc[1][NTH];
   chain_zero(acc);
-  chain_stage<T, 1, NT4, KC2, I>(acc, w2, W2, mO, Gs, LDG, tO, lane);
+  chain_stage<T, 1, NTH, KC2, I>(acc, w2, W2, mO, Gs, LDG, th, lane);
+  TL_SUB(30);
   const uint32_t stream = 2u * (uint32_t)l + 1u, thr = tl_u(s_c.thr);
   const uint64_t seed = tl_u(s_c.seed);
   const float inv_keep = tl_u(s_c.inv_keep);
 #pragma unroll
-  for (int ti = 0; ti < NT4; ++ti) {
-    const int p = tO + 16 * ti + r;
+  for (int ti = 0; ti < NTH; ++ti) {
+    const int p = th + 16 * ti + r;
     const long row = e.tok0 + p;
-    RT* hp = Hs + p * LDS + 16 * (w & 1) + 4 * g;
+    RT* hp = Hs + p * LDQ + 16 * fbh + 4 * g;
     float h[4], y[4];
     load4f(hp, h);
 #pragma unroll
@@ -521,12 +527,13 @@ TL_PHASE bool tl_phase_e(int l, int clip, int role, unsigned need) {
     store4f(hp, y);
   }
   __syncthreads();
-  tl_copy_out<RT, 32, LDS>(Hs, reinterpret_cast<RT*>(tl_p(it.y)), H, e.tok0, e.nvalid, 32 * fg, 0, TG, tid);
+  tl_copy_out<RT, 64, LDQ>(Hs, reinterpret_cast<RT*>(tl_p(it.y)), H, e.tok0, e.nvalid, 64 * fg, 0, TG, tid);
   __syncthreads();
+  TL_SUB(31);
   return true;
 }
 
-#define TL_STAMP(k) do { if (a.stamps != nullptr && threadIdx.x == 0) a.stamps[((size_t)blockIdx.x * a.n_layers + l) * 8 + (k)] = wall_clock64(); } while (0)
+#define TL_STAMP(k) do { if (a.stamps != nullptr && threadIdx.x == 0) a.stamps[((size_t)blockIdx.x * a.n_layers + l) * TL_STAMP_SLOTS + (k)] = wall_clock64(); } while (0)
 
 template <typename T, int TG, bool DROP>
 __global__ __launch_bounds__(TL_THREADS) void tlayer_fwd_kernel(TLayerArgs a) {
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(TL_THREADS) void tlayer_fwd_kernel(TLayerArgs a) {
     s_c.seed = eff_seed(a.seed, a.seed_dev);
     s_c.B = a.B; s_c.S = a.S; s_c.n_layers = a.n_layers; s_c.prerot = a.prerot; s_c.padL = a.padL; s_c.nW = a.nW;
     s_c.thr = a.drop_thresh24; s_c.inv_keep = a.inv_keep;
-    s_c.xcc = t.xcc; s_c.rank = t.rank; s_c.size = t.size;
+    s_c.xcc = t.xcc; s_c.rank = t.rank; s_c.size = t.size; s_c.stamps = a.stamps;
   }
   __syncthreads();
   bool ok = t.ok;
@@ -567,17 +574,13 @@ __global__ __launch_bounds__(TL_THREADS) void tlayer_fwd_kernel(TLayerArgs a) {
         tl_publish(++epoch);
         TL_STAMP(2);
 #pragma unroll 1
-        for (int role = t.rank; role < n_roles && ok; role += t.size) ok = tl_phase_c<T, TG>(l, clip, role, epoch);
+        for (int role = t.rank; role < n_roles && ok; role += t.size) ok = tl_phase_d<T, TG>(l, clip, role, epoch);
         tl_publish(++epoch);
         TL_STAMP(3);
 #pragma unroll 1
-        for (int role = t.rank; role < n_roles && ok; role += t.size) ok = tl_phase_d<T, TG>(l, clip, role, epoch);
-        tl_publish(++epoch);
-        TL_STAMP(4);
-#pragma unroll 1
         for (int role = t.rank; role < n_roles && ok; role += t.size) ok = tl_phase_e<T, TG>(l, clip, role, epoch);
         tl_publish(++epoch);
-        TL_STAMP(5);
+        TL_STAMP(4);
       }
     }
   }

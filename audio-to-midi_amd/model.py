@@ -389,17 +389,17 @@ class OutputSequenceGenerator:
         return bool(self._L.amt_tlayer_active(self._h))
 
     def tlayer_stamps(self, n_layers: int):
-        """Per-phase wall-clock stamps (100 MHz) of the last team launch as an int64 array [256 workgroups][n_layers][8]
+        """Per-phase wall-clock stamps (100 MHz) of the last team launch as an int64 array [256 workgroups][n_layers][32]
         (contexts created under AMT_TLAYER_STAMPS=1; None otherwise)."""
         import ctypes
 
         import numpy as np
-        n = 256 * n_layers * 8
+        n = 256 * n_layers * 32
         buf = np.zeros(n, dtype=np.uint64)
         got = int(self._L.amt_tlayer_stamps(self._h, buf.ctypes.data_as(ctypes.c_void_p), n))
         if got <= 0:
             return None
-        return buf.astype(np.int64).reshape(256, n_layers, 8)
+        return buf.astype(np.int64).reshape(256, n_layers, 32)
 
 
 class _DevView:

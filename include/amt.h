@@ -191,7 +191,7 @@ int32_t amt_team_status(const amt_ctx* ctx);
 /* The forward of the transformer stack (model.py:559-670) as ONE XCD-team launch (csrc/tlayer.hip): 1 if this context takes
  * it for training-size calls (the default on an 8-XCD x 32-CU device; AMT_TLAYER=0 or a timed-out team launch: 0 = one
  * launch per operator chain).  amt_tlayer_stamps: diagnostic (AMT_TLAYER_STAMPS=1 when the context was created): copies
- * the per-phase wall-clock stamps of the last such launch, [workgroup][layer][8] 64-bit words (100 MHz), returns the
+ * the per-phase wall-clock stamps of the last such launch, [workgroup][layer][32] 64-bit words (100 MHz), returns the
  * number of words written (0: stamps are off). */
 int32_t amt_tlayer_active(const amt_ctx* ctx);
 int32_t amt_tlayer_stamps(const amt_ctx* ctx, uint64_t* out, int32_t max_words);

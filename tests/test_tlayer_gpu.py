@@ -26,9 +26,9 @@ def _run(conf, params, audio, labels, dtype, tlayer, monkeypatch, train=True):
     return res
 
 
-# (dtype, clips, frames): float32 runs 64-row token groups (231 frames: 4 groups, the last one 39 rows; 500 frames: 8 groups =
-# 64 roles on 32 workgroups, two roles per phase); bfloat16 runs 128-row groups (500 frames: the benchmark's clip; 333:
-# three groups, 77 rows in the last).  9 clips: one team takes two clips.
+# (dtype, clips, frames): float32 runs 32-row token groups (231 frames: 8 groups x 4 heads = 32 roles, the last group 7 rows;
+# 500 frames: 16 groups = 64 roles on 32 workgroups, two roles per phase); bfloat16 runs 64-row groups (500 frames: the
+# benchmark's clip, 8 groups, 52 rows in the last; 333: six groups, 13 rows in the last).  9 clips: one team takes two clips.
 @pytest.mark.parametrize("dtype,B,S", [("float32", 3, 231), ("float32", 2, 500), ("bfloat16", 3, 500), ("bfloat16", 9, 333)])
 @pytest.mark.parametrize("train", [True, False])
 def test_team_layer_forward_equals_the_chain_launches(small_conf, dtype, B, S, train, monkeypatch):
