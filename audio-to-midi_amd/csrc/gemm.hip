@@ -7,6 +7,8 @@
 // gemm_nt computes D = W_tile . X_tile^T on the matrix cores with FEATURES on the MFMA row axis
 // and TOKENS on the column axis, so that a lane ends up with 4 consecutive output features of one
 // token: bias / gamma / GLU pairing are per-register and stores are 8-byte (bf16) vectors.
+#include <cstdio>
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
@@ -354,7 +356,10 @@ static int wgrad_group_prepare_t(DType dt, const WgradArgs* probs, int n, Partia
   WgradGroupN<CAP>& g = *gp;
   memset(&g, 0, sizeof(g));
   if (n <= 0) return 0;
-  if (n > CAP) n = CAP;      // (callers hand over at most CAP problems)
+  if (n > CAP) {             // a caller error (every caller chunks by CAP): losing weight gradients silently is not an option
+    fprintf(stderr, "amt: wgrad_group_prepare: %d problems handed to a group of %d - aborting\n", n, CAP);
+    abort();
+  }
   g.n = n;
   // XCD-aware item order (kernels.h).  At cfg2 (riders inside latency-bound chain launches) it measured slower: off
   // (profiles/r02_notes.md).  The stand-alone grouped launches of the large-N schedule (target_override >= 512: no riders from

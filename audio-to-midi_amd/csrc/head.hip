@@ -27,9 +27,9 @@ void head_probs(hipStream_t s, const float* logits_pad, int ldl, float* logits, 
   hipLaunchKernelGGL(head_probs_kernel, dim3(grid), dim3(256), 0, s, logits_pad, ldl, logits, probs, total, V);
 }
 
-template <typename T>
+template <typename T, typename LT>
 __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ lp, int ldl,
-                                                  const float* __restrict__ labels, float* __restrict__ loss_acc,
+                                                  const LT* __restrict__ labels, float* __restrict__ loss_acc,
                                                   T* __restrict__ dl, int ldd, long N, int V, float scale,
                                                   float inv_b) {
   __shared__ float red[4];
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ lp, 
     const int v = (int)(i - n * (unsigned)ldd);
     float d = 0.f;
     if (v < V) {
-      float z = lp[(size_t)n * ldl + v], y = labels[(size_t)n * V + v];
+      float z = lp[(size_t)n * ldl + v], y = (float)labels[(size_t)n * V + v];
       // -y log_sigmoid(z) - (1-y) log_sigmoid(-z) = max(z,0) - z y + log1p(exp(-|z|))
       const float t = __expf(-fabsf(z));                 // in (0, 1]
       acc += fmaxf(z, 0.f) - z * y + log1pf(t);
@@ -60,21 +60,22 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ lp, 
   }
 }
 
-void bce_loss(hipStream_t s, DType dt, const float* logits_pad, int ldl, const float* labels, float* loss_acc,
-              void* dlogits, int ldd, int N, int V, float scale, int B) {
+void bce_loss(hipStream_t s, DType dt, const float* logits_pad, int ldl, const void* labels, float* loss_acc,
+              void* dlogits, int ldd, int N, int V, float scale, int B, bool labels_f16) {
   long total = (long)N * ldd;
   if (total >= (1L << 31)) return;   // (N x 96 logits: 2^31 would be 22 million frames per call)
   // <= 256 blocks, loads of 4 iterations in flight: every block ends with two atomics on the SAME two
   // addresses (1024 contending adders cost a third of the former 29 us, the serial load loop the rest)
   int grid = (int)((total + 1023) / 1024 < 256 ? (total + 1023) / 1024 : 256);
   if (grid < 1) grid = 1;
-  ProfScope ps(s, "bce_loss", 0, (double)N * V * 8 + (double)N * ldd * (dt == DT_F32 ? 4 : 2));
-  if (dt == DT_F32)
-    hipLaunchKernelGGL((bce_kernel<float>), dim3(grid), dim3(256), 0, s, logits_pad, ldl, labels, loss_acc,
-                       (float*)dlogits, ldd, (long)N, V, scale, 1.f / B);
-  else
-    hipLaunchKernelGGL((bce_kernel<bf16>), dim3(grid), dim3(256), 0, s, logits_pad, ldl, labels, loss_acc,
-                       (bf16*)dlogits, ldd, (long)N, V, scale, 1.f / B);
+  ProfScope ps(s, "bce_loss", 0, (double)N * V * (labels_f16 ? 6 : 8) + (double)N * ldd * (dt == DT_F32 ? 4 : 2));
+  const float inv_b = 1.f / B;
+#define AMT_BCE(T_, LT_)                                                                                                  \
+  hipLaunchKernelGGL((bce_kernel<T_, LT_>), dim3(grid), dim3(256), 0, s, logits_pad, ldl, static_cast<const LT_*>(labels), \
+                     loss_acc, (T_*)dlogits, ldd, (long)N, V, scale, inv_b)
+  if (dt == DT_F32) { if (labels_f16) AMT_BCE(float, f16); else AMT_BCE(float, float); }
+  else { if (labels_f16) AMT_BCE(bf16, f16); else AMT_BCE(bf16, float); }
+#undef AMT_BCE
 }
 
 template <typename T>

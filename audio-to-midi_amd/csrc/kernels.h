@@ -383,8 +383,9 @@ void attn_local_bwd(hipStream_t s, DType dt, const AttnBwdArgs& a);
 void head_probs(hipStream_t s, const float* logits_pad, int ldl, float* logits, float* probs, int N, int V);
 // BCE-with-logits: loss_acc[0] += sum over all (n,v) of bce * scale / B ; dlogits(T)[N][ldd] = (sigmoid(z)-y)*scale/B
 // (columns >= V of dlogits are zeroed)
-void bce_loss(hipStream_t s, DType dt, const float* logits_pad, int ldl, const float* labels, float* loss_acc,
-              void* dlogits, int ldd, int N, int V, float scale, int B);
+// labels: float32, or IEEE half when labels_f16 (the reference's loader hands over float16 labels, grain_loader.py:88)
+void bce_loss(hipStream_t s, DType dt, const float* logits_pad, int ldl, const void* labels, float* loss_acc,
+              void* dlogits, int ldd, int N, int V, float scale, int B, bool labels_f16 = false);
 // elementwise dropout: Y = X * keep / (1-p)
 void dropout_apply(hipStream_t s, DType dt, const void* X, void* Y, size_t n, uint64_t seed, uint32_t stream,
                    uint32_t drop_thresh24, float inv_keep, const uint64_t* seed_dev = nullptr);

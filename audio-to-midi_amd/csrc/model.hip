@@ -343,6 +343,7 @@ struct amt_ctx {
   float* amax = nullptr;        // [layers][prev q,k,v,- | cur q,k,v,-]: delayed per-tensor scaling state
   uint64_t* seed_word = nullptr;   // device word added to every dropout seed (amt_seed_word / amt_advance_seed)
   TeamState* team = nullptr;    // XCD-team protocol words (team.h); null: no team launches (AMT_TEAM=0 and AMT_TLAYER=0)
+  bool labels_f16 = false;      // amt_set_label_dtype: the labels of amt_forward_backward* are IEEE half (grain_loader.py:88)
   bool team_cnn = false;        // AMT_TEAM=1: the Blocks of a CNN stage as one team launch (chain.hip: block_run_fwd)
   bool tlayer = false;          // AMT_TLAYER: the transformer stack's forward as one team launch (tlayer.hip)
   unsigned long long* tl_stamps = nullptr;   // AMT_TLAYER_STAMPS=1: per-phase wall-clock stamps of that launch (amt_tlayer_stamps)
@@ -856,7 +857,7 @@ __global__ void half_signal_kernel(unsigned* counter, unsigned* host_word, const
 // call ADDS its gradients there (the weight-gradient kernels add with fp32 atomics, the record sums add as well); the last
 // call's final pass writes accumulator / (scale * acc_count) to the caller's buffer and checks it.  No extra pass, no
 // second gradient buffer.
-int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labels, int B, int T, float scale,
+int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const void* labels, int B, int T, float scale,
                  bool train, uint64_t seed, float* grads_out, int* grads_valid, int phase = 0, int acc_index = 0,
                  int acc_count = 1) {
   const bool acc_first = acc_index == 0, acc_last = acc_index == acc_count - 1;
@@ -1069,7 +1070,7 @@ int run_backward(amt_ctx* c, hipStream_t s, const void* audio, const float* labe
 
   // loss + dlogits
   void* dlog = A.alloc((size_t)N * L.VP * es);
-  RUN(bce_loss(s, dt, c->logits_pad, L.VP, labels, c->loss_acc, dlog, L.VP, N, cfg.n_events, scale, B));
+  RUN(bce_loss(s, dt, c->logits_pad, L.VP, labels, c->loss_acc, dlog, L.VP, N, cfg.n_events, scale, B, c->labels_f16));
   // decoder backward
   wgrad(dlog, L.VP, c->hd_n, H, N, L.VP, H, L.hd_w, H, (long)L.hd_b, cfg.n_events);
   void* dhn = A.alloc((size_t)N * H * es);
@@ -1750,7 +1751,7 @@ int32_t amt_forward_train(amt_ctx* c, const void* audio, int32_t B, int32_t T, u
   return 0;
 }
 
-int32_t amt_forward_backward_accum(amt_ctx* c, const void* audio, const float* labels, int32_t B, int32_t T, float scale,
+int32_t amt_forward_backward_accum(amt_ctx* c, const void* audio, const void* labels, int32_t B, int32_t T, float scale,
                                    uint64_t seed, int32_t train, float* loss_out, float* grads_flat, int32_t* grads_valid,
                                    float* logits, int32_t phase, int32_t accum_index, int32_t accum_count, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1791,14 +1792,14 @@ int32_t amt_forward_backward_accum(amt_ctx* c, const void* audio, const float* l
   return 0;
 }
 
-int32_t amt_forward_backward(amt_ctx* c, const void* audio, const float* labels, int32_t B, int32_t T, float scale,
+int32_t amt_forward_backward(amt_ctx* c, const void* audio, const void* labels, int32_t B, int32_t T, float scale,
                              uint64_t seed, int32_t train, float* loss_out, float* grads_flat, int32_t* grads_valid,
                              float* logits, void* stream) {
   return amt_forward_backward_accum(c, audio, labels, B, T, scale, seed, train, loss_out, grads_flat, grads_valid, logits, 0, 0, 1,
                                     stream);
 }
 
-int32_t amt_forward_backward_phase(amt_ctx* c, const void* audio, const float* labels, int32_t B, int32_t T, float scale,
+int32_t amt_forward_backward_phase(amt_ctx* c, const void* audio, const void* labels, int32_t B, int32_t T, float scale,
                                    uint64_t seed, int32_t train, float* loss_out, float* grads_flat, int32_t* grads_valid,
                                    float* logits, int32_t phase, void* stream) {
   if (phase != 1 && phase != 2) { c->err = "phase must be 1 or 2"; return 1; }
@@ -1827,6 +1828,12 @@ int32_t amt_advance_seed(amt_ctx* c, uint64_t delta, void* stream) {
   hipLaunchKernelGGL(advance_seed_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), c->seed_word, delta);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { c->err = std::string("amt_advance_seed: ") + hipGetErrorString(e); return 1; }
+  return 0;
+}
+
+int32_t amt_set_label_dtype(amt_ctx* c, int32_t dtype) {
+  if (dtype != AMT_F32 && dtype != AMT_F16) { c->err = "amt_set_label_dtype: AMT_F32 or AMT_F16"; return 1; }
+  c->labels_f16 = dtype == AMT_F16;
   return 0;
 }
 
@@ -2038,6 +2045,16 @@ int32_t amt_grad_accumulator_reset(amt_ctx* c, void* stream) {
   fill_f32(static_cast<hipStream_t>(stream), c->gacc + c->gacc_pad, 0.f, c->L.n_params);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { c->err = std::string("amt_grad_accumulator_reset: ") + hipGetErrorString(e); return 1; }
+  return 0;
+}
+
+float* amt_optimizer_moment_ptr(amt_ctx* c, int32_t which) { return which == 0 ? c->adam_m : (which == 1 ? c->adam_v : nullptr); }
+
+int32_t amt_optimizer_set_count(amt_ctx* c, int32_t count) {
+  if (!c->norm2) { c->err = "amt_optimizer_set_count: call amt_optimizer_init first"; return 1; }
+  if (count < 0) { c->err = "amt_optimizer_set_count: count must be >= 0"; return 1; }
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipMemcpy(c->norm2 + 2, &count, sizeof(int), hipMemcpyHostToDevice));
   return 0;
 }
 

@@ -199,24 +199,45 @@ def audio_to_midi(model, path, output=None, overlap: float = 0.5, state=None):
 
 
 # --------------------------------------------------------------------------- checkpoints
-def save_checkpoint(directory, flat_params: np.ndarray, conf: dict, step: int = 0):
-    """Flat weight file (device layout, little-endian fp32) + metadata JSON (model.py:36-41)."""
+def save_checkpoint(directory, flat_params: np.ndarray, conf: dict, step: int = 0, optimizer=None):
+    """Flat weight file (device layout, little-endian fp32) + metadata JSON (model.py:36-41).  ``optimizer``: optional
+    ``(m, v, count)`` (OutputSequenceGenerator.optimizer_state) written beside it as ``opt_{step}.f32`` = [m | v], the count
+    into the metadata: what ``train(resume=True)`` restores.  Every file is written under a temporary name and renamed, the
+    metadata LAST: a crash in between leaves no checkpoint that ``load_checkpoint(step=None)`` would pick and then reject."""
     os.makedirs(directory, exist_ok=True)
     flat = np.ascontiguousarray(flat_params, dtype="<f4")
     if flat.size != _params.param_count(conf):
         raise ValueError("parameter count does not match the configuration")
-    flat.tofile(os.path.join(directory, f"params_{step}.f32"))
+
+    def put(name, write):
+        tmp = os.path.join(directory, name + ".tmp")
+        write(tmp)
+        os.replace(tmp, os.path.join(directory, name))
+
+    put(f"params_{step}.f32", lambda t: flat.tofile(t))
     meta = {"model": {k: v for k, v in conf.items()}, "data_prep": get_data_prep_config(), "step": int(step),
             "n_params": int(flat.size), "layout": "device (audio_to_midi_amd.params.device_layout)"}
-    with open(os.path.join(directory, f"metadata_{step}.json"), "w") as f:
-        json.dump(meta, f, indent=1)
+    if optimizer is not None:
+        m, v, count = optimizer
+        mv = np.concatenate([np.ascontiguousarray(m, dtype="<f4").reshape(-1), np.ascontiguousarray(v, dtype="<f4").reshape(-1)])
+        if mv.size != 2 * flat.size:
+            raise ValueError("optimizer moments do not match the parameter count")
+        put(f"opt_{step}.f32", lambda t: mv.tofile(t))
+        meta["optimizer"] = {"applied_updates": int(count), "file": f"opt_{step}.f32", "layout": "[m | v], device layout"}
+
+    def write_meta(t):
+        with open(t, "w") as f:
+            json.dump(meta, f, indent=1)
+    put(f"metadata_{step}.json", write_meta)
 
 
-def load_checkpoint(directory, step=None):
-    """-> (flat fp32 params, conf, step).  step=None picks the newest (infer.py:172 load_newest_checkpoint)."""
+def load_checkpoint(directory, step=None, with_optimizer: bool = False):
+    """-> (flat fp32 params, conf, step) [, (m, v, count) or None].  step=None picks the newest COMPLETE checkpoint (one whose
+    metadata exists; infer.py:172 load_newest_checkpoint)."""
     if step is None:
-        steps = [int(p[len("params_"):-len(".f32")]) for p in os.listdir(directory)
-                 if p.startswith("params_") and p.endswith(".f32")]
+        steps = [int(p[len("metadata_"):-len(".json")]) for p in os.listdir(directory)
+                 if p.startswith("metadata_") and p.endswith(".json")
+                 and os.path.exists(os.path.join(directory, "params_" + p[len("metadata_"):-len(".json")] + ".f32"))]
         if not steps:
             raise FileNotFoundError(f"no checkpoint in {directory}")
         step = max(steps)
@@ -225,4 +246,12 @@ def load_checkpoint(directory, step=None):
     flat = np.fromfile(os.path.join(directory, f"params_{step}.f32"), dtype="<f4")
     if flat.size != meta["n_params"] or flat.size != _params.param_count(meta["model"]):
         raise ValueError("checkpoint is inconsistent with its metadata")
-    return flat, meta["model"], int(step)
+    if not with_optimizer:
+        return flat, meta["model"], int(step)
+    opt = None
+    if "optimizer" in meta and os.path.exists(os.path.join(directory, meta["optimizer"]["file"])):
+        mv = np.fromfile(os.path.join(directory, meta["optimizer"]["file"]), dtype="<f4")
+        if mv.size != 2 * flat.size:
+            raise ValueError("optimizer file is inconsistent with the checkpoint")
+        opt = (mv[:flat.size], mv[flat.size:], int(meta["optimizer"]["applied_updates"]))
+    return flat, meta["model"], int(step), opt

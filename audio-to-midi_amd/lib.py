@@ -101,12 +101,15 @@ SIGNATURES = {
     "amt_advance_seed": (_i32, [_vp, _u64, _vp]),
     "amt_pack_tail": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amt_team_status": (_i32, [_vp]),
+    "amt_set_label_dtype": (_i32, [_vp, _i32]),
     "amt_tlayer_active": (_i32, [_vp]),
     "amt_tlayer_stamps": (_i32, [_vp, _vp, _i32]),
     "amt_adamw_step": (_i32, [_vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "amt_adamw_step_gated": (_i32, [_vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp, _vp]),
     "amt_optimizer_init": (_i32, [_vp, _f32]),
     "amt_optimizer_count": (_i32, [_vp]),
+    "amt_optimizer_moment_ptr": (_vp, [_vp, _i32]),
+    "amt_optimizer_set_count": (_i32, [_vp, _i32]),
     "amt_grad_accumulator_reset": (_i32, [_vp, _vp]),
     "amt_optimizer_status": (_i32, [_vp]),
     "amt_first_half_wait": (_i32, [_vp, _i32]),

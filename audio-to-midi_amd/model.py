@@ -223,7 +223,10 @@ class OutputSequenceGenerator:
         a = self._prep_audio(audio)
         B, _, T = a.shape
         S = T // 320
-        y = torch.as_tensor(labels).to(device=self.device, dtype=torch.float32).contiguous()
+        # float16 labels go in as they are (the reference's batches: grain_loader.py:88), anything else as float32
+        y = torch.as_tensor(labels)
+        y = y.to(device=self.device, dtype=torch.float16 if y.dtype == torch.float16 else torch.float32).contiguous()
+        self._label_dtype(y.dtype)
         if tuple(y.shape) != (B, S, self.n_events):
             raise ValueError(f"labels must be [{B}, {S}, {self.n_events}], got {tuple(y.shape)}")
         self._ensure_rope(rope_freqs, S)
@@ -248,6 +251,13 @@ class OutputSequenceGenerator:
         lv = loss.cpu().numpy()
         return StepOutput(float(lv[0]), float(lv[1]), grads, bool(int(valid.item())), logits)
 
+    def _label_dtype(self, dtype):
+        """Tell the context the element type of the labels of the calls that follow (include/amt.h: amt_set_label_dtype)."""
+        code = 2 if dtype == torch.float16 else 0          # AMT_F16 / AMT_F32
+        if getattr(self, "_label_code", 0) != code:
+            self._check(self._L.amt_set_label_dtype(self._h, code), "amt_set_label_dtype")
+            self._label_code = code
+
     # ------------------------------------------------------------------ the same step in two halves (DP overlap)
     def grad_bucket_split(self) -> int:
         """First flat index of the gradients completed by ``loss_and_grads_phase(1)`` (decoder, transformer,
@@ -257,7 +267,7 @@ class OutputSequenceGenerator:
     def loss_and_grads_phase(self, phase: int, audio, labels, grads_out: torch.Tensor, loss_out: torch.Tensor,
                              valid_out: torch.Tensor, scale: float = 1.0, seed: int = 0, train: bool = True, accum=(0, 1)):
         """Asynchronous half of ``loss_and_grads`` (include/amt.h: amt_forward_backward_phase).  All tensors are
-        caller-owned device tensors (audio in ``model.audio_dtype``, labels fp32); nothing is synchronised."""
+        caller-owned device tensors (audio in ``model.audio_dtype``, labels float32 or float16); nothing is synchronised."""
         if int(phase) not in (1, 2, 3):
             raise RuntimeError("amt_forward_backward_phase failed: phase must be 1, 2 or 3")
         if int(phase) == 3 and grads_out is not None:
@@ -265,6 +275,9 @@ class OutputSequenceGenerator:
         if audio.dtype != self.audio_dtype or not audio.is_cuda or not audio.is_contiguous():
             raise ValueError(f"audio must be a contiguous device tensor of dtype {self.audio_dtype} (model.audio_dtype): "
                              "this entry point converts nothing")
+        if labels.dtype not in (torch.float32, torch.float16) or not labels.is_cuda or not labels.is_contiguous():
+            raise ValueError("labels must be a contiguous device tensor of dtype float32 or float16")
+        self._label_dtype(labels.dtype)
         self._check(self._L.amt_forward_backward_accum(self._h, _lib.ptr(audio), _lib.ptr(labels), audio.shape[0],
                                                        audio.shape[2], float(scale), int(seed), 1 if train else 0,
                                                        _lib.ptr(loss_out), _lib.ptr(grads_out), _lib.ptr(valid_out), None,
@@ -345,6 +358,21 @@ class OutputSequenceGenerator:
     def optimizer_count(self) -> int:
         """Number of optimizer updates applied so far (device counter; synchronises).  include/amt.h: amt_optimizer_count."""
         return int(self._L.amt_optimizer_count(self._h))
+
+    def optimizer_state(self):
+        """(m, v, count): zero-copy device views of AdamW's moments (device layout, like the parameters) and the count of
+        applied updates - what a checkpoint needs to resume (train.py:799-831 restores the optimizer state)."""
+        pm, pv = self._L.amt_optimizer_moment_ptr(self._h, 0), self._L.amt_optimizer_moment_ptr(self._h, 1)
+        if not pm or not pv:
+            raise RuntimeError("no optimizer state: call init_optimizer first")
+        return (_DevView(pm, self.n_params, self.device).tensor(), _DevView(pv, self.n_params, self.device).tensor(),
+                self.optimizer_count())
+
+    def load_optimizer_state(self, m, v, count: int):
+        mm, vv, _ = self.optimizer_state()
+        mm.copy_(torch.as_tensor(m).reshape(-1))
+        vv.copy_(torch.as_tensor(v).reshape(-1))
+        self._check(self._L.amt_optimizer_set_count(self._h, int(count)), "amt_optimizer_set_count")
 
     def workspace_bytes(self) -> int:
         return int(self._L.amt_workspace_bytes(self._h))

@@ -115,12 +115,49 @@ class GradBucket:
         return self.buf[0:1]
 
 
+class InputBlock:
+    """The audio ``[B, 2, T]`` and the labels ``[B, S, V]`` of one batch as views of ONE contiguous byte buffer (device, or
+    pinned host): a batch travels in one copy.  The reference hands both over as float16 (grain_loader.py:88)."""
+
+    def __init__(self, audio_shape, audio_dtype, labels_shape, labels_dtype, device="cpu", pin: bool = False):
+        na = int(torch.Size(audio_shape).numel()) * torch.empty((), dtype=audio_dtype).element_size()
+        ny = int(torch.Size(labels_shape).numel()) * torch.empty((), dtype=labels_dtype).element_size()
+        self.label_offset = (na + 255) // 256 * 256
+        self.buf = torch.empty(self.label_offset + ny, dtype=torch.uint8, device=device, pin_memory=pin)
+        self.audio = self.buf[:na].view(audio_dtype).view(audio_shape)
+        self.labels = self.buf[self.label_offset:self.label_offset + ny].view(labels_dtype).view(labels_shape)
+        self.audio._amt_block = self
+        self.labels._amt_block = self
+
+    @staticmethod
+    def like(other: "InputBlock", device=None, pin: bool = False):
+        return InputBlock(other.audio.shape, other.audio.dtype, other.labels.shape, other.labels.dtype,
+                          device=other.buf.device if device is None else device, pin=pin)
+
+    def same_layout(self, other) -> bool:
+        return (isinstance(other, InputBlock) and self.buf.numel() == other.buf.numel() and self.audio.dtype == other.audio.dtype
+                and self.labels.dtype == other.labels.dtype and self.audio.shape == other.audio.shape
+                and self.labels.shape == other.labels.shape)
+
+    def __iter__(self):          # (audio, labels) = block
+        return iter((self.audio, self.labels))
+
+    def __getitem__(self, i):
+        return (self.audio, self.labels)[i]
+
+
 class HipTrainBackend:
     """Per-rank forward/backward/optimizer on the HIP library for fixed, device-resident inputs."""
 
     def __init__(self, model, audio: torch.Tensor, labels: torch.Tensor, bucket: GradBucket, scale: float = 1.0,
                  use_optimizer: bool = True, accum_steps: int = 1, fused: bool = False, optimizer_args: Optional[dict] = None):
-        audio = audio.to(dtype=model.audio_dtype)      # once, here: no conversion launch inside a captured step
+        # once, here: no conversion launch inside a captured step.  Audio in the context's input type, labels as given if they
+        # are float16 (the reference's batches), float32 otherwise; both in ONE device block (InputBlock): a batch is one upload
+        blk = InputBlock(audio.shape, model.audio_dtype, labels.shape,
+                         torch.float16 if labels.dtype == torch.float16 else torch.float32, device=audio.device)
+        blk.audio.copy_(audio)
+        blk.labels.copy_(labels)
+        audio, labels = blk.audio, blk.labels
         self.model, self.audio, self.labels, self.bucket, self.scale = model, audio, labels, bucket, float(scale)
         self.use_optimizer = use_optimizer
         self.optimizer_args = dict(optimizer_args or {})      # layer_lr_decay, b1, b2, eps, weight_decay, clip_norm (model.adamw_step)
@@ -138,7 +175,7 @@ class HipTrainBackend:
             raise ValueError("the rank's batch must be divisible by accum_steps")
         # input sets: the step reads FIXED device tensors (its launches are captured); a second set (add_input_set) lets the
         # upload of the next batch land where the NEXT step reads it while this step still reads its own (InputFeeder)
-        self._sets = [(audio, labels)]
+        self._sets = [blk]
         self.active = 0
         self._mb = self._minibatches(audio, labels)
         dev = audio.device
@@ -154,14 +191,15 @@ class HipTrainBackend:
 
     def add_input_set(self):
         """A further pair of input tensors (a copy of set 0, so that rehearsal runs on it are finite); returns its index."""
-        a0, y0 = self._sets[0]
-        self._sets.append((a0.clone(), y0.clone()))
+        blk = InputBlock.like(self._sets[0])
+        blk.buf.copy_(self._sets[0].buf)
+        self._sets.append(blk)
         return len(self._sets) - 1
 
     def use_set(self, i: int):
         """The input set the NEXT issued (or captured) step reads."""
         self.active = int(i)
-        self.audio, self.labels = self._sets[self.active]
+        self.audio, self.labels = self._sets[self.active].audio, self._sets[self.active].labels
         self._mb = self._minibatches(self.audio, self.labels)
 
     def full(self, seed: int):
@@ -218,8 +256,16 @@ class HipTrainBackend:
         self.model.loss_and_grads_phase(3, a, y, None, self.loss_buf, self.valid_buf, scale=self.scale, seed=seed, train=True,
                                         accum=(k - 1, k))
 
-    def wait_first_half(self):
-        self.model.first_half_wait()
+    def wait_first_half(self, timeout_ms: int = 10000) -> bool:
+        """True: the signal arrived.  False: it did not within ``timeout_ms``; the compute stream has then been synchronised
+        (the first range IS complete, its collective may be issued) and the signal counters re-aligned (amt_first_half_sync),
+        so a later wait pairs with the right signal again."""
+        try:
+            self.model.first_half_wait(int(timeout_ms))
+            return True
+        except RuntimeError:
+            self.model.first_half_sync()      # hipStreamSynchronize + "every signal so far is consumed"
+            return False
 
     def sync_signals(self):
         self.model.first_half_sync()
@@ -279,8 +325,8 @@ class InputFeeder:
         if backend is not None:
             while len(backend._sets) < 2:
                 backend.add_input_set()
-            self.stage = list(backend._sets[:2])                         # uploads land where a step reads them
-            self.audio, self.labels = backend._sets[0]
+            self.stage = list(backend._sets[:2])                         # uploads land where a step reads them (InputBlocks)
+            self.audio, self.labels = backend._sets[0].audio, backend._sets[0].labels
             self.up = 1 - backend.active                                 # first upload: the set the NEXT step will read
         else:
             self.audio, self.labels = audio_dev, labels_dev
@@ -295,12 +341,14 @@ class InputFeeder:
         self._ring, self._ring_ev, self._slot = None, None, 0      # two pinned host pairs for prefetch_from_host
 
     @staticmethod
-    def pin(audio, labels, audio_dtype):
-        """host batch -> pinned tensors in the dtypes the device takes (the reference's loader hands over float16 samples,
-        grain_loader.py:88)"""
-        a = torch.as_tensor(audio).to(audio_dtype).contiguous().pin_memory()
-        y = torch.as_tensor(labels).to(torch.float32).contiguous().pin_memory()
-        return a, y
+    def pin(audio, labels, audio_dtype, labels_dtype=torch.float32):
+        """host batch -> ONE pinned block in the dtypes the device takes (the reference's loader hands over float16 samples AND
+        float16 labels, grain_loader.py:88); returns its (audio, labels) views: ``prefetch(*pin(...))`` is one copy."""
+        a, y = torch.as_tensor(audio), torch.as_tensor(labels)
+        blk = InputBlock(a.shape, audio_dtype, y.shape, labels_dtype, pin=True)
+        blk.audio.copy_(a)
+        blk.labels.copy_(y)
+        return blk.audio, blk.labels
 
     def prefetch(self, host_audio: torch.Tensor, host_labels: torch.Tensor):
         if self.pending >= (1 if self.backend is not None else 2):
@@ -309,9 +357,14 @@ class InputFeeder:
         self.up ^= 1
         if self.consumed[i] is not None:
             self.consumed[i].synchronize()               # HOST wait (see the class comment); recorded a step ago
+        src = getattr(host_audio, "_amt_block", None)
+        dst = self.stage[i]
         with torch.cuda.stream(self.copy_stream):
-            self.stage[i][0].copy_(host_audio, non_blocking=True)
-            self.stage[i][1].copy_(host_labels, non_blocking=True)
+            if src is not None and src is getattr(host_labels, "_amt_block", None) and isinstance(dst, InputBlock) and dst.same_layout(src):
+                dst.buf.copy_(src.buf, non_blocking=True)        # audio and labels: one contiguous transfer
+            else:
+                dst[0].copy_(host_audio, non_blocking=True)
+                dst[1].copy_(host_labels, non_blocking=True)
             self.ready[i].record(self.copy_stream)
         self.pending += 1
 
@@ -319,8 +372,8 @@ class InputFeeder:
         """The same for an arbitrary host batch (numpy / pageable torch): converted into one of two persistent pinned pairs
         first (no pinned allocation per step); a pair is rewritten only after the upload that read it has finished."""
         if self._ring is None:
-            self._ring = [(torch.empty(self.audio.shape, dtype=self.audio.dtype).pin_memory(),
-                           torch.empty(self.labels.shape, dtype=self.labels.dtype).pin_memory()) for _ in range(2)]
+            self._ring = [InputBlock(self.audio.shape, self.audio.dtype, self.labels.shape, self.labels.dtype, pin=True)
+                          for _ in range(2)]
             self._ring_ev = [None, None]
         k = self._slot
         self._slot ^= 1
@@ -407,6 +460,13 @@ class DataParallelStep:
         if wire not in ("fp32", "bf16"):
             raise ValueError("wire must be 'fp32' or 'bf16'")
         self.wire = wire
+        # the first real --gpus N run must not be able to hang or to re-exec: prepare() runs ONE trial step of the chosen form
+        # (collectives included, its gradients discarded) when there is more than one rank; a signal time-out or a collective
+        # error on ANY rank makes EVERY rank fall back to the one-collective in-place form (overlap = False) in this process
+        self.fallback = None              # None, or the reason the overlapped form was given up
+        self.signal_timeout_ms = 10000
+        self._signal_failed = False
+        self._inject_failure = None       # tests: "signal" | "collective" makes this rank's trial step fail that way
         self._wire_buf = {}
         self.lr_base = lr_base
         self.cuda = bucket.buf.is_cuda
@@ -487,8 +547,52 @@ class DataParallelStep:
         return b.buf[b.HEAD:b.HEAD + self.split] if self.in_place else b.second_range(self.split)
 
     # ---- capture -----------------------------------------------------------------------------------
-    def prepare(self, seed: int = 0):
-        """Run once eagerly (plans the workspace: every allocation happens here), then capture the graphs."""
+    def prepare(self, seed: int = 0, trial: Optional[bool] = None):
+        """Run once eagerly (plans the workspace: every allocation happens here), capture the graphs, and - with more than
+        one rank (or ``trial=True``) - run one trial step of the overlapped form; see ``fallback``."""
+        self._prepare_graphs(seed)
+        if trial is None:
+            trial = self.world > 1 and (self.overlap or self.signal)
+        if trial and (self.overlap or self.signal):
+            reason = self._trial_step(seed)
+            if reason is not None:
+                self._fall_back(reason, seed)
+
+    def _trial_step(self, seed: int) -> Optional[str]:
+        """One step of the chosen form whose gradients are discarded; returns None or why it failed ON SOME RANK."""
+        be = self.backend
+        why = None
+        try:
+            self._issue(seed, apply=False)
+            if self.cuda:
+                torch.cuda.synchronize()
+            if self._signal_failed:
+                why = "first-half signal did not arrive within %d ms" % self.signal_timeout_ms
+            elif self._inject_failure == "collective":      # (tests: reported after taking part in every collective - peers must not hang)
+                why = "collective error: injected"
+        except RuntimeError as e:      # a collective refused the call (in-place range, stream, backend)
+            why = "collective error: " + str(e).splitlines()[0][:160]
+        self._inject_failure = None
+        getattr(be, "discard", lambda: None)()
+        if hasattr(be, "sync_signals") and self.signal:
+            be.sync_signals()
+        # every rank must take the same decision: MAX of the failure flags over a plain all-reduce of one word
+        if self.dist is not None and self.dist.is_initialized() and self.world > 1:
+            flag = torch.tensor([1.0 if why else 0.0], device=self.bucket.buf.device if self.dist.get_backend() == "nccl" else "cpu")
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+            if float(flag.item()) > 0 and why is None:
+                why = "another rank's trial step failed"
+        self.step_no = 0
+        self._signal_failed = False
+        return why
+
+    def _fall_back(self, reason: str, seed: int):
+        self.fallback = reason
+        self.overlap, self.signal = False, False
+        self._graphs, self._graph_sets = None, []
+        self._prepare_graphs(seed)
+
+    def _prepare_graphs(self, seed: int = 0):
         be = self.backend
         discard = getattr(be, "discard", lambda: None)      # fused protocol: rehearsal gradients must not reach the optimizer
         be.full(seed)
@@ -562,9 +666,17 @@ class DataParallelStep:
         """Issue one step (asynchronous on a device).  ``seed`` is used by eager steps; graph replays advance the
         device seed word instead."""
         self.step_no += 1
+        self._issue(self.step_no if seed is None else seed, apply=True)
+
+    def _issue(self, seed: int, apply: bool):
         be, b = self.backend, self.bucket
-        seed = self.step_no if seed is None else seed
         self._check_generation()
+        nsets = len(getattr(be, "_sets", [None]))
+        if self._graphs is not None and nsets != max(1, len(self._graph_sets)):
+            # (InputFeeder(backend=...) adds a second input set: constructed after prepare() its uploads would land in a set
+            # no captured graph reads, and every other batch would silently be the stale one)
+            raise RuntimeError("the backend has %d input sets but %d were captured: construct InputFeeder(backend=...) "
+                               "BEFORE DataParallelStep.prepare()" % (nsets, max(1, len(self._graph_sets))))
         if self._graphs is not None and len(self._graph_sets) > 1:
             self._graphs = self._graph_sets[be.active]      # the graph captured on the input set this step reads
         if self.signal:
@@ -576,7 +688,15 @@ class DataParallelStep:
                 self._graphs[0].replay()
             else:
                 be.full_signal(seed)
-            be.wait_first_half()
+            arrived = self._inject_failure != "signal" and be.wait_first_half(self.signal_timeout_ms)
+            if not arrived:
+                # no signal: the host has waited for the whole launch sequence instead (wait_first_half synchronised), so the
+                # collectives below are still correct - issued anyway, or the peers would sit in theirs - and the failure is
+                # recorded: prepare() turns it into the fall-back, a later step into an error
+                if self._inject_failure == "signal":
+                    torch.cuda.current_stream().synchronize()
+                    be.sync_signals()
+                self._signal_failed = True
             with torch.cuda.stream(self._comm):
                 self._mean_allreduce(self._first_range())
             self._mean_allreduce(self._second_range())
@@ -617,7 +737,12 @@ class DataParallelStep:
                 be.full(seed)
             if self.world > 1:
                 self._mean_allreduce(self._whole_range())                 # ONE bucket: flag, gradients, loss, flag
-        be.apply(self.step_no, self.lr_base)
+        if apply:
+            if self._signal_failed:
+                self._signal_failed = False
+                raise RuntimeError("the first-half signal of a step did not arrive within %d ms (the step itself completed: the "
+                                   "host synchronised instead); run with signal=False / overlap=False" % self.signal_timeout_ms)
+            be.apply(self.step_no, self.lr_base)
 
     def result(self) -> Tuple[float, bool]:
         """(loss, grads_valid) of the last step; synchronises.  grads_valid is the AND over ranks and halves (and is 0 for
@@ -644,9 +769,9 @@ class DataParallelStep:
 # ======================================================================================================
 def train(model, data_loader, *, num_steps: int, base_learning_rate: float = 1e-4, warmup_steps: int = 1000,
           layer_lr_decay: float = 0.7, weight_decay: float = 0.005, dist=None, overlap: Optional[bool] = None,
-          accum_steps: int = 1, loss_scaling: bool = False, grad_scale: float = 1.0, check_every: int = 1,
+          accum_steps: int = 1, loss_scaling: bool = False, grad_scale: float = 1.0, check_every: Optional[int] = None,
           checkpoint_dir=None, checkpoint_every: int = 20, checkpoints_to_keep: int = 3, print_every: int = 1000,
-          seed: int = 1234, log: Callable[[str], None] = print):
+          seed: int = 1234, log: Callable[[str], None] = print, resume: bool = False, save_optimizer: bool = True):
     """``train(...)`` of the reference (train.py:211-452, called from main at :872) on the HIP path.
 
     ``data_loader`` yields ``(events, audio)`` host batches - the reference's order (train.py:355) -: events
@@ -667,7 +792,13 @@ def train(model, data_loader, *, num_steps: int, base_learning_rate: float = 1e-
     * checkpoints (train.py:384-394, 799-812): every ``checkpoint_every`` steps the flat weight file + metadata
       (``infer.save_checkpoint``), the newest ``checkpoints_to_keep`` are kept; rank 0 only;
     * ``check_every``: how often the host synchronises to read (loss, valid) - the reference does every step (it decides on
-      the host); with the device gate 1 is only needed when ``loss_scaling`` is on.
+      the host); with the device gate that is only needed when ``loss_scaling`` is on.  Default: 1 with ``loss_scaling``,
+      otherwise the smaller of ``print_every`` and ``checkpoint_every`` (the step stays asynchronous in between);
+    * ``resume`` (train.py:799-831: the reference restores model AND optimizer state through its checkpoint manager, and
+      ``train(start_step=...)`` continues the count): with a checkpoint in ``checkpoint_dir`` the parameters, AdamW's moments
+      and the count of applied updates are restored and the loop continues at the checkpoint's step + 1 - schedule and bias
+      corrections go on where they stopped.  A checkpoint without optimizer state (``save_optimizer=False``, or written by
+      ``infer.save_checkpoint`` alone) restores the parameters and the step; the moments then restart from zero (logged).
 
     Out of scope, as in SURVEY.md section 2: test-set evaluation, TensorBoard, the (no-op) genetic recombination.
     Returns a dict: steps issued, updates applied, skipped steps, final scale, per-check (step, loss) history."""
@@ -685,8 +816,27 @@ def train(model, data_loader, *, num_steps: int, base_learning_rate: float = 1e-
         raise ValueError("the data loader is empty") from None
     dev = model.device
     audio_dev = torch.as_tensor(audio0).to(device=dev, dtype=model.audio_dtype).contiguous()
-    labels_dev = torch.as_tensor(events0).to(device=dev, dtype=torch.float32).contiguous()
+    ev0 = torch.as_tensor(events0)     # float16 labels (the reference's batches, grain_loader.py:88) stay float16 on the device
+    labels_dev = ev0.to(device=dev, dtype=torch.float16 if ev0.dtype == torch.float16 else torch.float32).contiguous()
     model.init_optimizer(layer_lr_decay)
+    if check_every is None:
+        cands = [c for c in (print_every, checkpoint_every if checkpoint_dir is not None else 0) if c and c > 0]
+        check_every = 1 if loss_scaling else (min(cands) if cands else max(1, num_steps))
+    start_step = 0
+    if resume and checkpoint_dir is not None and _os.path.isdir(str(checkpoint_dir)):
+        try:
+            flat, _conf, ck_step, opt = _infer.load_checkpoint(str(checkpoint_dir), with_optimizer=True)
+        except FileNotFoundError:
+            flat = None
+        if flat is not None:
+            model.load_flat(flat)
+            start_step = ck_step
+            if opt is not None:
+                model.load_optimizer_state(opt[0], opt[1], opt[2])
+                log(f"Resumed from step {ck_step}: parameters, AdamW moments and {opt[2]} applied updates restored")
+            else:
+                log(f"Resumed from step {ck_step}: parameters restored; no optimizer state in the checkpoint - moments and "
+                    "the update count restart from zero")
     bucket = GradBucket.of_model(model)
     controller = LossScaleController(scale=float(grad_scale), enabled=bool(loss_scaling))
     schedule = create_learning_rate_schedule(base_learning_rate, warmup_steps, num_steps)
@@ -711,7 +861,7 @@ def train(model, data_loader, *, num_steps: int, base_learning_rate: float = 1e-
     saved = []
     applied = model.optimizer_count()
     have_batch = True                      # batch 1 is already in the input tensors
-    for step_no in range(1, num_steps + 1):
+    for step_no in range(start_step + 1, num_steps + 1):
         if not have_batch:
             break
         feeder.take()                      # (batch k + 1 was sent on its way while step k was being issued)
@@ -750,15 +900,19 @@ def train(model, data_loader, *, num_steps: int, base_learning_rate: float = 1e-
             loss_sum, loss_n = 0.0, 0
         if checkpoint_dir is not None and rank == 0 and checkpoint_every and step_no % checkpoint_every == 0:
             torch.cuda.synchronize()
-            _infer.save_checkpoint(checkpoint_dir, model.weights_tensor().cpu().numpy(), model.conf, step=step_no)
+            opt = None
+            if save_optimizer:
+                om, ov, oc = model.optimizer_state()
+                opt = (om.cpu().numpy(), ov.cpu().numpy(), oc)
+            _infer.save_checkpoint(checkpoint_dir, model.weights_tensor().cpu().numpy(), model.conf, step=step_no, optimizer=opt)
             saved.append(step_no)
             while len(saved) > checkpoints_to_keep:
                 old = saved.pop(0)
-                for name in (f"params_{old}.f32", f"metadata_{old}.json"):
+                for name in (f"metadata_{old}.json", f"params_{old}.f32", f"opt_{old}.f32"):     # metadata first: never half a checkpoint
                     try:
                         _os.remove(_os.path.join(str(checkpoint_dir), name))
                     except OSError:
                         pass
     torch.cuda.synchronize()
     return {"steps": issued, "applied": model.optimizer_count(), "skipped": skipped, "grad_scale": controller.scale,
-            "history": history, "checkpoints": saved}
+            "history": history, "checkpoints": saved, "start_step": start_step}

@@ -234,6 +234,18 @@ def dominant_roofline(top, profile_steps):
             "numerator": "SURVEY.md 8(d): 2 N M K per GEMM / 4 B H S^2 64 per attention forward", "ridge": round(ridge, 1), **common}
 
 
+def dp_report_fields(dp):
+    """What the bench line says about the gradient exchange, from the DataParallelStep that ran it: the form actually used -
+    `dp.overlap` / `dp.signal` AFTER prepare(), whose trial step may have fallen back to the one-collective form - and why."""
+    fused = bool(getattr(dp, "in_place", False))
+    form = (("two collectives, the first overlapped with the CNN backward"
+             + (" behind a device-side signal of ONE launch sequence" if dp.signal else " (step cut in two host calls)")) if dp.overlap else "one bucket")
+    form += " (SUM, in place on the context's accumulator; 1 / world in the optimizer)" if fused else " (ReduceOp.AVG on a separate bucket)"
+    if dp.wire == "bf16":
+        form += "; bf16 on the wire, fp32 accumulation on arrival"
+    return {"grad_allreduce": form, "grad_allreduce_fallback": dp.fallback}
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` typed without a launcher: start the N ranks as child processes through
     torch.distributed.run (the reference gets its device mesh from one process, train.py:238-244, 834-842; here it is
@@ -250,6 +262,8 @@ def launch_ranks(args):
            "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
     log("bench: no WORLD_SIZE in the environment, starting the ranks:", " ".join(cmd))
     env = dict(os.environ)
+    # the pool's host driver supports dmabuf IPC only: without this RCCL / device-tensor sharing across processes fails with
+    # `hipIpcGetMemHandle: invalid argument` (the image exports it already; kept for an environment that was built by hand)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rc = subprocess.call(cmd, env=env)
     sys.exit(rc)
@@ -355,6 +369,8 @@ def main():
     ap.add_argument("--resident-inputs", action="store_true",
                     help="replay the same HBM-resident batch every step (rounds 1-3) instead of uploading a fresh batch per step "
                          "from pinned host memory on a copy stream (train.py:280 uploads every minibatch)")
+    ap.add_argument("--labels-fp32", action="store_true",
+                    help="labels as float32 (default: float16, the dtype the reference's loader hands over, grain_loader.py:88)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-fused-optimizer", action="store_true",
@@ -411,7 +427,10 @@ def main():
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # a collective that never completes fails the run after two minutes (non-zero exit, no silent hang); what CAN be
+            # recovered in-process - a missing first-half signal, a collective that raises - is DataParallelStep's fall-back
+            import datetime
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=120))
 
     import audio_to_midi_amd as amt
     from audio_to_midi_amd import lib as amtlib
@@ -421,7 +440,9 @@ def main():
         model.set_attn_fp8(True)
     audio_np, labels_np = amt.synth.make_batch_fast(B_PER_GPU, T_SAMPLES, seed=100 + rank)
     audio = torch.from_numpy(audio_np).to(dev, model.audio_dtype)    # inputs resident in HBM
-    labels = torch.from_numpy(labels_np).to(dev)
+    # labels in the reference loader's own dtype (`midi_events.astype(np.float16)`, grain_loader.py:88); --labels-fp32: float32
+    label_dtype = torch.float32 if args.labels_fp32 else torch.float16
+    labels = torch.from_numpy(labels_np).to(dev, label_dtype)
     # One flat fp32 bucket (audio_to_midi_amd.train.GradBucket): [finite flag of the whole step, 3 pad | gradients
     # (amt layout) | loss, finite flag of the first half].  With N > 1 it is averaged over the ranks (ReduceOp.AVG:
     # mean over the global batch, train.py:62; a flag stays 1.0 iff every rank's is 1).  The step itself - two-phase
@@ -462,10 +483,10 @@ def main():
     feeder, host_pool = None, []
     if not args.resident_inputs:
         feeder = amt_train.InputFeeder(backend=backend)
-        host_pool = [amt_train.InputFeeder.pin(audio_np, labels_np, model.audio_dtype)]
+        host_pool = [amt_train.InputFeeder.pin(audio_np, labels_np, model.audio_dtype, label_dtype)]      # one pinned block per batch: one upload
         for j in range(1, 4):
             an, yn = amt.synth.make_batch_fast(B_PER_GPU, T_SAMPLES, seed=1000 * j + rank)
-            host_pool.append(amt_train.InputFeeder.pin(an, yn, model.audio_dtype))
+            host_pool.append(amt_train.InputFeeder.pin(an, yn, model.audio_dtype, label_dtype))
         feeder.prefetch(*host_pool[0])
     step_i = [0]
 
@@ -562,10 +583,9 @@ def main():
                                    + ("" if args.no_optimizer else ", AdamW + global-norm clip + bf16 weight refresh"),
                        "global_batch": world * B_PER_GPU, "clip_seconds": CLIP_SECONDS, "frames": T_SAMPLES // 320,
                        "parallelism": f"dp{world}", "hipgraph": graph is not None,
-                       "grad_allreduce": ((("two collectives, the first overlapped with the CNN backward" + (" behind a device-side signal of ONE launch sequence" if dp.signal else " (step cut in two host calls)")) if overlap else "one bucket")
-                                          + (" (SUM, in place on the context's accumulator; 1 / world in the optimizer)" if fused else " (ReduceOp.AVG on a separate bucket)")
-                                          + ("; bf16 on the wire, fp32 accumulation on arrival" if args.wire == "bf16" else "")) if world > 1 or overlap else None,
+                       **(dp_report_fields(dp) if world > 1 or overlap else {"grad_allreduce": None}),
                        "optimizer": None if args.no_optimizer else ("fused: norm pass + commit pass over the context's gradient accumulator" if fused else "grads_finalize + adamw_compute + adamw_apply over the bucket"),
+                       "inputs": "audio float16, labels " + ("float32" if args.labels_fp32 else "float16 (grain_loader.py:88)") + ", one contiguous block per batch",
                        "weights": "random init (Equinox distributions), 11606230 params"},
             "model_tflops": round(world * FLOPS_PER_STEP / (elapsed / args.steps) / 1e12, 2),
             "host_issue_ms_per_step": round(host_issue_ms, 4),

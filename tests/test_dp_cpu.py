@@ -267,7 +267,7 @@ class _OracleInPlaceBackend:
         self.applied.append(open_)
 
 
-def _inplace_worker(rank, world, port, q, poison, overlap, accum, wire="fp32"):
+def _inplace_worker(rank, world, port, q, poison, overlap, accum, wire="fp32", inject=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -283,11 +283,18 @@ def _inplace_worker(rank, world, port, q, poison, overlap, accum, wire="fp32"):
                                accum_steps=accum)
     dp = train.DataParallelStep(be, bucket, split, dist=dist, overlap=overlap, graph=True, lr_base=1e-2, wire=wire)
     assert dp.in_place and be.world == world
+    if inject is not None and rank == world - 1:
+        dp._inject_failure = inject                        # this rank's trial step of the overlapped form "fails"
     dp.prepare(seed=0)
     assert float(bucket.grads.abs().max()) == 0.0          # the rehearsal's gradients were discarded
     dp.step()
     loss, valid = dp.result()
-    q.put((rank, loss, valid, be.applied[-1], be.flat.copy(), float(bucket.grads.abs().max())))
+    if inject is not None:
+        import bench
+        q.put((rank, loss, valid, be.applied[-1], be.flat.copy(), float(bucket.grads.abs().max()), dp.overlap, dp.fallback,
+               bench.dp_report_fields(dp)))
+    else:
+        q.put((rank, loss, valid, be.applied[-1], be.flat.copy(), float(bucket.grads.abs().max())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -325,6 +332,38 @@ def test_in_place_step_n_ranks_equal_one_rank(world, poison, overlap, accum):
         else:
             assert np.linalg.norm(flat - ref_new) < 1e-5 * np.linalg.norm(ref_new - flat0), rank
             assert np.array_equal(flat, outs[0][4])                  # replicas stay bit-identical
+
+
+def test_a_failed_trial_step_makes_every_rank_fall_back_to_one_collective():
+    """DataParallelStep.prepare() runs ONE trial step of the overlapped form when there is more than one
+    rank.  A failure seen by ONE rank (here injected on the last rank) becomes the decision of EVERY rank through a MAX
+    all-reduce of one word: all fall back, in the same process, to the one-collective in-place form - the one `north_star`
+    describes - and say so in the bench line (`grad_allreduce_fallback`).  The step that follows is the plain step."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_inplace_worker, args=(r, world, port, q, False, True, 1, "fp32", "collective")) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in range(world)], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle import optim
+    conf = _conf()
+    params = np_model.init_params(conf, seed=3, gamma=1.0)
+    audio, labels = synth.make_batch(4, 320 * 20, seed=9)
+    _, _, g = torch_model.loss_and_grads(params, audio, labels, conf)
+    flat0 = P.equinox_to_flat(params, conf).astype(np.float64)
+    ref_new = optim.AdamWChain(flat0.size).update(flat0, P.equinox_to_flat(g, conf).astype(np.float64), 1e-2)
+    for rank, loss, valid, applied, flat, gmax, overlap, fallback, fields in outs:
+        assert overlap is False and fallback is not None, (rank, overlap, fallback)
+        assert ("injected" in fallback) == (rank == world - 1)       # the other rank learnt it from the agreement word
+        assert fields["grad_allreduce_fallback"] == fallback and "one bucket" in fields["grad_allreduce"]
+        assert valid and applied and gmax == 0.0
+        assert np.linalg.norm(flat - ref_new) < 1e-5 * np.linalg.norm(ref_new - flat0), rank
+        assert np.array_equal(flat, outs[0][4])
 
 
 @pytest.mark.parametrize("world,overlap", [(2, False), (4, True)])

@@ -136,3 +136,27 @@ def test_checkpoint_round_trip(tmp_path, small_conf):
         infer.save_checkpoint(tmp_path, flat[:-1], small_conf)
     with pytest.raises(FileNotFoundError):
         infer.load_checkpoint(tmp_path / "nope")
+
+
+def test_checkpoint_is_complete_or_absent_and_carries_the_optimizer_state(tmp_path, small_conf):
+    """a checkpoint is written under temporary names and renamed, the metadata last, so the newest one
+    `load_checkpoint(step=None)` picks is always complete; AdamW's moments and the count of applied updates travel with
+    it (the reference restores its optimizer state through its checkpoint manager, train.py:799-831)."""
+    import os
+    from audio_to_midi_amd import params as P
+    n = P.param_count(small_conf)
+    flat = np.arange(n, dtype=np.float32) * 1e-6
+    infer.save_checkpoint(tmp_path, flat, small_conf, step=20, optimizer=(flat + 1, flat + 2, 17))
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".tmp")]
+    got, conf, step, opt = infer.load_checkpoint(tmp_path, with_optimizer=True)
+    assert step == 20 and np.array_equal(got, flat) and opt[2] == 17
+    assert np.array_equal(opt[0], flat + 1) and np.array_equal(opt[1], flat + 2)
+    # a crash between the weight file and the metadata of a LATER step: that step is not a checkpoint
+    (flat * 3).astype("<f4").tofile(os.path.join(tmp_path, "params_40.f32"))
+    got, _, step = infer.load_checkpoint(tmp_path)
+    assert step == 20 and np.array_equal(got, flat)
+    # a checkpoint without optimizer state loads with opt = None
+    infer.save_checkpoint(tmp_path, flat, small_conf, step=60)
+    assert infer.load_checkpoint(tmp_path, with_optimizer=True)[3] is None
+    with pytest.raises(ValueError):
+        infer.save_checkpoint(tmp_path, flat, small_conf, step=80, optimizer=(flat[:-1], flat, 1))

@@ -501,3 +501,76 @@ def test_captured_optimizer_takes_the_two_launch_form(small_conf, monkeypatch):
     torch.cuda.synchronize()
     assert int(flag.item()) == 1 and not torch.equal(model.weights_tensor(), p)
     assert model.optimizer_status() == 1 and model.optimizer_count() == 4
+
+
+@pytest.mark.gpu
+def test_float16_labels_go_in_as_they_are(small_conf):
+    """The reference's batches carry float16 labels (`midi_events.astype(np.float16)`, /root/reference/grain_loader.py:88):
+    amt_set_label_dtype(AMT_F16) makes amt_forward_backward* read them without a conversion.  On labels that are float16
+    values the two forms are the same computation: same loss, same gradients (up to the weight-gradient atomics)."""
+    import numpy as np
+    import torch
+    import audio_to_midi_amd as amt
+    from audio_to_midi_amd import synth
+    model = amt.OutputSequenceGenerator(small_conf, key=5, dtype="bfloat16", gamma=1.0)
+    audio, labels = synth.make_batch(2, 320 * 100, seed=8)
+    y16 = torch.from_numpy(labels).to(torch.float16)
+    a = model.loss_and_grads(torch.from_numpy(audio), y16, seed=3, train=True)
+    b = model.loss_and_grads(torch.from_numpy(audio), y16.to(torch.float32), seed=3, train=True)
+    assert abs(a.loss - b.loss) <= 1e-6 * abs(b.loss)
+    assert float((a.grads_flat - b.grads_flat).norm() / b.grads_flat.norm()) < 1e-5
+    # and the float16 rounding of the labels itself moves the loss by less than 1e-3 relative
+    c = model.loss_and_grads(torch.from_numpy(audio), torch.from_numpy(labels), seed=3, train=True)
+    assert abs(a.loss - c.loss) <= 1e-3 * abs(c.loss)
+
+
+@pytest.mark.gpu
+def test_input_feeder_uploads_one_block_per_batch(small_conf):
+    """HipTrainBackend keeps audio and labels of an input set in ONE device block and InputFeeder.pin builds the matching
+    pinned block, so a fresh batch is one host-to-device copy (train.py:280 uploads every minibatch)."""
+    import torch
+    import audio_to_midi_amd as amt
+    from audio_to_midi_amd import synth, train as T
+    model = amt.OutputSequenceGenerator(small_conf, key=5, dtype="bfloat16", gamma=1.0)
+    audio, labels = synth.make_batch(2, 320 * 100, seed=8)
+    bucket = T.GradBucket.of_model(model)
+    be = T.HipTrainBackend(model, torch.from_numpy(audio).cuda(), torch.from_numpy(labels).to("cuda", torch.float16), bucket, fused=True)
+    feeder = T.InputFeeder(backend=be)
+    assert isinstance(be._sets[0], T.InputBlock) and len(be._sets) == 2
+    a2, y2 = synth.make_batch(2, 320 * 100, seed=9)
+    ha, hy = T.InputFeeder.pin(a2, y2, model.audio_dtype, torch.float16)
+    assert ha._amt_block is hy._amt_block and ha.is_pinned()
+    feeder.prefetch(ha, hy)
+    feeder.take()
+    torch.cuda.synchronize()
+    assert torch.equal(be.audio.cpu(), ha) and torch.equal(be.labels.cpu(), hy)
+    assert be.labels.dtype == torch.float16 and be.audio.data_ptr() == be._sets[be.active].buf.data_ptr()
+
+
+@pytest.mark.gpu
+def test_train_resumes_where_a_checkpoint_left_off(small_conf, tmp_path):
+    """train(resume=True) restores parameters, AdamW moments and the count of applied updates from the newest checkpoint and
+    continues at its step + 1 (the reference: checkpoint manager + `start_step`, /root/reference/train.py:211, 799-831): 6 steps
+    in one go and 4 + 2 resumed steps on the same batches end with the same parameters (dropout off: p = 0 in this conf)."""
+    import torch
+    import audio_to_midi_amd as amt
+    from audio_to_midi_amd import synth, train as T
+    conf = dict(small_conf)
+    conf["transformer_dropout_rate"] = 0.0
+    batches = [synth.make_batch(2, 320 * 60, seed=40 + i) for i in range(6)]
+
+    def loader(lo, hi):
+        for a, y in batches[lo:hi]:
+            yield y, a
+
+    kw = dict(base_learning_rate=1e-3, warmup_steps=2, checkpoint_every=2, print_every=0, log=lambda *_: None)
+    m1 = amt.OutputSequenceGenerator(conf, key=11, dtype="float32", gamma=1.0)
+    r1 = T.train(m1, loader(0, 6), num_steps=6, checkpoint_dir=tmp_path / "a", **kw)
+    w1 = m1.weights_tensor().clone()
+    m2 = amt.OutputSequenceGenerator(conf, key=11, dtype="float32", gamma=1.0)
+    T.train(m2, loader(0, 4), num_steps=4, checkpoint_dir=tmp_path / "b", **kw)
+    m3 = amt.OutputSequenceGenerator(conf, key=99, dtype="float32", gamma=1.0)      # other weights: everything comes from the checkpoint
+    r3 = T.train(m3, loader(4, 6), num_steps=6, checkpoint_dir=tmp_path / "b", resume=True, **kw)
+    assert r3["start_step"] == 4 and r3["applied"] == 6 == r1["applied"]
+    rel = float((m3.weights_tensor() - w1).norm() / w1.norm())
+    assert rel < 1e-5, rel
