@@ -159,7 +159,7 @@ def _train_rank(rank, world, port, q, tmp):
 
     logs = []
     out = train.train(model, loader(), num_steps=12, base_learning_rate=2e-3, warmup_steps=3, dist=dist, checkpoint_dir=tmp,
-                      checkpoint_every=10, print_every=0, log=logs.append)
+                      checkpoint_every=10, print_every=0, check_every=1, log=logs.append)      # check_every=1: the host reads every step's flag
     q.put((rank, out["steps"], out["applied"], out["skipped"], [h[0] for h in out["history"]], [h[1] for h in out["history"]],
            model.weights_tensor().cpu().numpy().copy(), sorted(os.listdir(tmp))))
     dist.barrier()
@@ -196,7 +196,7 @@ def test_train_entry_across_rank_processes(tmp_path):
         _, steps, applied, skipped, hsteps, hloss, w, files = outs[r]
         assert steps == 12 and applied == 11 and skipped == 1 and 6 not in hsteps and len(hsteps) == 11, (r, steps, applied, skipped, hsteps)
         assert np.isfinite(w).all()
-        assert files == (["metadata_10.json", "params_10.f32"] if r == 0 else [])        # rank 0 writes the checkpoints
+        assert files == (["metadata_10.json", "opt_10.f32", "params_10.f32"] if r == 0 else [])        # rank 0 writes the checkpoints
     assert np.array_equal(outs[0][6], outs[1][6])
     assert np.allclose(outs[0][5], outs[1][5], rtol=1e-6)        # the loss every rank reports is the global mean
     assert np.mean(outs[0][5][-3:]) < np.mean(outs[0][5][:3])
