@@ -11,12 +11,13 @@ The output is stamped with `_build_id` (bench.build_id(): sha-256 over csrc/) so
 build it was taken from, and - when the stats CSV is given - carries each class's average launch duration under graph
 replay (`avg_launch_us_graph`) and the CSV's name (`_rocprof_stats`).
 
-gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE is in KB and reports exactly half of the
-bytes of wide coalesced reads -> x2; WRITE_SIZE (KB) is exact for 16-byte-per-lane stores and float atomics.
-bytes = (2*FETCH + WRITE) * 1024 (`hbm_bytes_per_launch`).  The x2 is calibrated for wide coalesced streaming reads only:
-for classes whose launches carry weight-gradient workgroups (atomics, 64-byte row segments: `fetch_correction` =
-"uncalibrated") the x1 figure is reported beside it (`hbm_bytes_per_launch_fetch_x1`) - the truth lies between the two
-(VERDICT r3, weak 15).
+gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE is in KB and reports exactly half of the bytes of 16-byte-per-lane
+reads -> x2; WRITE_SIZE (KB) is exact for 16-byte-per-lane stores and float atomics.  bytes = (2*FETCH + WRITE) * 1024
+(`hbm_bytes_per_launch`).  Round 5 calibrated the two access shapes of the weight-gradient workgroups that rounds 3-4 had
+left open (scratch/fetch_calib.hip, profiles/r05_fetch_calibration.txt): 128-byte row segments of panels whose rows are
+512 / 1024 / 2048 bytes apart read FETCH_SIZE x 1024 = 0.500 of the known bytes, exactly like a contiguous stream; 64-byte
+fp32 atomic-add segments read WRITE_SIZE = the bytes added and FETCH_SIZE = 0.  So x2 holds for every class of the step
+and `hbm_bytes_per_launch` is ONE number (the x1 figure of round 4's files is gone).
 """
 import collections, csv, glob, json, re, sys
 
@@ -33,7 +34,7 @@ def classify(name):
     if "ffn_fwd_fused_kernel" in name and "ffn_qkv" not in name:
         return "attn_out_fused" if "Lb0" in name else "ffn_fwd_fused"
     for key, cls in (("ffn_fwd_big_kernel", "ffn_fwd_big"), ("adamw_norm_kernel", "adamw_norm"), ("adamw_commit_kernel", "adamw_commit"), ("adamw_persist_kernel", "adamw_persist"),
-                     ("ffn_qkv_fwd_fused_kernel", "ffn_qkv_fwd_fused"), ("ffn_bwd_fused_kernel", "ffn_bwd_fused+wgrad"),
+                     ("ffn_qkv_fwd_fused_kernel", "ffn_qkv_fwd_fused"), ("tlayer_fwd_kernel", "tlayer_fwd"), ("ffn_bwd_fused_kernel", "ffn_bwd_fused+wgrad"),
                      ("block_run_fwd_kernel", "block_run_fwd"),
                      ("gemm_tn_group_kernel", "gemm_tn_wgrad_group<bf16>"), ("dwblock_bwd_kernel", "dwblock_bwd"),
                      ("block_fwd_fused_kernel", "block_fwd_fused"), ("block_bwd_fused_kernel", "block_bwd_fused+wgrad"),
@@ -102,13 +103,10 @@ if __name__ == "__main__":
     for c in fe:
         if c in wr and fe[c][1] == wr[c][1]:
             n = fe[c][1]
-            atom = "wgrad" in c or "gemm_tn" in c
             out[c] = {"launches_sampled": n, "fetch_size_kb_raw_per_launch": fe[c][0] / n,
                       "write_size_kb_per_launch": wr[c][0] / n,
                       "hbm_bytes_per_launch": (2 * fe[c][0] + wr[c][0]) * 1024 / n,
-                      "hbm_bytes_per_launch_fetch_x1": (fe[c][0] + wr[c][0]) * 1024 / n,
-                      "fetch_correction": "uncalibrated (weight-gradient workgroups: atomics, 64-byte segments): between x1 and x2" if atom
-                                          else "x2 (wide coalesced reads, MI355X_MICROARCH.md)"}
+                      "fetch_correction": "x2 (16-byte-per-lane reads incl. 128-byte row segments; atomics fetch nothing: profiles/r05_fetch_calibration.txt)"}
             if c in gd:
                 out[c]["avg_launch_us_graph"] = round(gd[c], 2)
     # the whole run (bench.py --steps 3 --warmup 1 --no-graph: 4 training steps + the eager preparation runs; divide by the
@@ -116,8 +114,7 @@ if __name__ == "__main__":
     ft, fn, fs = total(sys.argv[1], "FETCH_SIZE")
     wt, wn, ws = total(sys.argv[2], "WRITE_SIZE")
     out["_run_total"] = {"fetch_size_kb_raw": ft, "write_size_kb": wt, "launches": fn, "training_steps": fs,
-                         "hbm_bytes_fetch_x2": (2 * ft + wt) * 1024, "hbm_bytes_fetch_x1": (ft + wt) * 1024,
-                         "hbm_bytes_per_step_fetch_x2": (2 * ft + wt) * 1024 / max(fs, 1),
-                         "hbm_bytes_per_step_fetch_x1": (ft + wt) * 1024 / max(fs, 1)}
+                         "hbm_bytes": (2 * ft + wt) * 1024, "hbm_bytes_per_step": (2 * ft + wt) * 1024 / max(fs, 1),
+                         "hbm_bytes_written_per_step": wt * 1024 / max(fs, 1)}
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))
