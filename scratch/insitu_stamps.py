@@ -9,7 +9,7 @@ from audio_to_midi_amd import lib as amtlib
 dev = torch.device("cuda", 0)
 model = amt.OutputSequenceGenerator(amt.model_config, key=1234, dtype="bfloat16", device=dev)
 a, y = amt.synth.make_batch_fast(8, 160000, seed=100)
-audio = torch.from_numpy(a).to(dev, torch.bfloat16); labels = torch.from_numpy(y).to(dev)
+audio = torch.from_numpy(a).to(dev, model.audio_dtype); labels = torch.from_numpy(y).to(dev)
 grads = torch.zeros(model.n_params, dtype=torch.float32, device=dev)
 model.init_optimizer()
 def fwd_bwd(seed):
